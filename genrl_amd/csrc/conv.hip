@@ -1,0 +1,173 @@
+// Stride-2 convolution data movement for the GenRL encoder/decoder (gfx950).
+//
+// Activations are kept NHWC ([pixel][channel]) so that (a) the image channel-LayerNorm
+// (ImgChLayerNorm, agent/dreamer_utils.py:1031-1040) is a plain row LayerNorm and (b) every
+// convolution product is a dense row-major GEMM on the fp32-MFMA engine (gemm.hip):
+//
+//   Conv2d k,s=2 (encoder, :578-589)      y[(n,oh,ow), co] = cols[(n,oh,ow),(ci,kh,kw)] . W[co,(ci,kh,kw)]^T
+//   ConvTranspose2d k,s=2 (decoder, :654-671)  cols[(n,ih,iw),(co,kh,kw)] = x[(n,ih,iw), ci] . W[ci,(co,kh,kw)]
+//                                          y[n,oh,ow,co] = bias[co] + sum_{kh,kw} cols[(n,(oh-kh)/2,(ow-kw)/2),(co,kh,kw)]
+//
+// The two kernels here are the patch gather (im2col) and its adjoint in gather form (col2im): both
+// pure data movement, HBM-bound, no atomics, deterministic.  The reference's weight layouts
+// (Cout,Cin,kh,kw) / (Cin,Cout,kh,kw) are used as-is: the K order of `cols` is (c,kh,kw).
+// Index arithmetic is hoisted: per block a K-entry offset table and per-pixel bases live in LDS,
+// so the inner loops contain no integer division.
+#include "common.h"
+
+namespace {
+
+constexpr int RP = 32;  // output pixels per workgroup
+
+// cols[(n,a,b), (c,kh,kw)] = in[n, 2a+kh, 2b+kw, c]
+// MODE 0: in = f32 NHWC ; MODE 1: in = f32 NCHW ; MODE 2: in = u8 NCHW with x/255-0.5 fused
+// (WorldModel.preprocess, agent/dreamer.py:294-295).
+template <int MODE>
+__global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ in_, float* __restrict__ cols, long M,
+                                                     int Hi, int Wi, int C, int k, int Ho, int Wo) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int K = C * k * k;
+  int* in_off = reinterpret_cast<int*>(smem);
+  long* base = reinterpret_cast<long*>(smem + ((K * 4 + 15) / 16) * 16);
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  for (int kk = tid; kk < K; kk += 256) {
+    const int c = kk / (k * k), r = kk % (k * k), kh = r / k, kw = r % k;
+    in_off[kk] = (MODE == 0) ? (kh * Wi + kw) * C + c : (c * Hi + kh) * Wi + kw;
+  }
+  const long m0 = (long)blockIdx.x * RP;
+  if (tid < RP) {
+    const long m = m0 + tid;
+    if (m < M) {
+      const long n = m / (Ho * Wo);
+      const int p = (int)(m % (Ho * Wo)), a = p / Wo, b = p % Wo;
+      base[tid] = (MODE == 0) ? ((n * Hi + 2 * a) * Wi + 2 * b) * (long)C
+                              : (n * C * Hi + 2 * a) * (long)Wi + 2 * b;
+    }
+  }
+  __syncthreads();
+  for (int pix = threadIdx.y; pix < RP; pix += 4) {
+    const long m = m0 + pix;
+    if (m >= M) break;
+    const long bs = base[pix];
+    float* out = cols + m * K;
+    for (int kk = threadIdx.x; kk < K; kk += 64) {
+      float v;
+      if (MODE == 2)
+        v = (float)reinterpret_cast<const uint8_t*>(in_)[bs + in_off[kk]] / 255.0f - 0.5f;
+      else
+        v = reinterpret_cast<const float*>(in_)[bs + in_off[kk]];
+      out[kk] = v;
+    }
+  }
+}
+
+// out[n,y,x,c] = bias[c] + sum_{kh=y mod 2.., kw=x mod 2..} cols[(n,(y-kh)/2,(x-kw)/2), (c,kh,kw)]
+// cols rows are (n,a,b) over Ha x Wa; out is Ho x Wo with Ho = 2*(Ha-1)+k.
+// OUT_NCHW: write out[n,c,y,x] instead of NHWC.
+template <bool OUT_NCHW>
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ cols, const float* __restrict__ bias,
+                                                     float* __restrict__ out, long Mout, int Ha, int Wa, int C, int k,
+                                                     int Ho, int Wo) {
+  __shared__ long rowoff[RP][9];
+  __shared__ int kofs[RP][9];
+  __shared__ int nterm[RP];
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  const int kk = k * k;
+  const long Kc = (long)C * kk;
+  const long m0 = (long)blockIdx.x * RP;
+  if (tid < RP) {
+    const long m = m0 + tid;
+    int nt = 0;
+    if (m < Mout) {
+      const long n = m / (Ho * Wo);
+      const int p = (int)(m % (Ho * Wo)), y = p / Wo, x = p % Wo;
+      for (int kh = y & 1; kh < k; kh += 2) {
+        const int a = (y - kh) / 2;
+        if (y - kh < 0 || a >= Ha) continue;
+        for (int kw = x & 1; kw < k; kw += 2) {
+          const int b = (x - kw) / 2;
+          if (x - kw < 0 || b >= Wa) continue;
+          rowoff[tid][nt] = ((n * Ha + a) * Wa + b) * Kc;
+          kofs[tid][nt] = kh * k + kw;
+          ++nt;
+        }
+      }
+    }
+    nterm[tid] = nt;
+  }
+  __syncthreads();
+  for (int pix = threadIdx.y; pix < RP; pix += 4) {
+    const long m = m0 + pix;
+    if (m >= Mout) break;
+    const int nt = nterm[pix];
+    const long n = m / (Ho * Wo);
+    const int p = (int)(m % (Ho * Wo));
+    for (int c = threadIdx.x; c < C; c += 64) {
+      float acc = bias ? bias[c] : 0.f;
+      for (int t = 0; t < nt; ++t) acc += cols[rowoff[pix][t] + (long)c * kk + kofs[pix][t]];
+      if (OUT_NCHW)
+        out[(n * C + c) * (long)(Ho * Wo) + p] = acc;
+      else
+        out[m * C + c] = acc;
+    }
+  }
+}
+
+// out[b, c, p] = in[b, p, c]   (NHWC <-> NCHW flatten of the encoder embedding, :621)
+__global__ void transpose_last2_kernel(const float* __restrict__ in, float* __restrict__ out, long B, int P, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * P * C) return;
+  const long b = i / ((long)P * C);
+  const int r = (int)(i % ((long)P * C)), c = r / P, p = r % P;
+  out[i] = in[(b * P + p) * C + c];
+}
+
+}  // namespace
+
+extern "C" {
+
+// in_mode: 0 f32 NHWC, 1 f32 NCHW, 2 u8 NCHW (+preprocess). cols is [N*Ho*Wo, C*k*k].
+int genrl_im2col_s2(const void* in, float* cols, int Nimg, int Hi, int Wi, int C, int k, int in_mode, void* stream) {
+  const int Ho = (Hi - k) / 2 + 1, Wo = (Wi - k) / 2 + 1;
+  const long M = (long)Nimg * Ho * Wo;
+  if (M <= 0) return GENRL_OK;
+  if (k > 6 || k < 1) return GENRL_EINVAL;
+  const int K = C * k * k;
+  const size_t smem = ((K * 4 + 15) / 16) * 16 + RP * sizeof(long);
+  dim3 grid(cdiv(M, RP)), block(64, 4);
+  hipStream_t s = (hipStream_t)stream;
+  if (in_mode == 0) hipLaunchKernelGGL((im2col_kernel<0>), grid, block, smem, s, in, cols, M, Hi, Wi, C, k, Ho, Wo);
+  else if (in_mode == 1) hipLaunchKernelGGL((im2col_kernel<1>), grid, block, smem, s, in, cols, M, Hi, Wi, C, k, Ho, Wo);
+  else if (in_mode == 2) hipLaunchKernelGGL((im2col_kernel<2>), grid, block, smem, s, in, cols, M, Hi, Wi, C, k, Ho, Wo);
+  else return GENRL_EINVAL;
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}
+
+// cols is [N*Ha*Wa, C*k*k]; out is N x (2(Ha-1)+k) x (2(Wa-1)+k) x C (NHWC) or NCHW when out_nchw.
+// If Ho_override/Wo_override > 0 they give the output size (conv dgrad onto an input whose last
+// rows/cols were not covered by any window).
+int genrl_col2im_s2(const float* cols, const float* bias, float* out, int Nimg, int Ha, int Wa, int C, int k,
+                    int Ho_override, int Wo_override, int out_nchw, void* stream) {
+  const int Ho = Ho_override > 0 ? Ho_override : 2 * (Ha - 1) + k;
+  const int Wo = Wo_override > 0 ? Wo_override : 2 * (Wa - 1) + k;
+  const long M = (long)Nimg * Ho * Wo;
+  if (M <= 0) return GENRL_OK;
+  if (k > 6 || k < 1) return GENRL_EINVAL;
+  dim3 grid(cdiv(M, RP)), block(64, 4);
+  hipStream_t s = (hipStream_t)stream;
+  if (out_nchw) hipLaunchKernelGGL((col2im_kernel<true>), grid, block, 0, s, cols, bias, out, M, Ha, Wa, C, k, Ho, Wo);
+  else hipLaunchKernelGGL((col2im_kernel<false>), grid, block, 0, s, cols, bias, out, M, Ha, Wa, C, k, Ho, Wo);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}
+
+int genrl_transpose_last2(const float* in, float* out, long B, int P, int C, void* stream) {
+  const long n = B * P * C;
+  if (n <= 0) return GENRL_OK;
+  hipLaunchKernelGGL(transpose_last2_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, B, P, C);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,526 @@
+// Distribution / loss kernels of the GenRL hot path (gfx950): unimix categorical latents
+// (softmax -> 1% uniform mix -> exponential-race sample with straight-through gradient), the
+// categorical KL, two-hot symlog heads, the lambda-return scan, the MSE image likelihood and the
+// max-cosine imagination reward.  All small-row, HBM/L2-bound work: latent groups of K classes
+// live in aligned sub-groups of a 64-lane wavefront and are reduced with shuffles.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+// ---- one categorical latent of K classes held by an aligned group of W lanes ----
+// p = softmax(l); u = a*p + (1-a)/K; pn = u / sum(u)       (OneHotDist.__init__,
+// agent/dreamer_utils.py:179-183 + torch Categorical(probs=) renormalisation)
+template <int W>
+struct Cat {
+  float p, pn, s;  // softmax prob, renormalised unimix prob, sum(u)
+  __device__ __forceinline__ void init(float logit, bool valid, int K, float a) {
+    const float l = valid ? logit : -INFINITY;
+    const float m = group_max<W>(l);
+    const float e = valid ? expf(l - m) : 0.f;
+    const float z = group_sum<W>(e);
+    p = e / z;
+    const float u = valid ? a * p + (1.0f - a) / K : 0.f;
+    s = group_sum<W>(u);
+    pn = u / s;
+  }
+  // given g = dL/dpn (per class), return dL/dlogit
+  __device__ __forceinline__ float backward(float g, bool valid, float a) const {
+    const float gi = valid ? g : 0.f;
+    const float dot = group_sum<W>(gi * pn);
+    const float du = (gi - dot) / s;
+    const float dp = a * du;
+    const float dot2 = group_sum<W>(valid ? dp * p : 0.f);
+    return valid ? p * (dp - dot2) : 0.f;
+  }
+};
+
+__device__ __forceinline__ float clamp_log(float p) {
+  const float eps = 1.1920928955078125e-07f;  // torch.finfo(float32).eps (probs_to_logits clamp)
+  return logf(fminf(fmaxf(p, eps), 1.0f - eps));
+}
+
+// argmax within a group of W lanes, first index wins ties (torch.argmax on CPU).
+template <int W>
+__device__ __forceinline__ int group_argmax(float v, int idx) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ov > v || (ov == v && oi < idx)) {
+      v = ov;
+      idx = oi;
+    }
+  }
+  return idx;
+}
+
+// sample[g,k] = onehot(argmax_k pn/q) (q == nullptr: mode = argmax pn).  Also optionally writes pn.
+template <int W>
+__global__ __launch_bounds__(256) void onehot_fwd_kernel(const float* __restrict__ logits,
+                                                         const float* __restrict__ q, float* __restrict__ sample,
+                                                         float* __restrict__ probs, long G, int K, float a) {
+  const long g = ((long)blockIdx.x * 256 + threadIdx.x) / W;
+  const int k = threadIdx.x % W;
+  const bool valid = (g < G) && (k < K);
+  const long gi = g < G ? g : G - 1;
+  const float l = valid ? logits[gi * K + k] : 0.f;
+  Cat<W> c;
+  c.init(l, valid, K, a);
+  float score = valid ? (q ? c.pn / q[gi * K + k] : c.pn) : -INFINITY;
+  const int best = group_argmax<W>(score, k);
+  if (valid) {
+    sample[gi * K + k] = (k == best) ? 1.0f : 0.0f;
+    if (probs) probs[gi * K + k] = c.pn;
+  }
+}
+
+// straight-through backward: d sample / d logits = d pn / d logits
+template <int W>
+__global__ __launch_bounds__(256) void onehot_bwd_kernel(const float* __restrict__ logits,
+                                                         const float* __restrict__ gsample,
+                                                         float* __restrict__ dlogits, long G, int K, float a,
+                                                         int accumulate) {
+  const long g = ((long)blockIdx.x * 256 + threadIdx.x) / W;
+  const int k = threadIdx.x % W;
+  const bool valid = (g < G) && (k < K);
+  const long gi = g < G ? g : G - 1;
+  const float l = valid ? logits[gi * K + k] : 0.f;
+  Cat<W> c;
+  c.init(l, valid, K, a);
+  const float d = c.backward(valid ? gsample[gi * K + k] : 0.f, valid, a);
+  if (valid) dlogits[gi * K + k] = accumulate ? dlogits[gi * K + k] + d : d;
+}
+
+// KL(P||Q) summed over the S latents of a row + entropies.  One block per row.
+// ref: D.kl_divergence(Independent(OneHotDist)), agent/dreamer_utils.py:534-555; entropy :249-250
+template <int W>
+__global__ __launch_bounds__(256) void cat_kl_fwd_kernel(const float* __restrict__ lp, const float* __restrict__ lq,
+                                                         float* __restrict__ kl, float* __restrict__ ent_p,
+                                                         float* __restrict__ ent_q, int S, int K, float a) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  constexpr int GPB = 256 / W;  // groups per block iteration
+  const int k = threadIdx.x % W, gsub = threadIdx.x / W;
+  float akl = 0.f, aep = 0.f, aeq = 0.f;
+  for (int s0 = 0; s0 < S; s0 += GPB) {
+    const int s = s0 + gsub;
+    const bool valid = (s < S) && (k < K);
+    const long off = (row * S + (s < S ? s : S - 1)) * K + k;
+    Cat<W> cp, cq;
+    cp.init(valid ? lp[off] : 0.f, valid, K, a);
+    cq.init(valid ? lq[off] : 0.f, valid, K, a);
+    if (valid) {
+      const float lpp = clamp_log(cp.pn), lqq = clamp_log(cq.pn);
+      akl += cp.pn * (lpp - lqq);
+      aep -= cp.pn * lpp;
+      aeq -= cq.pn * lqq;
+    }
+  }
+  akl = block_sum_256(akl, red);
+  aep = block_sum_256(aep, red + 4);
+  aeq = block_sum_256(aeq, red + 8);
+  if (threadIdx.x == 0) {
+    kl[row] = akl;
+    if (ent_p) ent_p[row] = aep;
+    if (ent_q) ent_q[row] = aeq;
+  }
+}
+
+// dlp = gp[row] * dKL/dlp ; dlq = gq[row] * dKL/dlq   (either output may be null)
+template <int W>
+__global__ __launch_bounds__(256) void cat_kl_bwd_kernel(const float* __restrict__ lp, const float* __restrict__ lq,
+                                                         const float* __restrict__ gp, const float* __restrict__ gq,
+                                                         float* __restrict__ dlp, float* __restrict__ dlq, long G,
+                                                         int S, int K, float a) {
+  const long g = ((long)blockIdx.x * 256 + threadIdx.x) / W;
+  const int k = threadIdx.x % W;
+  const bool valid = (g < G) && (k < K);
+  const long gi = g < G ? g : G - 1;
+  const long row = gi / S;
+  Cat<W> cp, cq;
+  cp.init(valid ? lp[gi * K + k] : 0.f, valid, K, a);
+  cq.init(valid ? lq[gi * K + k] : 0.f, valid, K, a);
+  const float lpp = clamp_log(cp.pn), lqq = clamp_log(cq.pn);
+  if (dlp) {
+    const float d = cp.backward(valid ? (lpp - lqq + 1.0f) : 0.f, valid, a);
+    if (valid) dlp[gi * K + k] = gp[row] * d;
+  }
+  if (dlq) {
+    const float d = cq.backward(valid ? (-cp.pn / cq.pn) : 0.f, valid, a);
+    if (valid) dlq[gi * K + k] = gq[row] * d;
+  }
+}
+
+// ------------------------------------------------------------------ two-hot symlog head (255 bins)
+__device__ __forceinline__ float symlogf_(float x) { return copysignf(logf(fabsf(x) + 1.0f), x); }
+__device__ __forceinline__ float symexpf_(float x) { return copysignf(expf(fabsf(x)) - 1.0f, x); }
+
+struct TwoHot {
+  int below, above;
+  float wb, wa;
+};
+// TwoHotDist.log_prob target construction, agent/dreamer_utils.py:147-167 (wave-cooperative)
+__device__ __forceinline__ TwoHot twohot_target(const float* __restrict__ buckets, float x, int lane) {
+  const float xs = symlogf_(x);
+  int le = 0, gt = 0;
+  for (int j = lane; j < 255; j += 64) {
+    le += (buckets[j] <= xs);
+    gt += (buckets[j] > xs);
+  }
+  le = (int)wave_sum((float)le);
+  gt = (int)wave_sum((float)gt);
+  TwoHot t;
+  t.below = min(max(le - 1, 0), 254);
+  t.above = min(max(255 - gt, 0), 254);
+  const bool eq = t.below == t.above;
+  const float db = eq ? 1.0f : fabsf(buckets[t.below] - xs);
+  const float da = eq ? 1.0f : fabsf(buckets[t.above] - xs);
+  const float tot = db + da;
+  t.wb = da / tot;
+  t.wa = db / tot;
+  return t;
+}
+
+// mode 0: logprob of x ; mode 1: mean = symexp(sum softmax*buckets).  One wave per row.
+__global__ __launch_bounds__(256) void twohot_fwd_kernel(const float* __restrict__ logits,
+                                                         const float* __restrict__ x,
+                                                         const float* __restrict__ buckets, float* __restrict__ out,
+                                                         long R, int mode) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const float* lr = logits + row * 255;
+  float m = -INFINITY;
+  for (int j = lane; j < 255; j += 64) m = fmaxf(m, lr[j]);
+  m = wave_max(m);
+  float z = 0.f, sb = 0.f;
+  for (int j = lane; j < 255; j += 64) {
+    const float e = expf(lr[j] - m);
+    z += e;
+    sb += e * buckets[j];
+  }
+  z = wave_sum(z);
+  if (mode == 1) {
+    sb = wave_sum(sb);
+    if (lane == 0) out[row] = symexpf_(sb / z);
+    return;
+  }
+  const float lse = m + logf(z);
+  const TwoHot t = twohot_target(buckets, x[row], lane);
+  if (lane == 0) out[row] = t.wb * (lr[t.below] - lse) + t.wa * (lr[t.above] - lse);
+}
+
+__global__ __launch_bounds__(256) void twohot_bwd_kernel(const float* __restrict__ logits,
+                                                         const float* __restrict__ x,
+                                                         const float* __restrict__ buckets,
+                                                         const float* __restrict__ gout, float* __restrict__ dlogits,
+                                                         long R, int mode) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const float* lr = logits + row * 255;
+  float m = -INFINITY;
+  for (int j = lane; j < 255; j += 64) m = fmaxf(m, lr[j]);
+  m = wave_max(m);
+  float z = 0.f, sb = 0.f;
+  for (int j = lane; j < 255; j += 64) {
+    const float e = expf(lr[j] - m);
+    z += e;
+    sb += e * buckets[j];
+  }
+  z = wave_sum(z);
+  sb = wave_sum(sb);
+  const float g = gout[row];
+  float* dr = dlogits + row * 255;
+  if (mode == 1) {
+    const float mu = sb / z;
+    const float ds = g * expf(fabsf(mu));  // d symexp
+    for (int j = lane; j < 255; j += 64) dr[j] = ds * (expf(lr[j] - m) / z) * (buckets[j] - mu);
+    return;
+  }
+  const TwoHot t = twohot_target(buckets, x[row], lane);
+  for (int j = lane; j < 255; j += 64) {
+    float tg = 0.f;
+    if (j == t.below) tg += t.wb;
+    if (j == t.above) tg += t.wa;
+    dr[j] = g * (tg - expf(lr[j] - m) / z);
+  }
+}
+
+// ------------------------------------------------------------------ lambda-return scan
+// R_t = r_t + g_t*((1-lam)*v_{t+1} + lam*R_{t+1}), R_H = v_H.  reward [H,N], value [H+1,N].
+// ref: lambda_return, agent/dreamer_utils.py:228-253.  One thread per column; coalesced over N.
+__global__ void lambda_return_fwd_kernel(const float* __restrict__ reward, const float* __restrict__ value,
+                                         float* __restrict__ ret, int H, long N, float disc, float lam) {
+  const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float agg = value[(long)H * N + n];
+  for (int t = H - 1; t >= 0; --t) {
+    const float inp = reward[(long)t * N + n] + disc * value[(long)(t + 1) * N + n] * (1.0f - lam);
+    agg = inp + disc * lam * agg;
+    ret[(long)t * N + n] = agg;
+  }
+}
+__global__ void lambda_return_bwd_kernel(const float* __restrict__ gret, float* __restrict__ dreward,
+                                         float* __restrict__ dvalue, int H, long N, float disc, float lam) {
+  const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float a = 0.f;
+  dvalue[n] = 0.f;
+  for (int t = 0; t < H; ++t) {
+    a = gret[(long)t * N + n] + disc * lam * a;
+    dreward[(long)t * N + n] = a;
+    dvalue[(long)(t + 1) * N + n] = (t == H - 1) ? disc * a : disc * (1.0f - lam) * a;
+  }
+}
+
+// ------------------------------------------------------------------ MSE image likelihood
+// like[n] = -sum_{chw} (mean - (u8/255 - 0.5))^2   (MSEDist.log_prob, agent/dreamer_utils.py:74-83 with
+// WorldModel.preprocess, agent/dreamer.py:294-295).  One block per frame; 16-byte loads.
+__global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ mean, const uint8_t* __restrict__ obs,
+                                                      float* __restrict__ like, int E) {
+  __shared__ float red[8];
+  const long n = blockIdx.x;
+  const float* mp = mean + n * E;
+  const uint8_t* op = obs + n * E;
+  float a = 0.f;
+  for (int i = threadIdx.x; i < E; i += 256) {
+    const float d = mp[i] - ((float)op[i] / 255.0f - 0.5f);
+    a += d * d;
+  }
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) like[n] = -a;
+}
+__global__ void mse_bwd_kernel(const float* __restrict__ mean, const uint8_t* __restrict__ obs,
+                               const float* __restrict__ glike, float* __restrict__ dmean, long total, int E) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const float d = mean[i] - ((float)obs[i] / 255.0f - 0.5f);
+  dmean[i] = -2.0f * d * glike[i / E];
+}
+
+// ------------------------------------------------------------------ max-cosine reward
+// r = sum((u/mn)*(v/mn)), mn = max(|u|,|v|)  (tools/genrl_utils.py:240-242). u = target row
+// (index tidx[row] if given), v = agent row.  One wave per row.
+__global__ __launch_bounds__(256) void maxcos_fwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                         const long* __restrict__ urow, float* __restrict__ out,
+                                                         long R, int E) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const float* ur = u + (urow ? urow[row] : row) * E;
+  const float* vr = v + row * E;
+  float su = 0.f, sv = 0.f;
+  for (int j = lane; j < E; j += 64) {
+    su += ur[j] * ur[j];
+    sv += vr[j] * vr[j];
+  }
+  const float mn = fmaxf(sqrtf(wave_sum(su)), sqrtf(wave_sum(sv)));
+  float d = 0.f;
+  for (int j = lane; j < E; j += 64) d += (ur[j] / mn) * (vr[j] / mn);
+  d = wave_sum(d);
+  if (lane == 0) out[row] = d;
+}
+// gradient w.r.t. v only (the target is a constant)
+__global__ __launch_bounds__(256) void maxcos_bwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                         const long* __restrict__ urow, const float* __restrict__ gout,
+                                                         float* __restrict__ dv, long R, int E) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const float* ur = u + (urow ? urow[row] : row) * E;
+  const float* vr = v + row * E;
+  float su = 0.f, sv = 0.f, uv = 0.f;
+  for (int j = lane; j < E; j += 64) {
+    su += ur[j] * ur[j];
+    sv += vr[j] * vr[j];
+    uv += ur[j] * vr[j];
+  }
+  su = wave_sum(su);
+  sv = wave_sum(sv);
+  uv = wave_sum(uv);
+  const float g = gout[row];
+  float* dr = dv + row * E;
+  if (sv > su) {  // mn = |v|: r = uv / sv
+    for (int j = lane; j < E; j += 64) dr[j] = g * (ur[j] / sv - 2.0f * uv * vr[j] / (sv * sv));
+  } else {
+    for (int j = lane; j < E; j += 64) dr[j] = g * ur[j] / su;
+  }
+}
+
+// Reward alignment (video_text_reward, align_sequence; tools/genrl_utils.py:344-366) given the
+// per-step conv_in projections: score[t][n] = mean_{j<nf} maxcos(ct[j][n], ca[t+j][n]); best t*
+// per column (first max); ts_idx[tau][n] = max(tau - t*, 0) and the flattened target row index.
+__global__ __launch_bounds__(256) void align_index_kernel(const float* __restrict__ ct, const float* __restrict__ ca,
+                                                          long* __restrict__ urow, int T, long N, int E, int nf) {
+  const int lane = threadIdx.x & 63;
+  const long n = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float best = -INFINITY;
+  int bt = 0;
+  for (int t = 0; t < T - nf; ++t) {
+    float sc = 0.f;
+    for (int j = 0; j < nf; ++j) {
+      const float* ur = ct + ((long)j * N + n) * E;
+      const float* vr = ca + ((long)(t + j) * N + n) * E;
+      float su = 0.f, sv = 0.f;
+      for (int i = lane; i < E; i += 64) {
+        su += ur[i] * ur[i];
+        sv += vr[i] * vr[i];
+      }
+      const float mn = fmaxf(sqrtf(wave_sum(su)), sqrtf(wave_sum(sv)));
+      float d = 0.f;
+      for (int i = lane; i < E; i += 64) d += (ur[i] / mn) * (vr[i] / mn);
+      sc += wave_sum(d);
+    }
+    sc /= nf;
+    if (sc > best) {
+      best = sc;
+      bt = t;
+    }
+  }
+  for (int tau = lane; tau < T; tau += 64) urow[(long)tau * N + n] = (long)max(tau - bt, 0) * N + n;
+}
+
+template <typename F>
+int dispatch_w(int K, F&& f) {
+  if (K <= 4) return f(std::integral_constant<int, 4>{});
+  if (K <= 8) return f(std::integral_constant<int, 8>{});
+  if (K <= 16) return f(std::integral_constant<int, 16>{});
+  if (K <= 32) return f(std::integral_constant<int, 32>{});
+  if (K <= 64) return f(std::integral_constant<int, 64>{});
+  return GENRL_EINVAL;
+}
+
+}  // namespace
+
+extern "C" {
+
+int genrl_onehot_fwd(const float* logits, const float* q, float* sample, float* probs, long G, int K, float unimix,
+                     void* stream) {
+  if (G <= 0) return GENRL_OK;
+  return dispatch_w(K, [&](auto w) {
+    constexpr int W = decltype(w)::value;
+    hipLaunchKernelGGL((onehot_fwd_kernel<W>), dim3(cdiv(G * W, 256)), dim3(256), 0, (hipStream_t)stream, logits, q,
+                       sample, probs, G, K, unimix);
+    GENRL_CHECK_LAUNCH();
+    return GENRL_OK;
+  });
+}
+
+int genrl_onehot_bwd(const float* logits, const float* gsample, float* dlogits, long G, int K, float unimix,
+                     int accumulate, void* stream) {
+  if (G <= 0) return GENRL_OK;
+  return dispatch_w(K, [&](auto w) {
+    constexpr int W = decltype(w)::value;
+    hipLaunchKernelGGL((onehot_bwd_kernel<W>), dim3(cdiv(G * W, 256)), dim3(256), 0, (hipStream_t)stream, logits,
+                       gsample, dlogits, G, K, unimix, accumulate);
+    GENRL_CHECK_LAUNCH();
+    return GENRL_OK;
+  });
+}
+
+int genrl_cat_kl_fwd(const float* lp, const float* lq, float* kl, float* ent_p, float* ent_q, long R, int S, int K,
+                     float unimix, void* stream) {
+  if (R <= 0) return GENRL_OK;
+  return dispatch_w(K, [&](auto w) {
+    constexpr int W = decltype(w)::value;
+    hipLaunchKernelGGL((cat_kl_fwd_kernel<W>), dim3(R), dim3(256), 0, (hipStream_t)stream, lp, lq, kl, ent_p, ent_q, S,
+                       K, unimix);
+    GENRL_CHECK_LAUNCH();
+    return GENRL_OK;
+  });
+}
+
+int genrl_cat_kl_bwd(const float* lp, const float* lq, const float* gp, const float* gq, float* dlp, float* dlq, long R,
+                     int S, int K, float unimix, void* stream) {
+  if (R <= 0) return GENRL_OK;
+  const long G = R * S;
+  return dispatch_w(K, [&](auto w) {
+    constexpr int W = decltype(w)::value;
+    hipLaunchKernelGGL((cat_kl_bwd_kernel<W>), dim3(cdiv(G * W, 256)), dim3(256), 0, (hipStream_t)stream, lp, lq, gp,
+                       gq, dlp, dlq, G, S, K, unimix);
+    GENRL_CHECK_LAUNCH();
+    return GENRL_OK;
+  });
+}
+
+int genrl_twohot_fwd(const float* logits, const float* x, const float* buckets, float* out, long R, int mode,
+                     void* stream) {
+  if (R <= 0) return GENRL_OK;
+  hipLaunchKernelGGL(twohot_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, logits, x, buckets, out, R,
+                     mode);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}
+
+int genrl_twohot_bwd(const float* logits, const float* x, const float* buckets, const float* gout, float* dlogits,
+                     long R, int mode, void* stream) {
+  if (R <= 0) return GENRL_OK;
+  hipLaunchKernelGGL(twohot_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, logits, x, buckets, gout,
+                     dlogits, R, mode);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}
+
+int genrl_lambda_return_fwd(const float* reward, const float* value, float* ret, int H, long N, float disc, float lam,
+                            void* stream) {
+  if (N <= 0) return GENRL_OK;
+  hipLaunchKernelGGL(lambda_return_fwd_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, reward, value,
+                     ret, H, N, disc, lam);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}
+
+int genrl_lambda_return_bwd(const float* gret, float* dreward, float* dvalue, int H, long N, float disc, float lam,
+                            void* stream) {
+  if (N <= 0) return GENRL_OK;
+  hipLaunchKernelGGL(lambda_return_bwd_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, gret, dreward,
+                     dvalue, H, N, disc, lam);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}
+
+int genrl_mse_fwd(const float* mean, const uint8_t* obs, float* like, long Nimg, int E, void* stream) {
+  if (Nimg <= 0) return GENRL_OK;
+  hipLaunchKernelGGL(mse_fwd_kernel, dim3(Nimg), dim3(256), 0, (hipStream_t)stream, mean, obs, like, E);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}
+
+int genrl_mse_bwd(const float* mean, const uint8_t* obs, const float* glike, float* dmean, long Nimg, int E,
+                  void* stream) {
+  const long total = Nimg * E;
+  if (total <= 0) return GENRL_OK;
+  hipLaunchKernelGGL(mse_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, mean, obs, glike, dmean,
+                     total, E);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}
+
+int genrl_maxcos_fwd(const float* u, const float* v, const long* urow, float* out, long R, int E, void* stream) {
+  if (R <= 0) return GENRL_OK;
+  hipLaunchKernelGGL(maxcos_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, u, v, urow, out, R, E);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}
+
+int genrl_maxcos_bwd(const float* u, const float* v, const long* urow, const float* gout, float* dv, long R, int E,
+                     void* stream) {
+  if (R <= 0) return GENRL_OK;
+  hipLaunchKernelGGL(maxcos_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, u, v, urow, gout, dv, R,
+                     E);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}
+
+int genrl_align_index(const float* ct, const float* ca, long* urow, int T, long N, int E, int nf, void* stream) {
+  if (N <= 0) return GENRL_OK;
+  hipLaunchKernelGGL(align_index_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, ct, ca, urow, T, N, E,
+                     nf);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,578 @@
+"""torch.autograd bindings of the HIP kernels (libgenrl_hip.so).  PyTorch owns device memory,
+streams and the autograd graph; every flop of the hot path runs in the hand-written kernels.
+No CPU fallback: calling an op with a non-CUDA tensor raises."""
+import torch
+from torch.autograd import Function
+
+from ._lib import lib, check, GenrlHipError
+
+UNIMIX = 0.99
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise GenrlHipError('genrl_amd ops need tensors on the MI355X (no CPU fallback)')
+    assert t.is_contiguous(), 'non-contiguous tensor handed to a HIP op'
+    return t.data_ptr()
+
+
+def _f32(t):
+    assert t.dtype == torch.float32, t.dtype
+    return t
+
+
+def _ws(n, dev):
+    return torch.empty(max(int(n), 1), dtype=torch.float32, device=dev)
+
+
+# ------------------------------------------------------------------ raw (non-autograd) calls
+
+def sgemm(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate=False, a_off=0, b_off=0, c_off=0):
+    """C[m,n] (+)= sum_k A[m*a_rs+k*a_ks] B[n*b_rs+k*b_ks] (+bias[n]); offsets in elements."""
+    check(lib().genrl_sgemm(A.data_ptr() + 4 * a_off, a_rs, a_ks, B.data_ptr() + 4 * b_off, b_rs, b_ks,
+                            C.data_ptr() + 4 * c_off, ldc, _p(bias), M, N, K, int(accumulate), _stream()), 'sgemm')
+
+
+def colsum(x2d, out=None, accumulate=False):
+    M, N = x2d.shape
+    out = out if out is not None else torch.empty(N, device=x2d.device)
+    ws = _ws(lib().genrl_colsum_ws_floats(M, N), x2d.device)
+    check(lib().genrl_colsum(_p(x2d), N, _p(out), _p(ws), M, N, int(accumulate), _stream()), 'colsum')
+    return out
+
+
+def copy2d(src, lds, dst, ldd, rows, cols, rowscale=None, accumulate=False, src_off=0, dst_off=0):
+    check(lib().genrl_copy2d(src.data_ptr() + 4 * src_off, lds, dst.data_ptr() + 4 * dst_off, ldd, rows, cols,
+                             _p(rowscale), int(accumulate), _stream()), 'copy2d')
+
+
+def cat_cols(parts, rowscale=None):
+    """torch.cat(parts, -1) for 2-D row-major parts via strided copies (optionally row-masked)."""
+    R = parts[0].shape[0]
+    W = sum(p.shape[1] for p in parts)
+    out = torch.empty(R, W, device=parts[0].device)
+    off = 0
+    for p in parts:
+        copy2d(p.contiguous(), p.shape[1], out, W, R, p.shape[1], rowscale, dst_off=off)
+        off += p.shape[1]
+    return out
+
+
+def onehot_mode(logits):
+    """OneHotDist.mode() forward (argmax of the unimix probabilities), no gradient."""
+    lg = logits.contiguous()
+    K = lg.shape[-1]
+    out = torch.empty_like(lg)
+    check(lib().genrl_onehot_fwd(_p(lg), None, _p(out), None, lg.numel() // K, K, UNIMIX, _stream()), 'onehot_fwd')
+    return out
+
+
+def align_index(ct, ca, nf):
+    """ct (nf.., N, E) target projections (first nf steps used), ca (T, N, E) agent projections ->
+    flat target row index (T, N) int64 (tools/genrl_utils.py:344-361)."""
+    T, N, E = ca.shape
+    urow = torch.empty(T, N, dtype=torch.int64, device=ca.device)
+    check(lib().genrl_align_index(_p(ct.contiguous()), _p(ca.contiguous()), _p(urow), T, N, E, nf, _stream()), 'align')
+    return urow
+
+
+def transpose_last2_raw(x):
+    B, P, C = x.shape
+    out = torch.empty(B, C, P, device=x.device)
+    check(lib().genrl_transpose_last2(_p(x.contiguous()), _p(out), B, P, C, _stream()), 'transpose')
+    return out
+
+
+# ------------------------------------------------------------------ Linear
+
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x2 = _f32(x).reshape(-1, x.shape[-1]).contiguous()
+        M, K = x2.shape
+        N = W.shape[0]
+        y = torch.empty(M, N, device=x.device)
+        sgemm(x2, K, 1, W, K, 1, y, N, b, M, N, K)
+        ctx.save_for_backward(x2, W)
+        ctx.has_bias = b is not None
+        ctx.xshape = x.shape
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W = ctx.saved_tensors
+        M, K = x2.shape
+        N = W.shape[0]
+        dy2 = dy.reshape(M, N).contiguous()
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, device=dy.device)
+            sgemm(dy2, N, 1, W, 1, K, dx, K, None, M, K, N)          # dx = dy W
+            dx = dx.reshape(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty(N, K, device=dy.device)
+            sgemm(dy2, 1, N, x2, 1, K, dW, K, None, N, K, M)         # dW = dy^T x
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy2)
+        return dx, dW, db
+
+
+def linear(x, W, b=None):
+    return _Linear.apply(x, W, b)
+
+
+# ------------------------------------------------------------------ LayerNorm (+SiLU)
+
+class _LNAct(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, act):
+        x2 = _f32(x).reshape(-1, x.shape[-1]).contiguous()
+        M, N = x2.shape
+        y = torch.empty_like(x2)
+        mean = torch.empty(M, device=x.device)
+        rstd = torch.empty(M, device=x.device)
+        check(lib().genrl_ln_act_fwd(_p(x2), N, _p(gamma), _p(beta), _p(y), N, _p(mean), _p(rstd), M, N, eps, act,
+                                     _stream()), 'ln_act_fwd')
+        ctx.save_for_backward(x2, gamma, beta, mean, rstd)
+        ctx.act = act
+        ctx.xshape = x.shape
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, beta, mean, rstd = ctx.saved_tensors
+        M, N = x2.shape
+        dy2 = dy.reshape(M, N).contiguous()
+        need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        dg = torch.empty(N, device=dy.device) if need_p else None
+        db = torch.empty(N, device=dy.device) if need_p else None
+        ws = _ws(lib().genrl_ln_ws_floats(M, N), dy.device) if need_p else None
+        check(lib().genrl_ln_act_bwd(_p(dy2), N, _p(x2), N, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dx), N,
+                                     _p(dg), _p(db), _p(ws), M, N, ctx.act, 0, _stream()), 'ln_act_bwd')
+        return (dx.reshape(ctx.xshape) if dx is not None else None), dg, db, None, None
+
+
+def ln_act(x, gamma, beta, eps=1e-5, act=True):
+    return _LNAct.apply(x, gamma, beta, float(eps), int(act))
+
+
+# ------------------------------------------------------------------ GRU gates
+
+class _GRUGates(Function):
+    @staticmethod
+    def forward(ctx, pre, h, gamma, beta):
+        pre = _f32(pre).contiguous(); h = _f32(h).contiguous()
+        R, D = h.shape
+        out = torch.empty_like(h)
+        mean = torch.empty(R, device=h.device); rstd = torch.empty(R, device=h.device)
+        check(lib().genrl_gru_gates_fwd(_p(pre), _p(h), D, _p(gamma), _p(beta), _p(out), D, _p(mean), _p(rstd), R, D,
+                                        1e-5, _stream()), 'gru_gates_fwd')
+        ctx.save_for_backward(pre, h, gamma, beta, mean, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        pre, h, gamma, beta, mean, rstd = ctx.saved_tensors
+        R, D = h.shape
+        dout = dout.contiguous()
+        dpre = torch.empty_like(pre); dh = torch.empty_like(h)
+        need_p = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        dg = torch.empty(3 * D, device=h.device) if need_p else None
+        db = torch.empty(3 * D, device=h.device) if need_p else None
+        ws = _ws(lib().genrl_ln_ws_floats(R, 3 * D), h.device) if need_p else None
+        check(lib().genrl_gru_gates_bwd(_p(dout), D, _p(pre), _p(h), D, _p(gamma), _p(beta), _p(mean), _p(rstd),
+                                        _p(dpre), _p(dh), D, _p(dg), _p(db), _p(ws), R, D, 0, 0, _stream()),
+              'gru_gates_bwd')
+        return dpre, dh, dg, db
+
+
+def gru_gates(pre, h, gamma, beta):
+    return _GRUGates.apply(pre, h, gamma, beta)
+
+
+# ------------------------------------------------------------------ categorical latents
+
+class _OneHotSample(Function):
+    @staticmethod
+    def forward(ctx, logits, q):
+        lg = _f32(logits).contiguous()
+        K = lg.shape[-1]
+        G = lg.numel() // K
+        out = torch.empty_like(lg)
+        check(lib().genrl_onehot_fwd(_p(lg), _p(q.contiguous()), _p(out), None, G, K, UNIMIX, _stream()), 'onehot_fwd')
+        ctx.save_for_backward(lg)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (lg,) = ctx.saved_tensors
+        K = lg.shape[-1]
+        d = torch.empty_like(lg)
+        check(lib().genrl_onehot_bwd(_p(lg), _p(g.contiguous()), _p(d), lg.numel() // K, K, UNIMIX, 0, _stream()),
+              'onehot_bwd')
+        return d, None
+
+
+def onehot_sample(logits, q):
+    """OneHotDist.sample with exponential noise q (same numel as logits); straight-through grad."""
+    return _OneHotSample.apply(logits, q)
+
+
+class _CatKL(Function):
+    @staticmethod
+    def forward(ctx, lp, lq):
+        lp = _f32(lp).contiguous(); lq = _f32(lq).contiguous()
+        S, K = lp.shape[-2:]
+        R = lp.numel() // (S * K)
+        kl = torch.empty(R, device=lp.device)
+        check(lib().genrl_cat_kl_fwd(_p(lp), _p(lq), _p(kl), None, None, R, S, K, UNIMIX, _stream()), 'cat_kl_fwd')
+        ctx.save_for_backward(lp, lq)
+        return kl.reshape(lp.shape[:-2])
+
+    @staticmethod
+    def backward(ctx, g):
+        lp, lq = ctx.saved_tensors
+        S, K = lp.shape[-2:]
+        R = lp.numel() // (S * K)
+        g = g.reshape(R).contiguous()
+        dlp = torch.empty_like(lp) if ctx.needs_input_grad[0] else None
+        dlq = torch.empty_like(lq) if ctx.needs_input_grad[1] else None
+        check(lib().genrl_cat_kl_bwd(_p(lp), _p(lq), _p(g), _p(g), _p(dlp), _p(dlq), R, S, K, UNIMIX, _stream()),
+              'cat_kl_bwd')
+        return dlp, dlq
+
+
+def cat_kl(lp, lq):
+    return _CatKL.apply(lp, lq)
+
+
+def cat_entropy(logits):
+    lg = logits.detach().contiguous()
+    S, K = lg.shape[-2:]
+    R = lg.numel() // (S * K)
+    kl = torch.empty(R, device=lg.device); ent = torch.empty(R, device=lg.device)
+    check(lib().genrl_cat_kl_fwd(_p(lg), _p(lg), _p(kl), _p(ent), None, R, S, K, UNIMIX, _stream()), 'cat_kl_fwd')
+    return ent.reshape(lg.shape[:-2])
+
+
+# ------------------------------------------------------------------ two-hot
+
+_buckets = {}
+
+
+def twohot_buckets(dev):
+    k = str(dev)
+    if k not in _buckets:
+        _buckets[k] = torch.linspace(-20.0, 20.0, steps=255, device=dev)
+    return _buckets[k]
+
+
+class _TwoHot(Function):
+    @staticmethod
+    def forward(ctx, logits, x, mode):
+        lg = _f32(logits).contiguous()
+        R = lg.numel() // 255
+        b = twohot_buckets(lg.device)
+        xx = x.reshape(R).contiguous() if x is not None else None
+        out = torch.empty(R, device=lg.device)
+        check(lib().genrl_twohot_fwd(_p(lg), _p(xx), _p(b), _p(out), R, mode, _stream()), 'twohot_fwd')
+        ctx.save_for_backward(lg, xx if xx is not None else lg.new_empty(0))
+        ctx.mode = mode
+        return out.reshape(lg.shape[:-1])
+
+    @staticmethod
+    def backward(ctx, g):
+        lg, xx = ctx.saved_tensors
+        R = lg.numel() // 255
+        d = torch.empty_like(lg)
+        check(lib().genrl_twohot_bwd(_p(lg), _p(xx) if ctx.mode == 0 else None, _p(twohot_buckets(lg.device)),
+                                     _p(g.reshape(R).contiguous()), _p(d), R, ctx.mode, _stream()), 'twohot_bwd')
+        return d, None, None
+
+
+def twohot_logprob(logits, x):
+    """TwoHotDist(logits).log_prob(x): logits (...,255), x (...,1) or (...) -> (...)"""
+    return _TwoHot.apply(logits, x.detach(), 0)
+
+
+def twohot_mean(logits):
+    """TwoHotDist(logits).mean -> (...,1)"""
+    return _TwoHot.apply(logits, None, 1).unsqueeze(-1)
+
+
+# ------------------------------------------------------------------ lambda return
+
+class _LambdaReturn(Function):
+    @staticmethod
+    def forward(ctx, reward, value, disc, lam):
+        H = reward.shape[0]
+        N = reward.numel() // H
+        r = _f32(reward).contiguous(); v = _f32(value).contiguous()
+        assert v.shape[0] == H + 1
+        out = torch.empty_like(r)
+        check(lib().genrl_lambda_return_fwd(_p(r), _p(v), _p(out), H, N, disc, lam, _stream()), 'lambda_fwd')
+        ctx.dims = (H, N, disc, lam, value.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        H, N, disc, lam, vshape = ctx.dims
+        g = g.contiguous()
+        dr = torch.empty_like(g)
+        dv = torch.empty(vshape, device=g.device)
+        check(lib().genrl_lambda_return_bwd(_p(g), _p(dr), _p(dv), H, N, disc, lam, _stream()), 'lambda_bwd')
+        return dr, dv, None, None
+
+
+def lambda_return(reward, value, disc, lam):
+    """reward (H,N,1), value (H+1,N,1) [value[-1] is the bootstrap] -> (H,N,1)"""
+    return _LambdaReturn.apply(reward, value, float(disc), float(lam))
+
+
+# ------------------------------------------------------------------ MSE image likelihood
+
+class _MSELike(Function):
+    @staticmethod
+    def forward(ctx, mean, obs_u8):
+        m = _f32(mean).contiguous(); o = obs_u8.contiguous()
+        assert o.dtype == torch.uint8 and o.numel() == m.numel()
+        N = m.shape[0]
+        E = m.numel() // N
+        like = torch.empty(N, device=m.device)
+        check(lib().genrl_mse_fwd(_p(m), _p(o), _p(like), N, E, _stream()), 'mse_fwd')
+        ctx.save_for_backward(m, o)
+        return like
+
+    @staticmethod
+    def backward(ctx, g):
+        m, o = ctx.saved_tensors
+        N = m.shape[0]
+        d = torch.empty_like(m)
+        check(lib().genrl_mse_bwd(_p(m), _p(o), _p(g.contiguous()), _p(d), N, m.numel() // N, _stream()), 'mse_bwd')
+        return d, None
+
+
+def mse_like(mean, obs_u8):
+    """MSEDist(mean).log_prob(obs/255-0.5) per frame: mean (N,C,H,W) f32, obs (N,C,H,W) u8 -> (N,)"""
+    return _MSELike.apply(mean, obs_u8)
+
+
+# ------------------------------------------------------------------ max-cosine reward
+
+class _MaxCos(Function):
+    @staticmethod
+    def forward(ctx, u, v, urow):
+        v2 = _f32(v).reshape(-1, v.shape[-1]).contiguous()
+        u2 = _f32(u).reshape(-1, u.shape[-1]).contiguous()
+        R, E = v2.shape
+        ur = urow.reshape(R).contiguous() if urow is not None else None
+        out = torch.empty(R, device=v.device)
+        check(lib().genrl_maxcos_fwd(_p(u2), _p(v2), _p(ur), _p(out), R, E, _stream()), 'maxcos_fwd')
+        ctx.save_for_backward(u2, v2, ur if ur is not None else torch.empty(0, device=v.device))
+        ctx.has_idx = ur is not None
+        ctx.vshape = v.shape
+        return out.reshape(v.shape[:-1])
+
+    @staticmethod
+    def backward(ctx, g):
+        u2, v2, ur = ctx.saved_tensors
+        R, E = v2.shape
+        dv = torch.empty_like(v2)
+        check(lib().genrl_maxcos_bwd(_p(u2), _p(v2), _p(ur) if ctx.has_idx else None, _p(g.reshape(R).contiguous()),
+                                     _p(dv), R, E, _stream()), 'maxcos_bwd')
+        return None, dv.reshape(ctx.vshape), None
+
+
+def maxcos(u, v, urow=None):
+    """max_cosine_similarity(u[urow], v) along the last dim; gradient flows to v only."""
+    return _MaxCos.apply(u.detach(), v, urow)
+
+
+# ------------------------------------------------------------------ actor head
+
+class _ActorHead(Function):
+    @staticmethod
+    def forward(ctx, raw, eps, min_std, max_std):
+        r2 = _f32(raw).reshape(-1, raw.shape[-1]).contiguous()
+        R, A2 = r2.shape
+        A = A2 // 2
+        e = eps.reshape(R, A).contiguous()
+        act = torch.empty(R, A, device=raw.device)
+        check(lib().genrl_actor_head_fwd(_p(r2), _p(e), _p(act), None, None, R, A, min_std, max_std, _stream()),
+              'actor_head_fwd')
+        ctx.save_for_backward(r2, e)
+        ctx.cfg = (min_std, max_std, raw.shape)
+        return act.reshape(*raw.shape[:-1], A)
+
+    @staticmethod
+    def backward(ctx, g):
+        r2, e = ctx.saved_tensors
+        min_std, max_std, rshape = ctx.cfg
+        R, A2 = r2.shape
+        d = torch.empty_like(r2)
+        check(lib().genrl_actor_head_bwd(_p(g.reshape(R, A2 // 2).contiguous()), _p(r2), _p(e), _p(d), R, A2 // 2,
+                                         min_std, max_std, _stream()), 'actor_head_bwd')
+        return d.reshape(rshape), None, None, None
+
+
+def actor_sample(raw, eps, min_std=0.1, max_std=1.0):
+    """raw (...,2A)=[out|std_raw] -> action = tanh(out) + std*eps (Normal rsample)"""
+    return _ActorHead.apply(raw, eps, float(min_std), float(max_std))
+
+
+def actor_mean_std(raw, min_std=0.1, max_std=1.0):
+    r2 = raw.detach().reshape(-1, raw.shape[-1]).contiguous()
+    R, A2 = r2.shape
+    A = A2 // 2
+    mean = torch.empty(R, A, device=raw.device); std = torch.empty(R, A, device=raw.device)
+    check(lib().genrl_actor_head_fwd(_p(r2), None, None, _p(mean), _p(std), R, A, min_std, max_std, _stream()),
+          'actor_head_fwd')
+    return mean.reshape(*raw.shape[:-1], A), std.reshape(*raw.shape[:-1], A)
+
+
+# ------------------------------------------------------------------ stride-2 convolutions (NHWC)
+
+def _im2col(x, Nimg, Hi, Wi, C, k, mode):
+    Ho, Wo = (Hi - k) // 2 + 1, (Wi - k) // 2 + 1
+    cols = torch.empty(Nimg * Ho * Wo, C * k * k, device=x.device)
+    check(lib().genrl_im2col_s2(_p(x), _p(cols), Nimg, Hi, Wi, C, k, mode, _stream()), 'im2col')
+    return cols
+
+
+def _col2im(cols, bias, Nimg, Ha, Wa, C, k, Ho=0, Wo=0, nchw=False):
+    ho = Ho if Ho > 0 else 2 * (Ha - 1) + k
+    wo = Wo if Wo > 0 else 2 * (Wa - 1) + k
+    shape = (Nimg, C, ho, wo) if nchw else (Nimg, ho, wo, C)
+    out = torch.empty(shape, device=cols.device)
+    check(lib().genrl_col2im_s2(_p(cols), _p(bias), _p(out), Nimg, Ha, Wa, C, k, Ho, Wo, int(nchw), _stream()), 'col2im')
+    return out
+
+
+class _Conv2dS2(Function):
+    """nn.Conv2d(k, stride 2).  x: f32 NHWC (N,H,W,C) or u8 NCHW (N,C,H,W) [preprocess fused];
+    W (Co,Ci,k,k); returns NHWC (N,Ho,Wo,Co)."""
+    @staticmethod
+    def forward(ctx, x, W, b):
+        u8 = x.dtype == torch.uint8
+        x = x.contiguous()
+        if u8:
+            Nimg, C, Hi, Wi = x.shape
+        else:
+            Nimg, Hi, Wi, C = x.shape
+        Co, _, k, _ = W.shape
+        cols = _im2col(x, Nimg, Hi, Wi, C, k, 2 if u8 else 0)
+        M, K = cols.shape
+        y = torch.empty(M, Co, device=x.device)
+        sgemm(cols, K, 1, W, K, 1, y, Co, b, M, Co, K)
+        ctx.save_for_backward(x, W)
+        ctx.dims = (Nimg, Hi, Wi, C, k, u8)
+        Ho, Wo = (Hi - k) // 2 + 1, (Wi - k) // 2 + 1
+        return y.reshape(Nimg, Ho, Wo, Co)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        Nimg, Hi, Wi, C, k, u8 = ctx.dims
+        Co = W.shape[0]
+        K = C * k * k
+        Ho, Wo = (Hi - k) // 2 + 1, (Wi - k) // 2 + 1
+        M = Nimg * Ho * Wo
+        dy2 = dy.reshape(M, Co).contiguous()
+        dx = dW = db = None
+        if ctx.needs_input_grad[1]:
+            cols = _im2col(x, Nimg, Hi, Wi, C, k, 2 if u8 else 0)     # recomputed, not stored
+            dW = torch.empty(Co, K, device=dy.device)
+            sgemm(dy2, 1, Co, cols, 1, K, dW, K, None, Co, K, M)
+            dW = dW.reshape(W.shape)
+            del cols
+        if ctx.needs_input_grad[2]:
+            db = colsum(dy2)
+        if (not u8) and ctx.needs_input_grad[0]:
+            dcols = torch.empty(M, K, device=dy.device)
+            sgemm(dy2, Co, 1, W, 1, K, dcols, K, None, M, K, Co)      # dcols = dy W
+            dx = _col2im(dcols, None, Nimg, Ho, Wo, C, k, Hi, Wi)
+        return dx, dW, db
+
+
+def conv2d_s2(x, W, b):
+    return _Conv2dS2.apply(x, W, b)
+
+
+class _ConvT2dS2(Function):
+    """nn.ConvTranspose2d(k, stride 2).  x NHWC (N,Hi,Wi,Ci); W (Ci,Co,k,k); returns NHWC."""
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x = _f32(x).contiguous()
+        Nimg, Hi, Wi, Ci = x.shape
+        _, Co, k, _ = W.shape
+        M, Nw = Nimg * Hi * Wi, Co * k * k
+        cols = torch.empty(M, Nw, device=x.device)
+        sgemm(x, Ci, 1, W, 1, Nw, cols, Nw, None, M, Nw, Ci)          # cols = x W
+        y = _col2im(cols, b, Nimg, Hi, Wi, Co, k)
+        ctx.save_for_backward(x, W)
+        ctx.dims = (Nimg, Hi, Wi, Ci, Co, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        Nimg, Hi, Wi, Ci, Co, k = ctx.dims
+        Ho, Wo = 2 * (Hi - 1) + k, 2 * (Wi - 1) + k
+        M, Nw = Nimg * Hi * Wi, Co * k * k
+        dy = dy.contiguous()
+        dcols = _im2col(dy, Nimg, Ho, Wo, Co, k, 0)                   # (M, Nw)
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, Ci, device=dy.device)
+            sgemm(dcols, Nw, 1, W, Nw, 1, dx, Ci, None, M, Ci, Nw)    # dx = dcols W^T
+            dx = dx.reshape(Nimg, Hi, Wi, Ci)
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty(Ci, Nw, device=dy.device)
+            sgemm(x, 1, Ci, dcols, 1, Nw, dW, Nw, None, Ci, Nw, M)    # dW = x^T dcols
+            dW = dW.reshape(W.shape)
+        if ctx.needs_input_grad[2]:
+            db = colsum(dy.reshape(-1, Co))
+        return dx, dW, db
+
+
+def convT2d_s2(x, W, b):
+    return _ConvT2dS2.apply(x, W, b)
+
+
+class _TransposeLast2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return transpose_last2_raw(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return transpose_last2_raw(g.contiguous())
+
+
+def transpose_last2(x):
+    """(B,P,C) -> (B,C,P) contiguous"""
+    return _TransposeLast2.apply(x)
+
+
+# ------------------------------------------------------------------ optimiser
+
+def grad_norm(g_flat, out, scale=1.0):
+    ws = _ws(lib().genrl_sqnorm_ws_floats(g_flat.numel()), g_flat.device)
+    check(lib().genrl_grad_norm(_p(g_flat), g_flat.numel(), _p(out), _p(ws), scale, _stream()), 'grad_norm')
+    return out
+
+
+def adam_step(p, g, m, v, norm, gscale, clip, lr, eps, wd, step, b1=0.9, b2=0.999):
+    check(lib().genrl_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(norm), gscale, clip, lr, b1, b2, eps, wd,
+                                step, _stream()), 'adam_step')
+
+
+def scale_(p, s):
+    check(lib().genrl_scale(_p(p), p.numel(), s, _stream()), 'scale')

@@ -1,0 +1,110 @@
+/* genrl_hip.h — C-ABI of libgenrl_hip.so: the MI355X (gfx950) kernels under the GenRL
+ * world-model + imagination hot path.
+ *
+ * The reference (mazpie/genrl) has no FFI of its own: its hot path is Python calling
+ * torch.nn / torch.distributions.  This header is the boundary a maintainer binds
+ * instead (ctypes stub in INTEGRATION.md; genrl_amd/_lib.py is that stub).  Conventions:
+ *   - plain pointers (device memory, fp32 unless stated) and sizes; no torch types;
+ *   - `stream` is a hipStream_t passed as void*; entry points only enqueue work on it, never
+ *     synchronise and never allocate (workspaces `ws` are caller-provided, sizes from *_ws_floats);
+ *   - return 0 on success, 1 invalid argument, 2 launch failure; no exceptions cross the ABI.
+ * Each entry cites the reference code (file:line under /root/reference) whose arithmetic it
+ * replaces.
+ */
+#ifndef GENRL_HIP_H
+#define GENRL_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- dense products: nn.Linear fwd/dgrad/wgrad (agent/dreamer_utils.py:339-346,734,760,798)
+ * C[m,n] = sum_k A[m*a_rs+k*a_ks] * B[n*b_rs+k*b_ks] (+bias[n]) (+C if accumulate);
+ * one stride of each operand must be 1.  fp32 MFMA (v_mfma_f32_32x32x2_f32). */
+int genrl_sgemm(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks, float* C, long ldc,
+                const float* bias, int M, int N, int K, int accumulate, void* stream);
+
+/* ---- LayerNorm(+SiLU): NormLayer + act (agent/dreamer_utils.py:844-859,462-463,745) and, on NHWC
+ * activations, ImgChLayerNorm (:1031-1040).  act: 0 none, 1 SiLU. */
+int genrl_ln_act_fwd(const float* x, long ldx, const float* gamma, const float* beta, float* y, long ldy, float* mean,
+                     float* rstd, int M, int N, float eps, int act, void* stream);
+long genrl_ln_ws_floats(int M, int N);
+int genrl_ln_act_bwd(const float* dy, long lddy, const float* x, long ldx, const float* gamma, const float* beta,
+                     const float* mean, const float* rstd, float* dx, long lddx, float* dgamma, float* dbeta, float* ws,
+                     int M, int N, int act, int accumulate_params, void* stream);
+/* column sums (bias gradients) */
+long genrl_colsum_ws_floats(int M, int N);
+int genrl_colsum(const float* x, long ldx, float* out, float* ws, int M, int N, int accumulate, void* stream);
+
+/* ---- GRU gate block: GRUCell.forward after the projection (agent/dreamer_utils.py:778-785) */
+int genrl_gru_gates_fwd(const float* pre, const float* h, long ldh, const float* gamma, const float* beta, float* hout,
+                        long ldo, float* mean, float* rstd, int R, int D, float eps, void* stream);
+int genrl_gru_gates_bwd(const float* dhout, long lddo, const float* pre, const float* h, long ldh, const float* gamma,
+                        const float* beta, const float* mean, const float* rstd, float* dpre, float* dh, long lddh,
+                        float* dgamma, float* dbeta, float* ws, int R, int D, int dh_accumulate, int accumulate_params,
+                        void* stream);
+
+/* ---- actor Normal head: DistLayer 'normal' + rsample (agent/dreamer_utils.py:814-819) */
+int genrl_actor_head_fwd(const float* raw, const float* eps, float* action, float* mean, float* std, long R, int A,
+                         float min_std, float max_std, void* stream);
+int genrl_actor_head_bwd(const float* daction, const float* raw, const float* eps, float* draw, long R, int A,
+                         float min_std, float max_std, void* stream);
+
+/* strided 2-D copy with optional per-row scale (is_first reset mask, agent/dreamer_utils.py:433-435;
+ * torch.cat of [stoch, action] / [x, deter], :461,:777) */
+int genrl_copy2d(const float* src, long lds, float* dst, long ldd, long rows, int cols, const float* rowscale,
+                 int accumulate, void* stream);
+
+/* ---- categorical latents: OneHotDist (agent/dreamer_utils.py:177-197), sample with injected
+ * exponential noise q (argmax p/q == torch.multinomial), mode when q == NULL; straight-through bwd */
+int genrl_onehot_fwd(const float* logits, const float* q, float* sample, float* probs, long G, int K, float unimix,
+                     void* stream);
+int genrl_onehot_bwd(const float* logits, const float* gsample, float* dlogits, long G, int K, float unimix,
+                     int accumulate, void* stream);
+/* KL(Independent(OneHotDist(lp)) || Independent(OneHotDist(lq))) per row + entropies
+ * (EnsembleRSSM.kl_loss, agent/dreamer_utils.py:534-555; agent/dreamer.py:249-250) */
+int genrl_cat_kl_fwd(const float* lp, const float* lq, float* kl, float* ent_p, float* ent_q, long R, int S, int K,
+                     float unimix, void* stream);
+int genrl_cat_kl_bwd(const float* lp, const float* lq, const float* gp, const float* gq, float* dlp, float* dlq, long R,
+                     int S, int K, float unimix, void* stream);
+
+/* ---- TwoHotDist (agent/dreamer_utils.py:120-171): mode 0 log_prob(x), mode 1 mean */
+int genrl_twohot_fwd(const float* logits, const float* x, const float* buckets, float* out, long R, int mode,
+                     void* stream);
+int genrl_twohot_bwd(const float* logits, const float* x, const float* buckets, const float* gout, float* dlogits,
+                     long R, int mode, void* stream);
+
+/* ---- lambda_return (agent/dreamer_utils.py:228-253): reward [H,N], value [H+1,N] */
+int genrl_lambda_return_fwd(const float* reward, const float* value, float* ret, int H, long N, float disc, float lam,
+                            void* stream);
+int genrl_lambda_return_bwd(const float* gret, float* dreward, float* dvalue, int H, long N, float disc, float lam,
+                            void* stream);
+
+/* ---- MSEDist.log_prob against uint8 frames (agent/dreamer_utils.py:74-83; agent/dreamer.py:294-295) */
+int genrl_mse_fwd(const float* mean, const uint8_t* obs, float* like, long Nimg, int E, void* stream);
+int genrl_mse_bwd(const float* mean, const uint8_t* obs, const float* glike, float* dmean, long Nimg, int E,
+                  void* stream);
+
+/* ---- imagination reward: max_cosine_similarity + align_sequence index (tools/genrl_utils.py:240-242,344-366) */
+int genrl_maxcos_fwd(const float* u, const float* v, const long* urow, float* out, long R, int E, void* stream);
+int genrl_maxcos_bwd(const float* u, const float* v, const long* urow, const float* gout, float* dv, long R, int E,
+                     void* stream);
+int genrl_align_index(const float* ct, const float* ca, long* urow, int T, long N, int E, int nf, void* stream);
+
+/* ---- stride-2 conv data movement (Encoder/Decoder, agent/dreamer_utils.py:578-589,654-671) */
+int genrl_im2col_s2(const void* in, float* cols, int Nimg, int Hi, int Wi, int C, int k, int in_mode, void* stream);
+int genrl_col2im_s2(const float* cols, const float* bias, float* out, int Nimg, int Ha, int Wa, int C, int k,
+                    int Ho_override, int Wo_override, int out_nchw, void* stream);
+int genrl_transpose_last2(const float* in, float* out, long B, int P, int C, void* stream);
+
+/* ---- Optimizer.__call__ (agent/dreamer_utils.py:892-932) on flat buffers */
+long genrl_sqnorm_ws_floats(long n);
+int genrl_grad_norm(const float* g, long n, float* norm_out, float* ws, float scale, void* stream);
+int genrl_adam_step(float* p, const float* g, float* m, float* v, long n, const float* norm, float gscale, float clip,
+                    float lr, float b1, float b2, float eps, float wd, int step, void* stream);
+int genrl_scale(float* p, long n, float s, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,185 @@
+"""GPU parity of every HIP op (through the C-ABI, genrl_amd/ops.py) against the CPU oracle on the
+same seeded inputs: forward values and all input gradients.  fp32; tolerance stated per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import genrl_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('needs MI355X')
+    import genrl_amd.ops as ops_
+    return ops_
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def compare(hip_fn, ref_fn, inputs, rtol=2e-5, atol=2e-5, grad_mask=None, nondiff=()):
+    """inputs: list of CPU tensors.  Float tensors not in `nondiff` get gradients checked."""
+    cpu = [t.clone().requires_grad_(t.is_floating_point() and i not in nondiff) for i, t in enumerate(inputs)]
+    dev = [t.clone().cuda().requires_grad_(t.is_floating_point() and i not in nondiff) for i, t in enumerate(inputs)]
+    r = ref_fn(*cpu); h = hip_fn(*dev)
+    r = r if isinstance(r, (tuple, list)) else (r,)
+    h = h if isinstance(h, (tuple, list)) else (h,)
+    lr = lh = 0
+    for i, (a, b) in enumerate(zip(r, h)):
+        np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().numpy(), rtol=rtol, atol=atol, err_msg=f'out{i}')
+        if a.requires_grad:
+            w = torch.randn(a.shape, generator=g(100 + i))
+            lr = lr + (a * w).sum(); lh = lh + (b * w.cuda()).sum()
+    if torch.is_tensor(lr):
+        lr.backward(); lh.backward()
+        for i, (a, b) in enumerate(zip(cpu, dev)):
+            if a.requires_grad and a.grad is not None:
+                scale = max(1.0, a.grad.abs().max().item())
+                np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.numpy(), rtol=rtol * 5, atol=atol * scale,
+                                           err_msg=f'grad{i}')
+
+
+@pytest.mark.parametrize('M,N,K', [(64, 64, 16), (1, 1, 1), (37, 53, 29), (130, 70, 1034), (32, 255, 96),
+                                   (1024, 1024, 256), (2048, 4096, 64), (96, 16, 26)])
+def test_linear(ops, M, N, K):
+    x = torch.randn(M, K, generator=g(1)); W = torch.randn(N, K, generator=g(2)) / K ** 0.5
+    b = torch.randn(N, generator=g(3))
+    compare(ops.linear, F.linear, [x, W, b], rtol=1e-4, atol=1e-4)
+
+
+def test_sgemm_exact_layout(ops):
+    """transpose-detecting: asymmetric small-integer operands must be reproduced exactly"""
+    M, N, K = 70, 45, 33
+    A = torch.arange(M * K, dtype=torch.float32).reshape(M, K) % 7 - 3
+    B = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) * 3) % 5 - 2
+    C = torch.empty(M, N, device='cuda')
+    ops.sgemm(A.cuda(), K, 1, B.cuda(), K, 1, C, N, None, M, N, K)
+    assert torch.equal(C.cpu(), A @ B.T)
+    # row-contiguous operands + accumulate
+    At, Bt = A.T.contiguous().cuda(), B.T.contiguous().cuda()
+    ops.sgemm(At, 1, M, Bt, 1, N, C, N, None, M, N, K, accumulate=True)
+    assert torch.equal(C.cpu(), 2 * (A @ B.T))
+
+
+@pytest.mark.parametrize('M,N,act', [(5, 32, 1), (300, 1024, 1), (64, 3072, 0), (33, 48, 1)])
+def test_ln_act(ops, M, N, act):
+    x = torch.randn(M, N, generator=g(1)) * 2 + 0.3
+    ga = 1 + 0.1 * torch.randn(N, generator=g(2)); be = 0.1 * torch.randn(N, generator=g(3))
+    ref = lambda x, ga, be: (F.silu if act else (lambda t: t))(F.layer_norm(x, (N,), ga, be, 1e-3))
+    compare(lambda x, ga, be: ops.ln_act(x, ga, be, 1e-3, act), ref, [x, ga, be], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('R,D', [(7, 12), (128, 1024)])
+def test_gru_gates(ops, R, D):
+    pre = torch.randn(R, 3 * D, generator=g(1)); h = torch.randn(R, D, generator=g(2))
+    ga = 1 + 0.1 * torch.randn(3 * D, generator=g(3)); be = 0.1 * torch.randn(3 * D, generator=g(4))
+
+    def ref(pre, h, ga, be):
+        parts = F.layer_norm(pre, (3 * D,), ga, be, 1e-5)
+        r, c, u = torch.chunk(parts, 3, -1)
+        r = torch.sigmoid(r); c = torch.tanh(r * c); u = torch.sigmoid(u - 1.0)
+        return u * c + (1 - u) * h
+    compare(ops.gru_gates, ref, [pre, h, ga, be], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('R,S,K', [(9, 4, 4), (64, 32, 32), (5, 3, 7)])
+def test_onehot_and_kl(ops, R, S, K):
+    lg = torch.randn(R, S, K, generator=g(1)) * 2; lq = torch.randn(R, S, K, generator=g(2)) * 2
+    q = torch.empty(R * S, K).exponential_(1, generator=g(3))
+    compare(lambda l: ops.onehot_sample(l, q.cuda()), lambda l: O.onehot_sample(l, q), [lg], rtol=1e-4, atol=1e-6)
+    assert torch.equal(ops.onehot_mode(lg.cuda()).cpu(), O.onehot_mode(lg).detach())
+    compare(ops.cat_kl, O.cat_kl, [lg, lq], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ops.cat_entropy(lg.cuda()).cpu().numpy(), O.cat_entropy(lg).numpy(), rtol=1e-5)
+
+
+def test_twohot(ops):
+    lg = torch.randn(6, 5, 255, generator=g(1))
+    x = torch.tensor([-30., -20., -3.3, 0., 0.5, 19.999]).reshape(6, 1, 1) * torch.tensor([1., .5, 1.7, -1., 1e-3]).reshape(1, 5, 1)
+    compare(lambda l: ops.twohot_logprob(l, x.cuda()), lambda l: O.twohot_logprob(l, x), [lg], rtol=1e-4, atol=1e-5)
+    compare(ops.twohot_mean, O.twohot_mean, [lg], rtol=1e-4, atol=1e-5)
+
+
+def test_lambda_return(ops):
+    H, N = 16, 70
+    r = torch.rand(H, N, 1, generator=g(1)); v = torch.randn(H + 1, N, 1, generator=g(2))
+    ref = lambda r, v: O.lambda_return(r, v[:-1], 0.99 * torch.ones_like(r), v[-1], 0.95)
+    compare(lambda r, v: ops.lambda_return(r, v, 0.99, 0.95), ref, [r, v], rtol=1e-5, atol=1e-6)
+
+
+def test_mse_maxcos_actor(ops):
+    m = torch.randn(3, 3, 16, 16, generator=g(1)) * 0.3
+    o = torch.randint(0, 256, (3, 3, 16, 16), generator=g(2), dtype=torch.uint8)
+    compare(lambda m: ops.mse_like(m, o.cuda()), lambda m: -((m - (o / 255.0 - 0.5)) ** 2).sum([1, 2, 3]), [m],
+            rtol=1e-5, atol=1e-4)
+    u = torch.randn(5, 7, 48, generator=g(3)); v = torch.randn(5, 7, 48, generator=g(4)) * torch.rand(5, 7, 1, generator=g(5)) * 2
+    compare(lambda v: ops.maxcos(u.cuda(), v), lambda v: O.max_cosine_similarity(u, v), [v], rtol=1e-4, atol=1e-6)
+    idx = torch.randint(0, 35, (5, 7), generator=g(6))
+    compare(lambda v: ops.maxcos(u.cuda(), v, idx.cuda()), lambda v: O.max_cosine_similarity(u.reshape(35, 48)[idx], v),
+            [v], rtol=1e-4, atol=1e-6)
+    raw = torch.randn(9, 20, generator=g(7)); eps = torch.randn(9, 10, generator=g(8))
+
+    def ref(raw):
+        mean = torch.tanh(raw[:, :10]); std = 0.9 * torch.sigmoid(raw[:, 10:] + 2.0) + 0.1
+        return mean + std * eps
+    compare(lambda r: ops.actor_sample(r, eps.cuda()), ref, [raw], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('N,Hi,C,Co,k', [(2, 16, 3, 8, 4), (3, 31, 8, 16, 4), (2, 6, 16, 32, 4), (1, 63, 4, 4, 4)])
+def test_conv2d_s2(ops, N, Hi, C, Co, k):
+    x = torch.randn(N, C, Hi, Hi, generator=g(1)); W = torch.randn(Co, C, k, k, generator=g(2)) / (C * k * k) ** .5
+    b = torch.randn(Co, generator=g(3))
+    ref = lambda x, W, b: F.conv2d(x, W, b, stride=2).permute(0, 2, 3, 1)
+    compare(lambda x, W, b: ops.conv2d_s2(x.permute(0, 2, 3, 1).contiguous(), W, b), ref, [x, W, b], rtol=1e-4, atol=1e-4)
+
+
+def test_conv2d_s2_u8(ops):
+    o = torch.randint(0, 256, (2, 3, 64, 64), generator=g(1), dtype=torch.uint8)
+    W = torch.randn(48, 3, 4, 4, generator=g(2)) / 7; b = torch.randn(48, generator=g(3))
+    ref = lambda W, b: F.conv2d(o / 255.0 - 0.5, W, b, stride=2).permute(0, 2, 3, 1)
+    compare(lambda W, b: ops.conv2d_s2(o.cuda(), W, b), ref, [W, b], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('N,Hi,Ci,Co,k', [(2, 1, 32, 8, 5), (2, 5, 8, 4, 5), (3, 13, 4, 6, 6), (1, 30, 6, 3, 6)])
+def test_convT2d_s2(ops, N, Hi, Ci, Co, k):
+    x = torch.randn(N, Ci, Hi, Hi, generator=g(1)); W = torch.randn(Ci, Co, k, k, generator=g(2)) / (Ci * k) ** .5
+    b = torch.randn(Co, generator=g(3))
+    ref = lambda x, W, b: F.conv_transpose2d(x, W, b, stride=2).permute(0, 2, 3, 1)
+    compare(lambda x, W, b: ops.convT2d_s2(x.permute(0, 2, 3, 1).contiguous(), W, b), ref, [x, W, b], rtol=1e-4, atol=1e-4)
+
+
+def test_transpose_and_cat(ops):
+    x = torch.randn(3, 4, 6, generator=g(1))
+    compare(ops.transpose_last2, lambda x: x.transpose(1, 2).contiguous(), [x])
+    a, b = torch.randn(5, 7, generator=g(2)), torch.randn(5, 3, generator=g(3))
+    mask = torch.tensor([1., 0., 1., 1., 0.])
+    out = ops.cat_cols([a.cuda(), b.cuda()], mask.cuda()).cpu()
+    assert torch.equal(out, torch.cat([a, b], -1) * mask[:, None])
+
+
+def test_adam_and_norm(ops):
+    n = 100003
+    p = torch.randn(n, generator=g(1)); gr = torch.randn(n, generator=g(2)) * 3
+    pc = {'w': p.clone()}; st = {}
+    pd, gd = p.cuda(), gr.cuda(); m = torch.zeros(n, device='cuda'); v = torch.zeros(n, device='cuda')
+    norm = torch.empty(1, device='cuda')
+    for step in (1, 2):
+        ref_norm = O.optimizer_step(pc, {'w': gr}, st, lr=1e-3, eps=1e-8, clip=100.0, wd=1e-6)
+        ops.grad_norm(gd, norm)
+        ops.adam_step(pd, gd, m, v, norm, 1.0, 100.0, 1e-3, 1e-8, 1e-6, step)
+        np.testing.assert_allclose(norm.item(), ref_norm.item(), rtol=1e-5)
+        np.testing.assert_allclose(pd.cpu().numpy(), pc['w'].numpy(), rtol=1e-5, atol=2e-6)
+
+
+def test_align_index(ops):
+    T, N, E, nf = 17, 6, 24, 8
+    ct = torch.randn(T, N, E, generator=g(1)); ca = torch.randn(T, N, E, generator=g(2))
+    scores = torch.stack([O.max_cosine_similarity(ct[:nf], ca[t:t + nf]).mean(0) for t in range(T - nf)], 0)
+    best = scores.argmax(0)
+    ref = (torch.clamp(torch.arange(T)[:, None] - best[None], min=0)) * N + torch.arange(N)[None]
+    got = ops.align_index(ct.cuda(), ca.cuda(), nf).cpu()
+    assert torch.equal(got, ref)
