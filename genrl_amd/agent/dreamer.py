@@ -1,0 +1,374 @@
+"""MI355X-native `agent/dreamer.py`: DreamerAgent, WorldModel, ActorCritic with the reference's
+API (mazpie/genrl agent/dreamer.py) on top of the HIP kernels.  Same attribute / method /
+metric names; see SURVEY.md §8b for the call contract with train.py."""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import dreamer_utils as common
+from .. import noise, ops
+from ..tools.genrl_utils import *          # reward functions resolved through globals(), ref :9
+
+
+def stop_gradient(x):
+    return x.detach()
+
+
+Module = nn.Module
+
+
+def env_reward(agent, seq):  # ref :16-17
+    return agent.wm.heads['reward'](seq['feat']).mean
+
+
+class DreamerAgent(Module):  # ref :19-118
+    def __init__(self, name, cfg, obs_space, act_spec, **kwargs):
+        super().__init__()
+        self.name = name
+        self.cfg = cfg
+        self.cfg.update(**kwargs)
+        self.obs_space = obs_space
+        self.act_spec = act_spec
+        self._use_amp = (cfg.precision == 16)
+        self.device = cfg.device
+        self.act_dim = act_spec.shape[0]
+        self.wm = WorldModel(cfg, obs_space, self.act_dim)
+        self.instantiate_acting_behavior()
+        self.to(cfg.device)
+        self.requires_grad_(requires_grad=False)
+
+    def instantiate_acting_behavior(self):
+        self._acting_behavior = ActorCritic(self.cfg, self.act_spec, self.wm.inp_size).to(self.device)
+
+    def act(self, obs, meta, step, eval_mode, state):  # ref :41-64
+        if self.cfg.only_random_actions:
+            return np.random.uniform(-1, 1, self.act_dim).astype(self.act_spec.dtype), (None, None)
+        obs = {k: torch.as_tensor(np.copy(v), device=self.device).unsqueeze(0) for k, v in obs.items()}
+        if state is None:
+            latent = self.wm.rssm.initial(len(obs['reward']))
+            action = torch.zeros((len(obs['reward']),) + self.act_spec.shape, device=self.device)
+        else:
+            latent, action = state
+        with torch.no_grad():
+            embed = self.wm.encoder(self.wm.preprocess(obs))
+            should_sample = (not eval_mode) or (not self.cfg.eval_state_mean)
+            latent, _ = self.wm.rssm.obs_step(latent, action, embed, obs['is_first'], should_sample)
+            actor = self._acting_behavior.actor(self.wm.rssm.get_stoch(latent), latent['deter'])
+            action = actor.mean if eval_mode else actor.sample()
+        return action.cpu().numpy()[0], (latent, action)
+
+    def update_wm(self, data, step):  # ref :66-71
+        metrics = {}
+        state, outputs, mets = self.wm.update(data, state=None)
+        outputs['is_terminal'] = data['is_terminal']
+        metrics.update(mets)
+        return state, outputs, metrics
+
+    def update_acting_behavior(self, state=None, outputs=None, metrics={}, data=None, reward_fn=None):  # ref :73-92
+        if self.cfg.only_random_actions:
+            return {}, metrics
+        if outputs is not None:
+            post, is_terminal = outputs['post'], outputs['is_terminal']
+        else:
+            data = self.wm.preprocess(data)
+            with torch.no_grad():
+                post, _ = self.wm.rssm.observe(self.wm.encoder(data), data['action'], data['is_first'])
+            is_terminal = data['is_terminal']
+        start = {k: stop_gradient(v) for k, v in post.items()}
+        if reward_fn is None:
+            acting_reward_fn = lambda seq: globals()[self.cfg.acting_reward_fn](self, seq)
+        else:
+            acting_reward_fn = lambda seq: reward_fn(self, seq)
+        metrics.update(self._acting_behavior.update(self.wm, start, is_terminal, acting_reward_fn))
+        return start, metrics
+
+    def update(self, data, step):
+        state, outputs, metrics = self.update_wm(data, step)
+        start, metrics = self.update_acting_behavior(state, outputs, metrics, data)
+        return state, metrics
+
+    def report(self, data):  # ref :99-109
+        report = {}
+        data = self.wm.preprocess(data)
+        with torch.no_grad():
+            for key in self.wm.heads['decoder'].cnn_keys:
+                report[f'openl_{key.replace("/", "_")}'] = self.wm.video_pred(data, key)
+            for fn in getattr(self.cfg, 'additional_report_fns', []):
+                report.update(globals()[fn](self, data))
+        return report
+
+    def get_meta_specs(self):
+        return tuple()
+
+    def init_meta(self):
+        return OrderedDict()
+
+    def update_meta(self, meta, global_step, time_step, finetune=False):
+        return meta
+
+
+class WorldModel(Module):  # ref :120-321
+    def __init__(self, config, obs_space, act_dim):
+        super().__init__()
+        shapes = {k: tuple(v.shape) for k, v in obs_space.items()}
+        self.shapes = shapes
+        self.cfg = config
+        self.device = config.device
+        self.encoder = common.Encoder(shapes, **config.encoder)
+        key = self.encoder.cnn_keys[0]
+        sizes = common._conv_sizes(shapes[key][-1], config.encoder['cnn_kernels'])
+        embed_dim = 2 ** (len(sizes) - 1) * self.encoder._cnn_depth * sizes[-1] ** 2     # ref :129-132
+        self.embed_dim = embed_dim
+        self.rssm = common.EnsembleRSSM(**config.rssm, action_dim=act_dim, embed_dim=embed_dim, device=self.device)
+        self.heads = {}
+        self._use_amp = (config.precision == 16)
+        self.inp_size = self.rssm.get_feat_size()
+        self.decoder_input_fn = getattr(self.rssm, f'get_{config.decoder_inputs}')
+        self.decoder_input_size = getattr(self.rssm, f'get_{config.decoder_inputs}_size')()
+        self.heads['decoder'] = common.Decoder(shapes, **config.decoder, embed_dim=self.decoder_input_size,
+                                               image_dist=config.image_dist)
+        self.heads['reward'] = common.MLP(self.inp_size, (1,), **config.reward_head)
+        with torch.no_grad():
+            for p in self.heads['reward']._out.parameters():
+                p.data = p.data * 0
+        assert not config.pred_discount, 'discount head is not on the GenRL path (conf/env/dmc_pixels.yaml:6)'
+        for name in config.grad_heads:
+            assert name in self.heads, name
+        self.grad_heads = config.grad_heads
+        self.heads = nn.ModuleDict(self.heads)
+        self.model_opt = common.Optimizer('model', self.parameters(), **config.model_opt, use_amp=self._use_amp)
+        self.e2e_update_fns = {}
+        self.detached_update_fns = {}
+        self.eval()
+
+    def add_module_to_update(self, name, module, update_fn, detached=False):  # ref :158-164
+        self.add_module(name, module)
+        (self.detached_update_fns if detached else self.e2e_update_fns)[name] = update_fn
+        self.model_opt = common.Optimizer('model', self.parameters(), **self.cfg.model_opt, use_amp=self._use_amp)
+
+    def update(self, data, state=None):  # ref :166-187
+        self.train()
+        with common.RequiresGrad(self):
+            assert not (getattr(self.cfg, 'freeze_decoder', False) or getattr(self.cfg, 'freeze_post', False)
+                        or getattr(self.cfg, 'freeze_model', False)), 'freeze_* modes are off the north-star path'
+            model_loss, state, outputs, metrics = self.loss(data, state)
+            model_loss, metrics = self.update_additional_e2e_modules(data, outputs, model_loss, metrics)
+            metrics.update(self.model_opt(model_loss, self.parameters()))
+        if len(self.detached_update_fns) > 0:
+            detached_loss, metrics = self.update_additional_detached_modules(data, outputs, metrics)
+        self.eval()
+        return state, outputs, metrics
+
+    def update_additional_detached_modules(self, data, outputs, metrics):  # ref :189-200
+        detached_loss = 0
+        for k in self.detached_update_fns:
+            detached_module = getattr(self, k)
+            with common.RequiresGrad(detached_module):
+                add_loss, add_metrics = self.detached_update_fns[k](self, k, data, outputs, metrics)
+                metrics.update(add_metrics)
+                opt_metrics = self.model_opt(add_loss, detached_module.parameters())
+                metrics.update({f'{k}_{m}': opt_metrics[m] for m in opt_metrics})
+        return detached_loss, metrics
+
+    def update_additional_e2e_modules(self, data, outputs, model_loss, metrics):  # ref :202-208
+        for k in self.e2e_update_fns:
+            add_loss, add_metrics = self.e2e_update_fns[k](self, k, data, outputs, metrics)
+            model_loss = model_loss + add_loss
+            metrics.update(add_metrics)
+        return model_loss, metrics
+
+    def observe_data(self, data, state=None):  # ref :210-217
+        data = self.preprocess(data)
+        embed = self.encoder(data)
+        post, prior = self.rssm.observe(embed, data['action'], data['is_first'], state)
+        kl_loss, kl_value = self.rssm.kl_loss(post, prior, **self.cfg.kl)
+        outs = dict(embed=embed, post=post, prior=prior, is_terminal=data['is_terminal'])
+        return outs, {'model_kl': kl_value.mean()}
+
+    def loss(self, data, state=None):  # ref :219-252
+        data = self.preprocess(data)
+        embed = self.encoder(data)
+        post, prior = self.rssm.observe(embed, data['action'], data['is_first'], state)
+        kl_loss, kl_value = self.rssm.kl_loss(post, prior, **self.cfg.kl)
+        assert len(kl_loss.shape) == 0 or (len(kl_loss.shape) == 1 and kl_loss.shape[0] == 1), kl_loss.shape
+        likes = {}
+        losses = {'kl': kl_loss}
+        feat = self.rssm.get_feat(post)
+        for name, head in self.heads.items():
+            grad_head = (name in self.grad_heads)
+            if name == 'decoder':
+                inp = self.decoder_input_fn(post)
+                inp = inp if grad_head else stop_gradient(inp)
+                out = head(inp)
+            else:       # MLP heads consume feat = [stoch, deter] without the concatenation
+                s, d = self.rssm.get_stoch(post), post['deter']
+                if not grad_head:
+                    s, d = stop_gradient(s), stop_gradient(d)
+                out = head(s, d)
+            dists = out if isinstance(out, dict) else {name: out}
+            for key, dist in dists.items():
+                like = dist.log_prob(data[key])
+                likes[key] = like
+                losses[key] = -like.mean()
+        model_loss = sum(self.cfg.loss_scales.get(k, 1.0) * v for k, v in losses.items())
+        outs = dict(embed=embed, feat=feat, post=post, prior=prior, likes=likes, kl=kl_value)
+        metrics = {f'{name}_loss': value for name, value in losses.items()}
+        metrics['model_kl'] = kl_value.mean()
+        metrics['prior_ent'] = self.rssm.get_dist(prior).entropy().mean()
+        metrics['post_ent'] = self.rssm.get_dist(post).entropy().mean()
+        last_state = {k: v[:, -1] for k, v in post.items()}
+        return model_loss, last_state, outs, metrics
+
+    def imagine(self, policy, start, is_terminal, horizon, task_cond=None, eval_policy=False):  # ref :254-287
+        assert task_cond is None
+        flatten = lambda x: x.reshape([-1] + list(x.shape[2:]))
+        start = {k: flatten(v) for k, v in start.items()}
+        N = start['deter'].shape[0]
+        dev = start['deter'].device
+        A = policy._out._out.out_features
+        eps = noise.draw('normal', 'imag.act_eps', (horizon, N, A), dev) if not eval_policy else None
+        q = noise.draw('exp', 'imag.step_q', (horizon, N * self.rssm._stoch, self.rssm._discrete), dev)
+        rssm = self.rssm
+        seq = {k: [v] for k, v in start.items()}
+        seq['action'] = [torch.zeros(N, A, device=dev)]
+        for h in range(horizon):
+            stoch, deter = seq['stoch'][-1], seq['deter'][-1]
+            s_flat = stoch.reshape(N, -1)
+            raw = policy._out.raw(policy.trunk(stop_gradient(s_flat), stop_gradient(deter)))
+            if eval_policy:
+                action = ops.actor_mean_std(raw, policy._out._min_std, policy._out._max_std)[0]
+            else:
+                action = ops.actor_sample(raw, eps[h], policy._out._min_std, policy._out._max_std)
+            x = common._dense_ln_silu(s_flat, rssm._img_in[0], rssm._img_in[1], action)
+            deter = ops.gru_step(x, deter, rssm._cell._layer.weight, rssm._cell._norm.weight, rssm._cell._norm.bias)
+            logit = rssm._prior_logits(deter)
+            stoch = ops.onehot_sample(logit, q[h])
+            for key, value in dict(stoch=stoch, deter=deter, logit=logit, action=action).items():
+                seq[key].append(value)
+        seq = {k: torch.stack(v, 0) for k, v in seq.items()}
+        seq['feat'] = rssm.get_feat(seq)
+        disc = torch.ones(list(seq['deter'].shape[:-1]) + [1], device=dev)       # no discount head
+        seq['discount'] = disc * self.cfg.discount
+        seq['weight'] = torch.cumprod(torch.cat([torch.ones_like(disc[:1]), disc[:-1]], 0), 0)
+        return seq
+
+    def preprocess(self, obs):  # ref :289-305; uint8 frames stay uint8 (x/255-0.5 is fused downstream)
+        obs = dict(obs)
+        assert self.cfg.clip_rewards == 'identity'
+        obs['discount'] = (1.0 - obs['is_terminal'].float())
+        if 'reward' in obs and len(obs['discount'].shape) < len(obs['reward'].shape):
+            obs['discount'] = obs['discount'].unsqueeze(-1)
+        return obs
+
+    def video_pred(self, data, key, nvid=8):  # ref :307-321
+        decoder = self.heads['decoder']
+        truth = data[key][:nvid].float() / 255.0
+        embed = self.encoder(data)
+        states, _ = self.rssm.observe(embed[:nvid, :5], data['action'][:nvid, :5], data['is_first'][:nvid, :5])
+        recon = decoder(self.decoder_input_fn(states))[key].mean[:nvid]
+        init = {k: v[:, -1] for k, v in states.items()}
+        prior = self.rssm.imagine(data['action'][:nvid, 5:], init)
+        prior_recon = decoder(self.decoder_input_fn(prior))[key].mean
+        model = torch.clip(torch.cat([recon[:, :5] + 0.5, prior_recon + 0.5], 1), 0, 1)
+        error = (model - truth + 1) / 2
+        return torch.cat([truth, model, error], 3)
+
+
+class ActorCritic(Module):  # ref :323-462
+    def __init__(self, config, act_spec, feat_size, name=''):
+        super().__init__()
+        self.name = name
+        self.cfg = config
+        self.act_spec = act_spec
+        self._use_amp = (config.precision == 16)
+        self.device = config.device
+        assert not getattr(self.cfg, 'discrete_actions', False)
+        self.actor_grad = getattr(self.cfg, f'{self.name}_actor_grad'.strip('_'))
+        assert self.actor_grad == 'dynamics', 'GenRL trains the actor through the dynamics'
+        self.actor = common.MLP(feat_size, act_spec.shape[0], **self.cfg.actor)
+        self.critic = common.MLP(feat_size, (1,), **self.cfg.critic)
+        assert self.cfg.slow_target and self.cfg.reward_ema
+        self._target_critic = common.MLP(feat_size, (1,), **self.cfg.critic)
+        self._updates = 0
+        self.actor_opt = common.Optimizer('actor', self.actor.parameters(), **self.cfg.actor_opt, use_amp=self._use_amp)
+        self.critic_opt = common.Optimizer('critic', self.critic.parameters(), **self.cfg.critic_opt, use_amp=self._use_amp)
+        self.register_buffer('ema_vals', torch.zeros((2,)).to(self.device))
+        self.reward_ema = common.RewardEMA(device=self.device)
+        self.rewnorm = common.StreamNorm(momentum=1, scale=1.0, device=self.device)
+        with torch.no_grad():
+            for p in self.critic._out.parameters():
+                p.data = p.data * 0
+            for s, d in zip(self.critic.parameters(), self._target_critic.parameters()):
+                d.data = s.data.clone()
+        # the slow critic is never trained: no wgrad for it (drops the reference's waste)
+        self._target_critic.requires_grad_(False)
+
+    def update(self, world_model, start, is_terminal, reward_fn):  # ref :366-390
+        metrics = {}
+        hor = self.cfg.imag_horizon
+        self._target_critic.requires_grad_(False)
+        with common.RequiresGrad(self.actor):
+            seq = world_model.imagine(self.actor, start, is_terminal, hor)
+            reward = reward_fn(seq)
+            seq['reward'], mets1 = self.rewnorm(reward)
+            mets1 = {f'reward_{k}': v for k, v in mets1.items()}
+            target, mets2, baseline = self.target(seq)
+            actor_loss, mets3 = self.actor_loss(seq, target, baseline)
+            metrics.update(self.actor_opt(actor_loss, self.actor.parameters()))
+        with common.RequiresGrad(self.critic):
+            seq = {k: stop_gradient(v) for k, v in seq.items()}
+            critic_loss, mets4 = self.critic_loss(seq, target)
+            metrics.update(self.critic_opt(critic_loss, self.critic.parameters()))
+        metrics.update(**mets1, **mets2, **mets3, **mets4)
+        self.update_slow_target()
+        return {f'{self.name}_{k}'.strip('_'): v for k, v in metrics.items()}
+
+    def actor_loss(self, seq, target, baseline):  # ref :392-429 (actor_grad 'dynamics')
+        metrics = {}
+        offset, scale = self.reward_ema(target, self.ema_vals)
+        normed_target = (target - offset) / scale
+        metrics['normed_target_mean'] = normed_target.mean()
+        metrics['normed_target_std'] = normed_target.std()
+        metrics['reward_ema_005'] = self.ema_vals[0].clone()
+        metrics['reward_ema_095'] = self.ema_vals[1].clone()
+        objective = normed_target[1:]
+        ent_scale = self.cfg.actor_ent
+        if ent_scale != 0:
+            raise NotImplementedError('actor_ent != 0 is off the GenRL path (agent/genrl.yaml:9)')
+        with torch.no_grad():       # entropy is a metric only when its scale is 0 (no wasted backward)
+            s, d = seq['stoch'][:-2], seq['deter'][:-2]
+            ent = self.actor(s.reshape(list(s.shape[:-2]) + [-1]), d).entropy()[:, :, None]
+        metrics['actor_ent'] = ent.mean()
+        metrics['actor_ent_scale'] = ent_scale
+        weight = stop_gradient(seq['weight'])
+        actor_loss = -(weight[:-2] * objective).mean()
+        return actor_loss, metrics
+
+    def critic_loss(self, seq, target):  # ref :431-438
+        s, d = seq['stoch'][:-1], seq['deter'][:-1]
+        dist = self.critic(s.reshape(list(s.shape[:-2]) + [-1]), d)
+        target = stop_gradient(target)
+        weight = stop_gradient(seq['weight'])
+        critic_loss = -(dist.log_prob(target)[:, :, None] * weight[:-1]).mean()
+        with torch.no_grad():
+            metrics = {'critic': dist.mean.mean()}
+        return critic_loss, metrics
+
+    def target(self, seq):  # ref :440-453
+        reward, disc = seq['reward'], seq['discount']
+        s = seq['stoch']
+        value = self._target_critic(s.reshape(list(s.shape[:-2]) + [-1]), seq['deter']).mean
+        target = common.lambda_return(reward[:-1], value[:-1], self.cfg.discount, bootstrap=value[-1],
+                                      lambda_=self.cfg.discount_lambda, axis=0)
+        metrics = {'critic_slow': value.mean(), 'critic_target': target.mean()}
+        return target, metrics, value[:-1]
+
+    def update_slow_target(self):  # ref :455-462
+        if self._updates % self.cfg.slow_target_update == 0:
+            mix = 1.0 if self._updates == 0 else float(self.cfg.slow_target_fraction)
+            with torch.no_grad():
+                for s, d in zip(self.critic.parameters(), self._target_critic.parameters()):
+                    d.data.copy_(mix * s.data + (1 - mix) * d.data)
+        self._updates += 1

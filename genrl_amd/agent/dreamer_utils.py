@@ -1,0 +1,735 @@
+"""MI355X-native building blocks behind the reference's `agent/dreamer_utils.py` API.
+
+Class names, constructor signatures, sub-module and parameter names follow the reference
+(mazpie/genrl agent/dreamer_utils.py; weight contract in SURVEY.md §8a) so that `state_dict()`s and
+pickled agents are interchangeable; every forward/backward runs in the hand-written HIP kernels
+of libgenrl_hip.so (genrl_amd/ops.py).  nn.Module containers (nn.Linear, nn.Conv2d, nn.LayerNorm)
+are used only as *parameter holders*: their torch forward is never called on the hot path.
+
+Only what the GenRL path configures is implemented (norm 'layer'/'none', act SiLU, discrete
+latents, GRU cell, dists mse / twohot / normal / onehot); other reference options raise.
+"""
+import re
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import noise, ops
+
+Module = nn.Module
+
+
+def symlog(x):  # ref :13-14
+    return torch.sign(x) * torch.log(torch.abs(x) + 1.0)
+
+
+def symexp(x):  # ref :16-17
+    return torch.sign(x) * (torch.exp(torch.abs(x)) - 1.0)
+
+
+# ----------------------------------------------------------------------------- distributions
+
+class MSEDist:
+    """ref :62-83.  `log_prob` accepts the raw uint8 frames (preprocess fused into the kernel)."""
+    def __init__(self, mode, agg='sum'):
+        assert agg == 'sum'
+        self._mode = mode
+
+    @property
+    def mean(self):
+        return self._mode
+
+    def mode(self):
+        return self._mode
+
+    def log_prob(self, value):
+        assert self._mode.shape == value.shape, (self._mode.shape, value.shape)
+        if value.dtype != torch.uint8:           # already-preprocessed floats: undo (x+0.5)*255 exactly
+            value = torch.round((value + 0.5) * 255.0).to(torch.uint8)
+        lead = self._mode.shape[:-3]
+        like = ops.mse_like(self._mode.reshape((-1,) + tuple(self._mode.shape[-3:])),
+                            value.reshape((-1,) + tuple(value.shape[-3:])))
+        return like.reshape(lead)
+
+
+class TwoHotDist:
+    """ref :120-171 (255 symlog buckets in [-20, 20])."""
+    def __init__(self, logits, low=-20.0, high=20.0):
+        assert logits.shape[-1] == 255
+        assert low == -20.0 and high == 20.0
+        self.logits = logits
+
+    @property
+    def mean(self):
+        return ops.twohot_mean(self.logits)
+
+    @property
+    def mode(self):
+        return self.mean
+
+    def log_prob(self, x):
+        return ops.twohot_logprob(self.logits, x)
+
+
+class OneHotDist:
+    """ref :177-197 wrapped in Independent(.,1) (ref :413-415): unimix categorical latents."""
+    def __init__(self, logits, site='onehot'):
+        self.logits_raw = logits
+        self.site = site
+
+    def sample(self, sample_shape=()):
+        lg = self.logits_raw
+        K = lg.shape[-1]
+        q = noise.draw('exp', self.site, (lg.numel() // K, K), lg.device)
+        return ops.onehot_sample(lg, q)
+
+    def mode(self):
+        return ops.onehot_mode(self.logits_raw)
+
+    def entropy(self):
+        return ops.cat_entropy(self.logits_raw)
+
+
+def kl_divergence(p, q):
+    return ops.cat_kl(p.logits_raw, q.logits_raw)
+
+
+class NormalDist:
+    """Independent(Normal(tanh(out), std), 1) of DistLayer 'normal' (ref :814-819)."""
+    def __init__(self, raw, min_std, max_std, site='actor'):
+        self.raw, self.min_std, self.max_std, self.site = raw, min_std, max_std, site
+
+    def sample(self):
+        A = self.raw.shape[-1] // 2
+        eps = noise.draw('normal', self.site, tuple(self.raw.shape[:-1]) + (A,), self.raw.device)
+        return ops.actor_sample(self.raw, eps, self.min_std, self.max_std)
+
+    rsample = sample
+
+    @property
+    def mean(self):
+        return ops.actor_mean_std(self.raw, self.min_std, self.max_std)[0]
+
+    def entropy(self):
+        std = ops.actor_mean_std(self.raw, self.min_std, self.max_std)[1]
+        return (0.5 + 0.5 * np.log(2 * np.pi) + torch.log(std)).sum(-1)
+
+
+# ----------------------------------------------------------------------------- scans (API parity)
+
+def lambda_return(reward, value, pcont, bootstrap, lambda_, axis):
+    """ref :228-253 (axis 0, constant pcont).  reward/value (H,N,1); bootstrap (N,1)."""
+    assert axis == 0
+    disc = float(pcont) if isinstance(pcont, (int, float)) else float(pcont.flatten()[0])
+    v = torch.cat([value, bootstrap[None]], 0)
+    return ops.lambda_return(reward, v, disc, lambda_)
+
+
+def static_scan(fn, inputs, start, reverse=False, unpack=False):
+    """ref :255-300 (generic python scan; the hot loops do not use it)."""
+    last, outs = start, None
+    for i in range(inputs[0].shape[0]):
+        last = fn(last, *[x[i] for x in inputs]) if unpack else fn(last, tuple(x[i] for x in inputs))
+        items = [last] if isinstance(last, dict) else list(last)
+        if outs is None:
+            outs = [{k: [v] for k, v in it.items()} if isinstance(it, dict) else [it] for it in items]
+        else:
+            for o, it in zip(outs, items):
+                if isinstance(it, dict):
+                    for k, v in it.items():
+                        o[k].append(v)
+                else:
+                    o.append(it)
+    return [{k: torch.stack(v, 0) for k, v in o.items()} if isinstance(o, dict) else torch.stack(o, 0) for o in outs]
+
+
+# ----------------------------------------------------------------------------- layers
+
+def get_act(name):
+    if name == 'none':
+        return nn.Identity()
+    if hasattr(nn, name):
+        return getattr(nn, name)()
+    raise NotImplementedError(name)
+
+
+class NormLayer(Module):  # ref :844-859
+    def __init__(self, name, dim=None):
+        super().__init__()
+        if name == 'none':
+            self._layer = None
+        elif name == 'layer':
+            assert dim is not None
+            self._layer = nn.LayerNorm(dim)
+        else:
+            raise NotImplementedError(name)
+
+    def forward(self, features):
+        if self._layer is None:
+            return features
+        return ops.ln_act(features, self._layer.weight, self._layer.bias, self._layer.eps, act=False)
+
+
+class ImgChLayerNorm(nn.Module):  # ref :1031-1040 (parameter holder; applied on NHWC rows)
+    def __init__(self, ch, eps=1e-03):
+        super().__init__()
+        self.norm = torch.nn.LayerNorm(ch, eps=eps)
+
+    def forward(self, x):  # x NCHW, API parity only (hot path works on NHWC)
+        y = ops.ln_act(x.permute(0, 2, 3, 1).contiguous(), self.norm.weight, self.norm.bias, self.norm.eps, act=False)
+        return y.permute(0, 3, 1, 2)
+
+
+def _dense_ln_silu(x, lin, norm, x2=None):
+    """Linear (+ second concatenated input) + LayerNorm + SiLU with the reference's layer objects."""
+    y = ops.linear(x, lin.weight, lin.bias) if x2 is None else ops.linear2(x, x2, lin.weight, lin.bias)
+    if norm._layer is None:
+        return ops_silu(y)
+    return ops.ln_act(y, norm._layer.weight, norm._layer.bias, norm._layer.eps, act=True)
+
+
+def ops_silu(x):
+    raise NotImplementedError('norm: none is not on the GenRL path (conf/defaults/genrl.yaml uses layer)')
+
+
+class GRUCell(Module):  # ref :750-785
+    def __init__(self, inp_size, size, norm=False, act='Tanh', update_bias=-1, device='cuda', **kwargs):
+        super().__init__()
+        assert norm and act == 'Tanh' and update_bias == -1, 'only the GenRL configuration is implemented'
+        self._inp_size, self._size = inp_size, size
+        self._update_bias = update_bias
+        self.device = device
+        self._layer = nn.Linear(inp_size + size, 3 * size, bias=False, **kwargs)
+        self._norm = nn.LayerNorm(3 * size)
+
+    def get_initial_state(self, inputs=None, batch_size=None, dtype=None):
+        return torch.zeros((batch_size), self._size, device=self.device)
+
+    @property
+    def state_size(self):
+        return self._size
+
+    def forward(self, inputs, deter_state):
+        out = ops.gru_step(inputs, deter_state[0], self._layer.weight, self._norm.weight, self._norm.bias)
+        return out, [out]
+
+
+class DistLayer(Module):  # ref :787-841
+    def __init__(self, in_dim, shape, dist='mse', min_std=0.1, max_std=1.0, init_std=0.0, bias=True):
+        super().__init__()
+        self._in_dim = in_dim
+        self._shape = shape if type(shape) in [list, tuple] else [shape]
+        self._dist, self._min_std, self._init_std, self._max_std = dist, min_std, init_std, max_std
+        self._out = nn.Linear(in_dim, int(np.prod(shape)), bias=bias)
+        if dist == 'normal':
+            self._std = nn.Linear(in_dim, int(np.prod(shape)))
+        elif dist not in ('twohot', 'mse', 'onehot'):
+            raise NotImplementedError(dist)
+
+    def raw(self, inputs):
+        out = ops.linear(inputs, self._out.weight, self._out.bias)
+        if self._dist == 'normal':
+            std = ops.linear(inputs, self._std.weight, self._std.bias)
+            return torch.cat([out, std], -1)
+        return out
+
+    def forward(self, inputs):
+        raw = self.raw(inputs)
+        if self._dist == 'normal':
+            return NormalDist(raw, self._min_std, self._max_std)
+        if self._dist == 'twohot':
+            return TwoHotDist(raw)
+        if self._dist == 'mse':
+            return MSEDist(raw.reshape(list(inputs.shape[:-1]) + list(self._shape)))
+        if self._dist == 'onehot':
+            return OneHotDist(raw)
+        raise NotImplementedError(self._dist)
+
+
+class MLP(Module):  # ref :718-747
+    def __init__(self, in_shape, shape, layers, units, act='SiLU', norm='none', **out):
+        super().__init__()
+        assert act == 'SiLU'
+        self._in_shape = in_shape
+        if out['dist'] == 'twohot':
+            shape = 255
+        self._shape = (shape,) if isinstance(shape, int) else shape
+        self._layers, self._units, self._norm = layers, units, norm
+        last_units = in_shape
+        for index in range(self._layers):
+            self.add_module(f'dense{index}', nn.Linear(last_units, units, bias=norm != 'none'))
+            self.add_module(f'norm{index}', NormLayer(norm, units))
+            last_units = units
+        self._out = DistLayer(units, shape, **out)
+
+    def trunk(self, features, features2=None):
+        """features2: optional second input concatenated after `features` (feat = [stoch, deter])
+        consumed without materialising the concatenation."""
+        x = features.reshape([-1, features.shape[-1]])
+        x2 = features2.reshape([-1, features2.shape[-1]]) if features2 is not None else None
+        for index in range(self._layers):
+            x = _dense_ln_silu(x, getattr(self, f'dense{index}'), getattr(self, f'norm{index}'), x2)
+            x2 = None
+        return x.reshape(list(features.shape[:-1]) + [x.shape[-1]])
+
+    def forward(self, features, features2=None):
+        return self._out(self.trunk(features, features2))
+
+
+# ----------------------------------------------------------------------------- encoder / decoder
+
+def _conv_sizes(size, kernels, transposed=False):
+    out = []
+    for k in kernels:
+        size = 2 * (size - 1) + k if transposed else (size - k) // 2 + 1
+        out.append(size)
+    return out
+
+
+class Encoder(Module):  # ref :558-628
+    def __init__(self, shapes, cnn_keys=r'.*', mlp_keys=r'.*', act='SiLU', norm='none',
+                 cnn_depth=48, cnn_kernels=(4, 4, 4, 4), mlp_layers=[400, 400, 400, 400], symlog_inputs=False):
+        super().__init__()
+        self.shapes = shapes
+        self.cnn_keys = [k for k, v in shapes.items() if re.match(cnn_keys, k) and len(v) == 3]
+        self.mlp_keys = [k for k, v in shapes.items() if re.match(mlp_keys, k) and len(v) == 1]
+        assert act == 'SiLU' and norm == 'layer', 'GenRL path: SiLU + layer norm'
+        assert len(self.mlp_keys) == 0, 'proprio MLP inputs are not on the GenRL pixel path'
+        self._cnn_depth, self._cnn_kernels = cnn_depth, cnn_kernels
+        layers = []
+        for i, kernel in enumerate(self._cnn_kernels):
+            prev_depth = 3 if i == 0 else 2 ** (i - 1) * self._cnn_depth
+            depth = 2 ** i * self._cnn_depth
+            layers += [nn.Conv2d(prev_depth, depth, kernel, stride=2), ImgChLayerNorm(depth), get_act(act)]
+        self._conv_model = nn.Sequential(*layers)
+
+    def forward(self, data):
+        key = self.cnn_keys[0]
+        x = data[key]
+        shape = self.shapes[key]
+        batch_dims = x.shape[:-len(shape)]
+        x = x.reshape((-1,) + tuple(x.shape)[len(batch_dims):])
+        out = self._cnn(x)
+        return out.reshape(tuple(batch_dims) + tuple(out.shape[1:]))
+
+    def _cnn(self, x):
+        """x: uint8 NCHW frames (x/255-0.5 fused into the first layer's patch gather) or float NCHW."""
+        if x.dtype != torch.uint8:
+            x = x.permute(0, 2, 3, 1).contiguous()
+        for i in range(len(self._cnn_kernels)):
+            conv, ln = self._conv_model[3 * i], self._conv_model[3 * i + 1]
+            x = ops.conv2d_s2(x, conv.weight, conv.bias)
+            x = ops.ln_act(x, ln.norm.weight, ln.norm.bias, ln.norm.eps, act=True)
+        n, h, w, c = x.shape
+        return ops.transpose_last2(x.reshape(n, h * w, c)).reshape(n, c * h * w)    # NCHW flatten, ref :621
+
+
+class Decoder(Module):  # ref :631-715
+    def __init__(self, shapes, cnn_keys=r'.*', mlp_keys=r'.*', act='SiLU', norm='none',
+                 cnn_depth=48, cnn_kernels=(4, 4, 4, 4), mlp_layers=[400, 400, 400, 400], embed_dim=1024,
+                 mlp_dist='mse', image_dist='mse'):
+        super().__init__()
+        self._embed_dim, self._shapes = embed_dim, shapes
+        self.cnn_keys = [k for k, v in shapes.items() if re.match(cnn_keys, k) and len(v) == 3]
+        self.mlp_keys = [k for k, v in shapes.items() if re.match(mlp_keys, k) and len(v) == 1]
+        assert act == 'SiLU' and norm == 'layer' and image_dist == 'mse'
+        assert len(self.mlp_keys) == 0 and len(self.cnn_keys) == 1
+        self._cnn_depth, self._cnn_kernels = cnn_depth, cnn_kernels
+        self.channels = {k: self._shapes[k][0] for k in self.cnn_keys}
+        self._conv_in = nn.Sequential(nn.Linear(embed_dim, 32 * self._cnn_depth))
+        layers, n = [], len(self._cnn_kernels)
+        for i, kernel in enumerate(self._cnn_kernels):
+            prev_depth = 32 * self._cnn_depth if i == 0 else 2 ** (n - (i - 1) - 2) * self._cnn_depth
+            depth = 2 ** (n - i - 2) * self._cnn_depth
+            last = i == n - 1
+            if last:
+                depth = sum(self.channels.values())
+            layers += [nn.ConvTranspose2d(prev_depth, depth, kernel, stride=2),
+                       NormLayer('none', depth) if last else ImgChLayerNorm(depth),
+                       nn.Identity() if last else get_act(act)]
+        self._conv_model = nn.Sequential(*layers)
+
+    def forward(self, features):
+        return self._cnn(features)
+
+    def _cnn(self, features):
+        lead = features.shape[:-1]
+        x = ops.linear(features.reshape(-1, features.shape[-1]), self._conv_in[0].weight, self._conv_in[0].bias)
+        x = x.reshape(-1, 1, 1, 32 * self._cnn_depth)             # NHWC with 1x1 pixels
+        n = len(self._cnn_kernels)
+        for i in range(n):
+            conv = self._conv_model[3 * i]
+            x = ops.convT2d_s2(x, conv.weight, conv.bias)
+            if i != n - 1:
+                ln = self._conv_model[3 * i + 1]
+                x = ops.ln_act(x, ln.norm.weight, ln.norm.bias, ln.norm.eps, act=True)
+        N, H, W, C = x.shape
+        x = ops.transpose_last2(x.reshape(N, H * W, C)).reshape(tuple(lead) + (C, H, W))   # -> NCHW
+        return {key: MSEDist(x) for key in self.channels}
+
+
+# ----------------------------------------------------------------------------- RSSM
+
+class EnsembleRSSM(Module):  # ref :302-555
+    def __init__(self, ensemble=5, stoch=30, deter=200, hidden=200, discrete=False, act='SiLU', norm='none',
+                 std_act='softplus', min_std=0.1, action_dim=None, embed_dim=1536, device='cuda',
+                 single_obs_posterior=False, cell_input='stoch', cell_type='gru'):
+        super().__init__()
+        assert action_dim is not None
+        assert discrete and ensemble == 1 and cell_type == 'gru' and cell_input == 'stoch' and norm == 'layer', \
+            'GenRL path: discrete latents, ensemble 1, GRU, layer norm'
+        self.device = device
+        self._embed_dim, self._action_dim, self._ensemble = embed_dim, action_dim, ensemble
+        self._stoch, self._deter, self._hidden, self._discrete = stoch, deter, hidden, discrete
+        self._norm, self._cell_type, self.cell_input = norm, cell_type, cell_input
+        self.single_obs_posterior = single_obs_posterior
+        self._cell = GRUCell(self._hidden, self._deter, norm=True, device=self.device)
+        self._ensemble_img_dist = nn.ModuleList([nn.Linear(hidden, stoch * discrete) for _ in range(ensemble)])
+        self._obs_dist = nn.Linear(hidden, stoch * discrete)
+        self._img_in = nn.Sequential(nn.Linear(stoch * discrete + action_dim, hidden), NormLayer(norm, hidden))
+        self._ensemble_img_out = nn.ModuleList(
+            [nn.Sequential(nn.Linear(deter, hidden), NormLayer(norm, hidden)) for _ in range(ensemble)])
+        in_obs = embed_dim if single_obs_posterior else deter + embed_dim
+        self._obs_out = nn.Sequential(nn.Linear(in_obs, hidden), NormLayer(norm, hidden))
+
+    # ---- shapes / helpers
+    def initial(self, batch_size):
+        z = lambda *s: torch.zeros(list(s), device=self.device)
+        return dict(logit=z(batch_size, self._stoch, self._discrete), stoch=z(batch_size, self._stoch, self._discrete),
+                    deter=self._cell.get_initial_state(None, batch_size))
+
+    def get_stoch_size(self):
+        return self._stoch * self._discrete
+
+    def get_deter_size(self):
+        return self._cell.state_size
+
+    def get_feat_size(self):
+        return self.get_deter_size() + self.get_stoch_size()
+
+    def get_stoch(self, state):
+        s = state['stoch']
+        return s.reshape(list(s.shape[:-2]) + [self._stoch * self._discrete])
+
+    def get_deter(self, state):
+        return state['deter']
+
+    def get_feat(self, state):
+        return torch.cat([self.get_stoch(state), self.get_deter(state)], -1)
+
+    def get_dist(self, state, ensemble=False):
+        assert not ensemble
+        return OneHotDist(state['logit'].float())
+
+    def get_unif_dist(self, state):
+        return OneHotDist(torch.ones_like(state['logit']), site='rssm.unif')
+
+    # ---- single steps (API parity; acting / data-free paths)
+    def _prior_logits(self, deter):
+        x = _dense_ln_silu(deter, self._ensemble_img_out[0][0], self._ensemble_img_out[0][1])
+        lg = ops.linear(x, self._ensemble_img_dist[0].weight, self._ensemble_img_dist[0].bias)
+        return lg.reshape(list(lg.shape[:-1]) + [self._stoch, self._discrete])
+
+    def _post_logits(self, embed, deter=None):
+        if self.single_obs_posterior:
+            x = _dense_ln_silu(embed, self._obs_out[0], self._obs_out[1])
+        else:
+            x = _dense_ln_silu(deter, self._obs_out[0], self._obs_out[1], embed)
+        lg = ops.linear(x, self._obs_dist.weight, self._obs_dist.bias)
+        return lg.reshape(list(lg.shape[:-1]) + [self._stoch, self._discrete])
+
+    def get_stoch_stats_from_deter_state(self, temp_state, sample=True, site='rssm.prior'):
+        logit = self._prior_logits(temp_state['deter'])
+        d = OneHotDist(logit, site=site)
+        return (d.sample() if sample else d.mode()), {'logit': logit}
+
+    def img_step(self, prev_state, prev_action, sample=True, site='rssm.prior'):
+        x = _dense_ln_silu(self.get_stoch(prev_state), self._img_in[0], self._img_in[1], prev_action)
+        deter = ops.gru_step(x, prev_state['deter'], self._cell._layer.weight, self._cell._norm.weight,
+                             self._cell._norm.bias)
+        stoch, stats = self.get_stoch_stats_from_deter_state({'deter': deter}, bool(sample), site)
+        return {'stoch': stoch, 'deter': deter, **stats}
+
+    def get_post_stoch(self, embed, prior, should_sample=True):
+        logit = self._post_logits(embed, prior['deter'])
+        d = OneHotDist(logit, site='rssm.post')
+        return (d.sample() if should_sample else d.mode()), {'logit': logit}
+
+    def obs_step(self, prev_state, prev_action, embed, is_first, should_sample=True):
+        m = 1.0 - is_first.float()
+        prev_state = {k: torch.einsum('b,b...->b...', m, v) for k, v in prev_state.items()}
+        prev_action = torch.einsum('b,b...->b...', m, prev_action)
+        prior = self.img_step(prev_state, prev_action, should_sample)
+        stoch, stats = self.get_post_stoch(embed, prior, should_sample)
+        return {'stoch': stoch, 'deter': prior['deter'], **stats}, prior
+
+    # ---- sequences
+    def observe(self, embed, action, is_first, state=None):
+        """ref :362-371.  With single_obs_posterior the posterior, `_img_in`, the x-half of the GRU
+        projection and the prior head are batched over all T steps; only h_{t-1} W_h + LN + gates is
+        sequential (ops.gru_seq).  Without it, falls back to the step-by-step form."""
+        B, T = action.shape[:2]
+        if not self.single_obs_posterior:
+            return self._observe_stepwise(embed, action, is_first, state)
+        S, K = self._stoch, self._discrete
+        dev = embed.device
+        tm = lambda x: x.transpose(0, 1).contiguous()                          # (B,T,..) -> (T,B,..)
+        emb, act, first = tm(embed), tm(action), tm(is_first)
+        mask = (1.0 - first.float()).contiguous()                              # (T,B)
+        plog = self._post_logits(emb.reshape(T * B, -1)).reshape(T, B, S, K)
+        pst = ops.onehot_sample(plog, noise.draw('exp', 'wm.post_q', (T, B * S, K), dev))
+        st0 = state if state is not None else self.initial(B)
+        prev = torch.cat([st0['stoch'].reshape(1, B, S * K), pst.reshape(T, B, S * K)[:-1]], 0)
+        mrow = mask.reshape(T * B, 1)
+        x = _dense_ln_silu((prev.reshape(T * B, S * K) * mrow), self._img_in[0], self._img_in[1],
+                           act.reshape(T * B, -1) * mrow)
+        deter = ops.gru_seq(x.reshape(T, B, -1), mask, st0['deter'], self._cell._layer.weight,
+                            self._cell._norm.weight, self._cell._norm.bias)
+        qlog = self._prior_logits(deter.reshape(T * B, -1)).reshape(T, B, S, K)
+        qst = ops.onehot_sample(qlog, noise.draw('exp', 'wm.prior_q', (T, B * S, K), dev))
+        bm = lambda x: x.transpose(0, 1)
+        post = {'stoch': bm(pst), 'deter': bm(deter), 'logit': bm(plog)}
+        prior = {'stoch': bm(qst), 'deter': bm(deter), 'logit': bm(qlog)}
+        return post, prior
+
+    def _observe_stepwise(self, embed, action, is_first, state=None):
+        B, T = action.shape[:2]
+        state = state if state is not None else self.initial(B)
+        posts, priors = [], []
+        for t in range(T):
+            post, prior = self.obs_step(state, action[:, t], embed[:, t], is_first[:, t])
+            posts.append(post); priors.append(prior); state = post
+        st = lambda L: {k: torch.stack([d[k] for d in L], 1) for k in L[0]}
+        return st(posts), st(priors)
+
+    def imagine(self, action, state=None, sample=True):
+        """ref :373-381: prior rollout for given actions (B,T,A)."""
+        B, T = action.shape[:2]
+        state = state if state is not None else self.initial(B)
+        outs = []
+        for t in range(T):
+            state = self.img_step(state, action[:, t], sample)
+            outs.append(state)
+        return {k: torch.stack([d[k] for d in outs], 1) for k in outs[0]}
+
+    # ---- losses
+    def kl_loss(self, post, prior, forward, balance, free, free_avg):
+        """ref :534-555 (balance != 0.5, free_avg False)."""
+        assert balance != 0.5 and not free_avg
+        lhs, rhs = (prior, post) if forward else (post, prior)
+        mix = balance if forward else (1 - balance)
+        l, r = lhs['logit'], rhs['logit']
+        value = value_lhs = ops.cat_kl(l, r.detach())
+        value_rhs = ops.cat_kl(l.detach(), r)
+        # max(value, free) without materialising a device scalar (no H2D copy on the hot path)
+        loss = mix * torch.clamp_min(value_lhs, free).mean() + (1 - mix) * torch.clamp_min(value_rhs, free).mean()
+        return loss, value
+
+
+# ----------------------------------------------------------------------------- optimiser
+
+class FlatGroup:
+    """Parameters of one optimiser group re-homed into one flat fp32 buffer (params and grads are
+    views), so clip-norm + decay + Adam is one pass and DP needs one all-reduce per group."""
+    def __init__(self, params):
+        self.params = [p for p in params]
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.n = n
+        self.flat = torch.empty(n, device=dev)
+        self.grad = torch.zeros(n, device=dev)
+        self.m = torch.zeros(n, device=dev)
+        self.v = torch.zeros(n, device=dev)
+        self.step = 0
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view(p.shape)
+            p.grad = self.grad[off:off + k].view(p.shape)
+            off += k
+        self.norm = torch.zeros(1, device=dev)
+
+    def owns(self, params):
+        return len(params) == len(self.params) and all(a is b for a, b in zip(params, self.params))
+
+    def rebind(self):
+        """re-attach .grad views (zero_grad(set_to_none) or external code may have dropped them)"""
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            g = self.grad[off:off + k].view(p.shape)
+            if p.grad is None:
+                p.grad = g
+            elif p.grad.data_ptr() != g.data_ptr():
+                g.copy_(p.grad); p.grad = g
+            off += k
+
+
+class Optimizer:
+    """ref :871-932: backward -> clip by global norm -> p *= (1-wd) for *every* handed parameter
+    -> Adam -> zero_grad, as HIP kernels over flat buffers and without host syncs (metrics are
+    0-d device tensors).  `grad_reduce` is the DP hook (one all-reduce per group)."""
+    grad_reduce = None      # set by genrl_amd.dp: callable(flat_grad) -> divisor
+    grad_hook = None        # test hook: callable(opt_name, params) after backward, before the step
+
+    def __init__(self, name, parameters, lr, eps=1e-4, clip=None, wd=None, opt='adam', wd_pattern=r'.*', use_amp=False):
+        assert 0 <= wd < 1
+        assert not clip or 1 <= clip
+        assert opt == 'adam' and wd_pattern == r'.*'
+        assert not use_amp, 'precision 16 (autocast) is a "next" row (SURVEY §8f.4); run with precision: 32'
+        self._name, self._clip, self._wd, self._lr, self._eps = name, clip, wd, lr, eps
+        self._params = list(parameters)
+        self._groups = []
+        self._live_cache = {}
+        self._once = True
+
+    def _group_for(self, params):
+        for g in self._groups:
+            if g.owns(params):
+                return g
+        # a parameter can only live in one flat buffer: groups must be disjoint
+        ids = {id(p) for p in params}
+        for g in self._groups:
+            assert not ids & {id(p) for p in g.params}, 'overlapping optimiser groups'
+        g = FlatGroup(params)
+        self._groups.append(g)
+        return g
+
+    def __call__(self, loss, params, decay_only=()):
+        params = [p for p in params]
+        assert len(loss.shape) == 0 or (len(loss.shape) == 1 and loss.shape[0] == 1), (self._name, loss.shape)
+        metrics = {}
+        if self._once:
+            count = sum(p.numel() for p in params if p.requires_grad)
+            print(f'Found {count} {self._name} parameters.')
+            self._once = False
+        metrics[f'{self._name}_loss'] = loss.detach()
+        # parameters that get a gradient from this loss form the Adam group; the others handed in
+        # only receive weight decay (connector weights during the world-model step).
+        key = tuple(id(p) for p in params)
+        if key not in self._live_cache:                 # graph topology is static across iterations
+            self._live_cache[key] = [p for p in params if p.requires_grad and _in_graph(loss, p)]
+        live = self._live_cache[key]
+        group = self._group_for(live)
+        group.rebind()
+        loss.backward()
+        if Optimizer.grad_hook is not None:
+            Optimizer.grad_hook(self._name, live)
+        gscale = 1.0
+        if Optimizer.grad_reduce is not None:
+            gscale = 1.0 / Optimizer.grad_reduce(group.grad)
+        ops.grad_norm(group.grad, group.norm, gscale)
+        metrics[f'{self._name}_grad_norm'] = group.norm[0].clone()
+        group.step += 1
+        ops.adam_step(group.flat, group.grad, group.m, group.v, group.norm, gscale, float(self._clip or 0.0),
+                      self._lr, self._eps, float(self._wd or 0.0), group.step)
+        if self._wd:
+            live_ids = {id(p) for p in live}
+            for p in params:
+                if id(p) not in live_ids:
+                    other = self._flat_owner(p)
+                    if other is None:
+                        ops.scale_(p.data, 1.0 - self._wd) if p.data.is_contiguous() else p.data.mul_(1.0 - self._wd)
+            for g in self._decay_groups(params, live_ids):
+                ops.scale_(g.flat, 1.0 - self._wd)
+        group.grad.zero_()
+        return metrics
+
+    def _flat_owner(self, p):
+        for g in self._groups:
+            for q in g.params:
+                if q is p:
+                    return g
+        return None
+
+    def _decay_groups(self, params, live_ids):
+        """flat groups all of whose parameters were handed in without being live"""
+        ids = {id(p) for p in params} - live_ids
+        return [g for g in self._groups if g.params and all(id(q) in ids for q in g.params)]
+
+
+def _in_graph(loss, p):
+    """True if parameter p is reachable from loss in the autograd graph."""
+    cache = getattr(loss, '_genrl_leafs', None)
+    if cache is None:
+        cache, seen, stack = set(), set(), [loss.grad_fn]
+        while stack:
+            fn = stack.pop()
+            if fn is None or fn in seen:
+                continue
+            seen.add(fn)
+            if hasattr(fn, 'variable'):
+                cache.add(id(fn.variable))
+            stack.extend(f for f, _ in fn.next_functions)
+        try:
+            loss._genrl_leafs = cache
+        except Exception:
+            pass
+    return id(p) in cache
+
+
+# ----------------------------------------------------------------------------- misc (ref :934-1029)
+
+class StreamNorm:
+    def __init__(self, shape=(), momentum=0.99, scale=1.0, eps=1e-8, device='cuda'):
+        self.device, self._shape, self._momentum, self._scale, self._eps = device, tuple(shape), momentum, scale, eps
+        self.mag = self.mean = self.square_mean = None
+        self.step = 0
+
+    def reset(self):
+        self.step, self.mag, self.mean, self.square_mean = 0, None, None, None
+
+    def __call__(self, inputs):
+        metrics = {}
+        self.update(inputs)
+        metrics['mean'] = inputs.mean()
+        metrics['std'] = inputs.std()
+        outputs = self.transform(inputs)
+        metrics['normed_mean'] = outputs.mean()
+        metrics['normed_std'] = outputs.std()
+        return outputs, metrics
+
+    def update(self, inputs):
+        self.step += 1
+        batch = inputs.detach().reshape((-1,) + self._shape)
+        ema = lambda old, new: new.clone() if old is None else self._momentum * old + (1 - self._momentum) * new
+        self.mag = ema(self.mag, torch.abs(batch).mean(0))
+        self.mean = ema(self.mean, torch.mean(batch))
+        self.square_mean = ema(self.square_mean, torch.mean(batch * batch))
+
+    def transform(self, inputs):
+        if self._momentum == 1:
+            return inputs
+        values = inputs.reshape((-1,) + self._shape) / (self.mag[None] + self._eps) * self._scale
+        return values.reshape(inputs.shape)
+
+
+class RequiresGrad:
+    def __init__(self, model):
+        self._model = model
+
+    def __enter__(self):
+        self._model.requires_grad_(requires_grad=True)
+
+    def __exit__(self, *args):
+        self._model.requires_grad_(requires_grad=False)
+
+
+class RewardEMA:
+    """ref :1014-1029.  `all_gather` is the DP hook so the quantiles see the global batch."""
+    all_gather = None
+
+    def __init__(self, device, alpha=1e-2):
+        self.device, self.alpha = device, alpha
+        self.range = torch.tensor([0.05, 0.95]).to(device)
+
+    def __call__(self, x, ema_vals):
+        flat_x = torch.flatten(x.detach())
+        if RewardEMA.all_gather is not None:
+            flat_x = RewardEMA.all_gather(flat_x)
+        x_quantile = torch.quantile(input=flat_x, q=self.range)
+        ema_vals[:] = self.alpha * x_quantile + (1 - self.alpha) * ema_vals
+        scale = torch.clip(ema_vals[1] - ema_vals[0], min=1.0)
+        return ema_vals[0].detach(), scale.detach()

@@ -1,0 +1,34 @@
+"""Random-number sites of the hot path.  The reference draws noise implicitly
+(torch.multinomial in OneHotDist.sample, Normal.rsample, randn_like); here every
+site asks this module for an explicit noise tensor which the HIP kernels consume
+(exponential-race argmax for categoricals, eps for Gaussians).  By default noise comes from the
+device's torch generator; `inject()` replays given tensors per site so that runs are comparable
+across devices bit-for-bit in their noise ("identical replay batches and seeds")."""
+import contextlib
+import torch
+
+_injected = None
+
+
+def draw(kind, site, shape, device):
+    """kind: 'exp' (Exp(1)) or 'normal' (N(0,1)); site: string naming the RNG call site."""
+    if _injected is not None and site in _injected:
+        q = _injected[site]
+        t = q.pop(0) if isinstance(q, list) else q
+        assert tuple(t.shape) == tuple(shape), (site, tuple(t.shape), tuple(shape))
+        return t.to(device=device, dtype=torch.float32).contiguous()
+    if kind == 'exp':
+        return torch.empty(shape, device=device, dtype=torch.float32).exponential_(1.0)
+    return torch.randn(shape, device=device, dtype=torch.float32)
+
+
+@contextlib.contextmanager
+def inject(sites):
+    """sites: dict site -> tensor, or -> list of tensors consumed first-in-first-out."""
+    global _injected
+    prev = _injected
+    _injected = {k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in sites.items()}
+    try:
+        yield
+    finally:
+        _injected = prev

@@ -10,6 +10,8 @@ UNIMIX = 0.99
 
 
 def _stream():
+    if not torch.cuda.is_available():
+        raise GenrlHipError('genrl_amd ops need an MI355X (torch.cuda unavailable); there is no CPU fallback')
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -576,3 +578,181 @@ def adam_step(p, g, m, v, norm, gscale, clip, lr, eps, wd, step, b1=0.9, b2=0.99
 
 def scale_(p, s):
     check(lib().genrl_scale(_p(p), p.numel(), s, _stream()), 'scale')
+
+
+# ------------------------------------------------------------------ fused multi-input layers
+
+class _Linear2(Function):
+    """y = [x1, x2] W^T + b without materialising the concatenation: W = [W1 | W2] column blocks
+    (torch.cat([stoch, action]) -> _img_in, agent/dreamer_utils.py:461-462; feat -> MLP dense0)."""
+    @staticmethod
+    def forward(ctx, x1, x2, W, b):
+        a = _f32(x1).reshape(-1, x1.shape[-1]).contiguous()
+        c = _f32(x2).reshape(-1, x2.shape[-1]).contiguous()
+        M, K1 = a.shape
+        K2 = c.shape[1]
+        N, K = W.shape
+        assert K == K1 + K2 and c.shape[0] == M
+        y = torch.empty(M, N, device=a.device)
+        sgemm(a, K1, 1, W, K, 1, y, N, b, M, N, K1)
+        sgemm(c, K2, 1, W, K, 1, y, N, None, M, N, K2, accumulate=True, b_off=K1)
+        ctx.save_for_backward(a, c, W)
+        ctx.has_bias = b is not None
+        ctx.shapes = (x1.shape, x2.shape)
+        return y.reshape(*x1.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, c, W = ctx.saved_tensors
+        M, K1 = a.shape
+        K2 = c.shape[1]
+        N, K = W.shape
+        dy2 = dy.reshape(M, N).contiguous()
+        d1 = d2 = dW = db = None
+        if ctx.needs_input_grad[0]:
+            d1 = torch.empty(M, K1, device=dy.device)
+            sgemm(dy2, N, 1, W, 1, K, d1, K1, None, M, K1, N)
+            d1 = d1.reshape(ctx.shapes[0])
+        if ctx.needs_input_grad[1]:
+            d2 = torch.empty(M, K2, device=dy.device)
+            sgemm(dy2, N, 1, W, 1, K, d2, K2, None, M, K2, N, b_off=K1)
+            d2 = d2.reshape(ctx.shapes[1])
+        if ctx.needs_input_grad[2]:
+            dW = torch.empty(N, K, device=dy.device)
+            sgemm(dy2, 1, N, a, 1, K1, dW, K, None, N, K1, M)
+            sgemm(dy2, 1, N, c, 1, K2, dW, K, None, N, K2, M, c_off=K1)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = colsum(dy2)
+        return d1, d2, dW, db
+
+
+def linear2(x1, x2, W, b=None):
+    return _Linear2.apply(x1, x2, W, b)
+
+
+class _GRUStep(Function):
+    """One GRUCell step h' = GRU(x, h) (agent/dreamer_utils.py:771-785): W = [Wx | Wh] (3D, I+D),
+    no bias, LayerNorm over 3D, gates fused.  Rows = imagination rows."""
+    @staticmethod
+    def forward(ctx, x, h, W, gamma, beta):
+        x = _f32(x).contiguous(); h = _f32(h).contiguous()
+        R, I = x.shape
+        D = h.shape[1]
+        K = I + D
+        pre = torch.empty(R, 3 * D, device=x.device)
+        sgemm(x, I, 1, W, K, 1, pre, 3 * D, None, R, 3 * D, I)
+        sgemm(h, D, 1, W, K, 1, pre, 3 * D, None, R, 3 * D, D, accumulate=True, b_off=I)
+        out = torch.empty_like(h)
+        mean = torch.empty(R, device=x.device); rstd = torch.empty(R, device=x.device)
+        check(lib().genrl_gru_gates_fwd(_p(pre), _p(h), D, _p(gamma), _p(beta), _p(out), D, _p(mean), _p(rstd), R, D,
+                                        1e-5, _stream()), 'gru_gates_fwd')
+        ctx.save_for_backward(x, h, W, gamma, beta, pre, mean, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, h, W, gamma, beta, pre, mean, rstd = ctx.saved_tensors
+        R, I = x.shape
+        D = h.shape[1]
+        K = I + D
+        dout = dout.contiguous()
+        dpre = torch.empty_like(pre); dh = torch.empty_like(h)
+        need_p = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        dg = torch.empty(3 * D, device=h.device) if need_p else None
+        db = torch.empty(3 * D, device=h.device) if need_p else None
+        ws = _ws(lib().genrl_ln_ws_floats(R, 3 * D), h.device) if need_p else None
+        check(lib().genrl_gru_gates_bwd(_p(dout), D, _p(pre), _p(h), D, _p(gamma), _p(beta), _p(mean), _p(rstd),
+                                        _p(dpre), _p(dh), D, _p(dg), _p(db), _p(ws), R, D, 0, 0, _stream()),
+              'gru_gates_bwd')
+        dx = dW = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            sgemm(dpre, 3 * D, 1, W, 1, K, dx, I, None, R, I, 3 * D)
+        if ctx.needs_input_grad[1]:
+            sgemm(dpre, 3 * D, 1, W, 1, K, dh, D, None, R, D, 3 * D, accumulate=True, b_off=I)
+        else:
+            dh = None
+        if ctx.needs_input_grad[2]:
+            dW = torch.empty(3 * D, K, device=h.device)
+            sgemm(dpre, 1, 3 * D, x, 1, I, dW, K, None, 3 * D, I, R)
+            sgemm(dpre, 1, 3 * D, h, 1, D, dW, K, None, 3 * D, D, R, c_off=I)
+        return dx, dh, dW, dg, db
+
+
+def gru_step(x, h, W, gamma, beta):
+    return _GRUStep.apply(x, h, W, gamma, beta)
+
+
+class _GRUSeq(Function):
+    """The whole GRU recurrence of EnsembleRSSM.observe / VideoSSM.update over T steps with the
+    non-recurrent half hoisted: pre_x = x W_x^T for all T at once; per step only
+    h_{t-1} W_h^T (+ LayerNorm + gates) is sequential.  x (T,B,I); mask (T,B) multiplies h_{t-1}
+    (is_first reset, agent/dreamer_utils.py:433-434) or None; h0 (B,D).  Returns deter (T,B,D)."""
+    @staticmethod
+    def forward(ctx, x, mask, h0, W, gamma, beta):
+        x = _f32(x).contiguous()
+        T, B, I = x.shape
+        D = h0.shape[1]
+        K = I + D
+        dev = x.device
+        pre = torch.empty(T, B, 3 * D, device=dev)
+        sgemm(x, I, 1, W, K, 1, pre, 3 * D, None, T * B, 3 * D, I)
+        hm = torch.empty(T, B, D, device=dev)           # masked previous state per step
+        out = torch.empty(T, B, D, device=dev)
+        mean = torch.empty(T, B, device=dev); rstd = torch.empty(T, B, device=dev)
+        L = lib(); s = _stream()
+        h0 = _f32(h0).contiguous()
+        for t in range(T):
+            src, soff = (h0, 0) if t == 0 else (out, (t - 1) * B * D)
+            check(L.genrl_copy2d(src.data_ptr() + 4 * soff, D, hm.data_ptr() + 4 * t * B * D, D, B, D,
+                                 (mask.data_ptr() + 4 * t * B) if mask is not None else None, 0, s), 'copy2d')
+            sgemm(hm, D, 1, W, K, 1, pre, 3 * D, None, B, 3 * D, D, accumulate=True, a_off=t * B * D, b_off=I,
+                  c_off=t * B * 3 * D)
+            check(L.genrl_gru_gates_fwd(pre.data_ptr() + 4 * t * B * 3 * D, hm.data_ptr() + 4 * t * B * D, D, _p(gamma),
+                                        _p(beta), out.data_ptr() + 4 * t * B * D, D, mean.data_ptr() + 4 * t * B,
+                                        rstd.data_ptr() + 4 * t * B, B, D, 1e-5, s), 'gru_gates_fwd')
+        ctx.save_for_backward(x, mask if mask is not None else x.new_empty(0), W, gamma, beta, pre, hm, mean, rstd)
+        ctx.has_mask = mask is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, mask, W, gamma, beta, pre, hm, mean, rstd = ctx.saved_tensors
+        T, B, I = x.shape
+        D = hm.shape[2]
+        K = I + D
+        dev = x.device
+        dout = dout.contiguous()
+        dpre = torch.empty_like(pre)
+        dh = torch.zeros(B, D, device=dev)               # gradient flowing into h_{t} from step t+1
+        dhm = torch.empty(B, D, device=dev)
+        gsum = torch.empty(B, D, device=dev)
+        dg = torch.zeros(3 * D, device=dev); db = torch.zeros(3 * D, device=dev)
+        ws = _ws(lib().genrl_ln_ws_floats(B, 3 * D), dev)
+        L = lib(); s = _stream()
+        for t in range(T - 1, -1, -1):
+            # total gradient on h_t = external + recurrent
+            check(L.genrl_copy2d(dout.data_ptr() + 4 * t * B * D, D, gsum.data_ptr(), D, B, D, None, 0, s), 'copy2d')
+            check(L.genrl_copy2d(dh.data_ptr(), D, gsum.data_ptr(), D, B, D, None, 1, s), 'copy2d')
+            check(L.genrl_gru_gates_bwd(gsum.data_ptr(), D, pre.data_ptr() + 4 * t * B * 3 * D,
+                                        hm.data_ptr() + 4 * t * B * D, D, _p(gamma), _p(beta),
+                                        mean.data_ptr() + 4 * t * B, rstd.data_ptr() + 4 * t * B,
+                                        dpre.data_ptr() + 4 * t * B * 3 * D, dhm.data_ptr(), D, _p(dg), _p(db), _p(ws),
+                                        B, D, 0, 1, s), 'gru_gates_bwd')
+            sgemm(dpre, 3 * D, 1, W, 1, K, dhm, D, None, B, D, 3 * D, accumulate=True, a_off=t * B * 3 * D, b_off=I)
+            check(L.genrl_copy2d(dhm.data_ptr(), D, dh.data_ptr(), D, B, D,
+                                 (mask.data_ptr() + 4 * t * B) if ctx.has_mask else None, 0, s), 'copy2d')
+        dx = dW = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            sgemm(dpre, 3 * D, 1, W, 1, K, dx, I, None, T * B, I, 3 * D)
+        if ctx.needs_input_grad[3]:
+            dW = torch.empty(3 * D, K, device=dev)
+            sgemm(dpre, 1, 3 * D, x, 1, I, dW, K, None, 3 * D, I, T * B)
+            sgemm(dpre, 1, 3 * D, hm, 1, D, dW, K, None, 3 * D, D, T * B, c_off=I)
+        dh0 = dh if ctx.needs_input_grad[2] else None
+        return dx, None, dh0, dW, dg, db
+
+
+def gru_seq(x, mask, h0, W, gamma, beta):
+    return _GRUSeq.apply(x, mask, h0, W, gamma, beta)

@@ -1,0 +1,89 @@
+"""MI355X-native reward functions behind `tools/genrl_utils.py:240-409` (compute_reward,
+video_text_reward, max_cosine_similarity).  The prompt tables, cv2 video helpers and the
+InternVideo2 loader of the reference's file (lines 1-238) are host-side lookup code outside the
+hot path: the text/video embedder is supplied by the caller as
+`agent.wm.viclip_model` (the attribute the reference itself prefers, tools/genrl_utils.py:290-291).
+"""
+import torch
+
+from .. import ops
+
+# task -> prompt; populated by the integrator. Fallback: the task name in words.
+TASK2PROMPT = {}
+
+
+def max_cosine_similarity(u, v, dim=-1):  # ref :240-242
+    assert dim == -1
+    return ops.maxcos(u, v)
+
+
+def _conv_in(agent, stoch):
+    """decoder._conv_in[0] on flattened stoch (ref :253-256)."""
+    lin = agent.wm.heads['decoder']._conv_in[0]
+    return ops.linear(stoch.reshape(list(stoch.shape[:-2]) + [-1]), lin.weight, lin.bias)
+
+
+def compute_reward(agent, agent_seq, target_seq, score_fn='cosine'):  # ref :250-277
+    if score_fn != 'max_cosine':
+        raise NotImplementedError(f'{score_fn}: the GenRL configuration uses max_cosine (agent/genrl.yaml:21)')
+    with torch.no_grad():
+        conv_target = _conv_in(agent, target_seq['stoch'])
+    conv_agent = _conv_in(agent, agent_seq['stoch'])
+    return ops.maxcos(conv_target, conv_agent)
+
+
+def _text_feature(agent, task_prompt):
+    wm = agent.wm
+    if not hasattr(wm, 'viclip_model'):
+        raise RuntimeError('video_text_reward needs a text embedder: set agent.wm.viclip_model to an object with '
+                           'get_txt_feat(text) -> (1, 512) (InternVideo2 lookup stays host-side PyTorch)')
+    prompt = task_prompt if task_prompt != '' else TASK2PROMPT.get(agent.cfg.task, agent.cfg.task.replace('_', ' '))
+    with torch.no_grad():
+        return wm.viclip_model.get_txt_feat(prompt).to(agent.device).float()
+
+
+def _build_target(agent, video_embed, T, B, sample_for_target, skip_first_target):
+    """ref :303-311: the cached `unconditional_target`, time-major (T, B, ...)."""
+    steps = T + 1 if skip_first_target else T
+    with torch.no_grad():
+        ve = video_embed.reshape(1, 1, -1).repeat(B, steps, 1)
+        stats = agent.wm.connector.video_imagine(ve, dreamer_init=None, sample=sample_for_target,
+                                                 reset_every_n_frames=False, denoise=True)
+        if skip_first_target:
+            stats = {k: v[:, 1:] for k, v in stats.items()}
+        return {k: v.transpose(0, 1).contiguous() for k, v in stats.items()}
+
+
+def video_text_reward(agent, seq, score_fn='cosine', sample_for_target=False, weighted_align=False,
+                      align_initial=False, align_sequence=False, task_prompt='', skip_first_target=False, **kwargs):
+    """ref :279-370.  The per-window conv_in projections of the reference (9x redundant)
+    are computed once; alignment + final max-cosine reward run in two HIP kernels."""
+    if score_fn != 'max_cosine' or weighted_align or align_initial:
+        raise NotImplementedError('only the shipped configuration (max_cosine, align_sequence) is implemented')
+    n_frames = agent.wm.connector.n_frames
+    T, B = seq['deter'].shape[:2]
+    if not hasattr(agent, 'unconditional_target'):      # computed once, never refreshed
+        agent.unconditional_target = _build_target(agent, _text_feature(agent, task_prompt), T, B,
+                                                   sample_for_target, skip_first_target)
+    target = agent.unconditional_target
+    with torch.no_grad():
+        ct = _conv_in(agent, target['stoch'])            # (T, B, E)
+    ca = _conv_in(agent, seq['stoch'])
+    if align_sequence:
+        urow = ops.align_index(ct, ca.detach(), n_frames)
+        reward = ops.maxcos(ct, ca, urow)
+    else:
+        reward = ops.maxcos(ct, ca)
+    return reward.unsqueeze(-1)
+
+
+def video_video_reward(agent, seq, **kwargs):  # ref :372-409
+    if not hasattr(agent, 'unconditional_target'):
+        wm = agent.wm
+        if not hasattr(wm, 'video_prompt_embed'):
+            raise RuntimeError('video_video_reward: decode + embed the prompt video host-side (cv2 + InternVideo2) '
+                               'and set agent.wm.video_prompt_embed to the (1,512) feature')
+        T, B = seq['deter'].shape[:2]
+        agent.unconditional_target = _build_target(agent, wm.video_prompt_embed.to(agent.device).float(), T, B,
+                                                   kwargs['sample_for_target'], kwargs['skip_first_target'])
+    return video_text_reward(agent, seq, **kwargs)

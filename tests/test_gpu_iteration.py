@@ -1,0 +1,151 @@
+"""End-to-end GPU parity of one train.py iteration (update_wm incl. connector step, second
+connector step, update_imag_behavior) through the drop-in modules, against
+ (a) golden vectors generated from the reference (tests/golden/*.npz) and
+ (b) the CPU oracle on the same weights / batch / injected noise.
+fp32; losses within 1e-3 relative (north_star), most far tighter."""
+import os
+import numpy as np
+import pytest
+import torch
+
+import detgen
+from oracle import genrl_oracle as O
+from oracle.iteration import run_iteration
+from param_shapes import agent_param_shapes
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+class FakeClip:
+    def get_txt_feat(self, text):
+        g = torch.Generator().manual_seed(123)
+        return torch.nn.functional.normalize(torch.randn(1, 512, generator=g), dim=-1)
+
+
+def sites_from(noise):
+    return {'wm.post_q': noise['wm']['post_q'], 'wm.prior_q': noise['wm']['prior_q'],
+            'conn.clip_eps': [noise['conn1']['clip_eps'], noise['conn2']['clip_eps']],
+            'conn.init_q': [noise['conn1']['init_q'], noise['conn2']['init_q']],
+            'conn.ikl_init_q': [noise['conn1']['ikl_init_q'], noise['conn2']['ikl_init_q']],
+            'conn.ikl_step_q': [noise['conn1']['ikl_step_q'], noise['conn2']['ikl_step_q']],
+            'imag.act_eps': noise['imag']['act_eps'], 'imag.step_q': noise['imag']['step_q'],
+            'imag.target_init_q': noise['imag']['target_init_q']}
+
+
+def run_product(name, lr_zero, cfg_over, ocfg_over):
+    if not torch.cuda.is_available():
+        pytest.skip('needs MI355X')
+    from genrl_amd import config, noise as gnoise
+    from genrl_amd.agent import dreamer_utils as common
+    g = dict(np.load(os.path.join(G, name)))
+    B, T, A, S, K, H, seed, _ = [int(x) for x in g['meta']]
+    over = dict(cfg_over)
+    if lr_zero:
+        for k in ('model_opt', 'actor_opt', 'critic_opt'):
+            over[k] = dict(lr=0.0, wd=0.0)
+    cfg = config.default_cfg(B, T, device='cuda', **over)
+    ag = config.make_agent(cfg, act_dim=A)
+    ocfg = O.make_cfg(stoch=S, discrete=K, act_dim=A, horizon=H, **ocfg_over)
+    p = detgen.det_state_dict(agent_param_shapes(ocfg), seed)
+    ag.load_state_dict({k: v.cuda() for k, v in p.items()})
+    ag.wm.viclip_model = FakeClip()
+    batch_cpu = {k[len('batch.'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('batch.')}
+    batch = {k: v.cuda() for k, v in batch_cpu.items()}
+    noise = detgen.iteration_noise(B, T, S, K, A, H, seed=seed)
+    grads, phase = {}, []
+    names = {id(q): n for n, q in ag.named_parameters()}
+
+    def hook(opt_name, params):
+        ph = {'model': 'wm' if 'wm' not in grads else ('conn1' if 'conn1' not in grads else 'conn2'),
+              'actor': 'actor', 'critic': 'critic'}[opt_name]
+        grads[ph] = {names[id(q)]: q.grad.detach().clone().cpu() for q in params}
+    common.Optimizer.grad_hook = hook
+    try:
+        with gnoise.inject(sites_from(noise)):
+            state, outputs, mets = ag.update_wm(batch, 0)
+            mets_wm = {k: float(v) for k, v in mets.items()}
+            _, mets = ag.wm.update_additional_detached_modules(batch, outputs, mets)
+            _, mets = ag.update_imag_behavior(state=None, outputs=outputs, metrics=mets, seq_data=batch)
+    finally:
+        common.Optimizer.grad_hook = None
+    torch.cuda.synchronize()
+    mets = {k: float(v) for k, v in mets.items()}
+    return g, ocfg, p, batch_cpu, noise, ag, outputs, mets_wm, mets, grads
+
+
+def check_vs_golden(g, mets_wm, mets, rtol):
+    for key, val in g.items():
+        for pre, src in (('metrics_wm.', mets_wm), ('metrics_conn2.', mets), ('metrics_imag.', mets)):
+            if key.startswith(pre):
+                n = key[len(pre):]
+                if pre == 'metrics_wm.' and ('connector' in n or 'aligner' in n):
+                    continue
+                np.testing.assert_allclose(src[n], float(val), rtol=rtol, atol=2e-6, err_msg=n)
+
+
+def test_tiny_iteration_vs_reference_and_oracle():
+    tiny_o = dict(deter=32, hidden=32, units=32, cnn_depth=4)
+    from genrl_amd import config
+    g, ocfg, p, batch, noise, ag, outputs, mets_wm, mets, grads = run_product('tiny_iter.npz', True, config.tiny_overrides(), tiny_o)
+    # sampled latent indices identical to the reference's
+    assert (outputs['post']['stoch'].argmax(-1).cpu().numpy() == g['post_idx']).all()
+    assert (outputs['prior']['stoch'].argmax(-1).cpu().numpy() == g['prior_idx']).all()
+    assert (ag.unconditional_target['stoch'].argmax(-1).cpu().numpy() == g['target_idx']).all()
+    c = lambda a, b, **kw: np.testing.assert_allclose(a.detach().cpu().numpy(), b, **kw)
+    c(outputs['embed'], g['full.embed'], rtol=1e-4, atol=1e-5)
+    c(outputs['post']['logit'], g['full.post_logit'], rtol=1e-4, atol=1e-5)
+    c(outputs['prior']['logit'], g['full.prior_logit'], rtol=1e-4, atol=1e-5)
+    c(outputs['kl'], g['full.kl'], rtol=1e-4, atol=1e-5)
+    c(outputs['likes']['observation'], g['full.like_obs'], rtol=1e-5)
+    c(outputs['likes']['reward'], g['full.like_rew'], rtol=1e-4, atol=1e-5)
+    check_vs_golden(g, mets_wm, mets, 2e-4)
+    # gradients against the reference's (stored for tensors <= 20k elements) and the oracle's
+    n = 0
+    for key, val in g.items():
+        if key.startswith('grad.'):
+            _, ph, name = key.split('.', 2)
+            np.testing.assert_allclose(grads[ph][name].numpy(), val, rtol=1e-3, atol=1e-5 * max(1.0, np.abs(val).max()), err_msg=key)
+            n += 1
+    assert n > 50
+    text = FakeClip().get_txt_feat('')
+    res = run_iteration(p, ocfg, batch, noise, text, apply_updates=False)
+    for ph in ('wm', 'conn1', 'conn2', 'actor', 'critic'):
+        assert set(grads[ph]) == set(res['grads'][ph]), (ph, set(grads[ph]) ^ set(res['grads'][ph]))
+        for name, gref in res['grads'][ph].items():
+            a, b = grads[ph][name].numpy(), gref.numpy()
+            np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-5 * max(1.0, np.abs(b).max()), err_msg=f'{ph}.{name}')
+
+
+def test_tiny_optimizer_step_vs_reference():
+    tiny_o = dict(deter=32, hidden=32, units=32, cnn_depth=4)
+    from genrl_amd import config
+    g, ocfg, p, batch, noise, ag, outputs, mets_wm, mets, grads = run_product('tiny_opt.npz', False, config.tiny_overrides(), tiny_o)
+    check_vs_golden(g, mets_wm, mets, 1e-3)
+    sd = ag.state_dict()
+    bad = 0
+    for key, val in g.items():
+        if key.startswith('psum.'):
+            name = key[len('psum.'):]
+            if '_target_critic.' in name or name.startswith('_acting'):
+                continue
+            d = (sd[name].cpu() - p[name]).double()
+            if not np.isclose(d.abs().sum().item(), val[1], rtol=0.05, atol=1e-7):
+                bad += 1
+    assert bad <= 3, bad
+    # slow critic hard-copied after the first update (agent/dreamer.py:455-462)
+    for k in sd:
+        if k.startswith('_imag_behavior._target_critic.'):
+            assert torch.equal(sd[k], sd[k.replace('_target_critic', 'critic')])
+
+
+def test_c1_full_dims_vs_reference():
+    g, ocfg, p, batch, noise, ag, outputs, mets_wm, mets, grads = run_product('c1_full.npz', True, {}, {})
+    mism = (outputs['post']['stoch'].argmax(-1).cpu().numpy() != g['post_idx']).mean()
+    assert mism < 2e-3, mism
+    check_vs_golden(g, mets_wm, mets, 1e-3)
+    for key, val in g.items():
+        if key.startswith('gsum.'):
+            _, ph, name = key.split('.', 2)
+            l2 = grads[ph][name].double().norm().item()
+            np.testing.assert_allclose(l2, val[2], rtol=5e-3, atol=1e-6, err_msg=key)
