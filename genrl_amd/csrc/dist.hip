@@ -342,11 +342,10 @@ __global__ __launch_bounds__(256) void maxcos_bwd_kernel(const float* __restrict
   uv = wave_sum(uv);
   const float g = gout[row];
   float* dr = dv + row * E;
-  if (sv > su) {  // mn = |v|: r = uv / sv
-    for (int j = lane; j < E; j += 64) dr[j] = g * (ur[j] / sv - 2.0f * uv * vr[j] / (sv * sv));
-  } else {
-    for (int j = lane; j < E; j += 64) dr[j] = g * ur[j] / su;
-  }
+  // torch.max(|u|,|v|) backward: the larger norm gets the gradient; an exact tie (u == v, which
+  // happens when the imagined latents equal the target's) splits it evenly.
+  const float wv = sv > su ? 1.0f : (sv == su ? 0.5f : 0.0f);
+  for (int j = lane; j < E; j += 64) dr[j] = g * (ur[j] / fmaxf(su, sv) - wv * 2.0f * uv * vr[j] / (sv * sv));
 }
 
 // Reward alignment (video_text_reward, align_sequence; tools/genrl_utils.py:344-366) given the

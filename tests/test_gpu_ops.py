@@ -121,6 +121,8 @@ def test_mse_maxcos_actor(ops):
     idx = torch.randint(0, 35, (5, 7), generator=g(6))
     compare(lambda v: ops.maxcos(u.cuda(), v, idx.cuda()), lambda v: O.max_cosine_similarity(u.reshape(35, 48)[idx], v),
             [v], rtol=1e-4, atol=1e-6)
+    vt = v.clone(); vt[0] = u[0]      # exact ties |u| == |v|: torch.max splits the gradient
+    compare(lambda v: ops.maxcos(u.cuda(), v), lambda v: O.max_cosine_similarity(u, v), [vt], rtol=1e-4, atol=1e-6)
     raw = torch.randn(9, 20, generator=g(7)); eps = torch.randn(9, 10, generator=g(8))
 
     def ref(raw):
