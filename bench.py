@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""Headline benchmark: world-model + imagination update steps/sec on synthetic 64x64 RGB replay
+(BASELINE.json metric; configs[1]: batch 32 x seq 32, full WM + 2x connector + imag-behaviour
+update with video_text_reward), one process per GPU.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A step = one train.py iteration (train.py:273-340): agent.update_wm (WM Adam step + connector step)
++ wm.update_additional_detached_modules (2nd connector step) + agent.update_imag_behavior
+(actor + critic steps).  Inputs are resident in HBM before the timed region.  Strong scaling: the
+global batch (32 sequences) is sharded over ranks; gradients are all-reduced (RCCL) once per
+optimiser group.  Prints ONE JSON line on rank 0.
+"""
+import argparse, json, os, sys, time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+
+
+def synth_batch(B, T, A=10, img=64, seed=0):
+    """Synthetic replay batch of SURVEY §8(d) c2 (numpy PCG64, seeded)."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    obs = g.integers(0, 256, size=(B, T, 3, img, img), dtype=np.uint8)
+    act = g.uniform(-1, 1, size=(B, T, A)).astype(np.float32)
+    rew = g.uniform(0, 2, size=(B, T, 1)).astype(np.float32)
+    is_first = np.zeros((B, T), bool); is_first[:, 0] = True
+    e = g.standard_normal(size=(B, T // 8, 512)).astype(np.float32)
+    e /= np.linalg.norm(e, axis=-1, keepdims=True)
+    return dict(observation=obs, action=act, reward=rew, discount=np.ones((B, T, 1), np.float32),
+                is_first=is_first, is_last=np.zeros((B, T), bool), is_terminal=np.zeros((B, T), bool),
+                clip_video=np.repeat(e, 8, axis=1))
+
+
+class TextStub:
+    """InternVideo2 text embedder stand-in (weights are not available offline): seeded unit vector."""
+    def get_txt_feat(self, text):
+        g = torch.Generator().manual_seed(123)
+        return torch.nn.functional.normalize(torch.randn(1, 512, generator=g), dim=-1)
+
+
+def one_step(ag, batch):
+    state, outputs, mets = ag.update_wm(batch, 0)
+    _, mets = ag.wm.update_additional_detached_modules(batch, outputs, mets)
+    _, mets = ag.update_imag_behavior(state=None, outputs=outputs, metrics=mets, seq_data=batch)
+    return mets
+
+
+def cpu_baseline(B=4, T=16, threads=None):
+    """The CPU oracle (oracle/, a port of the reference's arithmetic validated against golden vectors
+    generated from the reference) timed on this box's host cores on a bounded sample."""
+    from oracle import genrl_oracle as O
+    from oracle.iteration import run_iteration
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import detgen
+    from param_shapes import agent_param_shapes
+    threads = threads or min(16, os.cpu_count())      # more threads only add OpenMP overhead at these sizes
+    torch.set_num_threads(threads)
+    cfg = O.make_cfg()
+    p = detgen.det_state_dict(agent_param_shapes(cfg), 0)
+    batch = {k: torch.from_numpy(v) for k, v in synth_batch(B, T).items()}
+    noise = detgen.iteration_noise(B, T, cfg.stoch, cfg.discrete, cfg.act_dim, cfg.horizon)
+    text = TextStub().get_txt_feat('')
+    t0 = time.time()
+    run_iteration(p, cfg, batch, noise, text, apply_updates=True)
+    dt = time.time() - t0
+    scale = (32 * 32) / (B * T)
+    return dict(value=1.0 / (dt * scale), unit='steps/s', cores=threads, kind='port',
+                sample=f'one full iteration at B{B}xT{T} ({B*T} of 1024 rows) took {dt:.2f} s on {threads} threads; '
+                       f'value = 1/({dt:.2f} s x {scale:g}) assumes linear scaling in rows to B32xT32')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--length', type=int, default=32)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-profile', action='store_true')
+    ap.add_argument('--dump-gemm', default='')
+    args = ap.parse_args()
+
+    from genrl_amd import build, config, dp, ops, flops_model
+    build.build(verbose=False)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (the hot path has no CPU fallback)')
+    rank, world, local = dp.init()
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    torch.cuda.set_device(local)
+    dev = f'cuda:{local}'
+    from genrl_amd.agent import dreamer_utils as common
+    dp.install(common.Optimizer, common.RewardEMA)
+
+    B, T = args.batch, args.length
+    torch.manual_seed(0)                         # identical random-init weights on every rank
+    cfg = config.default_cfg(B // world, T, device=dev)
+    ag = config.make_agent(cfg)
+    ag.wm.viclip_model = TextStub()
+    full = synth_batch(B, T)
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in dp.shard_batch({k: torch.from_numpy(v) for k, v in full.items()}, rank, world).items()} \
+        if world > 1 else {k: torch.from_numpy(v).to(dev) for k, v in full.items()}
+    torch.manual_seed(1234 + rank)               # per-rank sampling noise
+
+    for _ in range(args.warmup):
+        mets = one_step(ag, batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mets = one_step(ag, batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = dp.barrier_max(time.perf_counter() - t0, dev)
+    loss = float(mets['model_loss'])
+    assert np.isfinite(loss), loss
+
+    out = None
+    if rank == 0:
+        sps = args.steps / dt
+        fl = flops_model.iteration_gflop(B * T)
+        out = {'metric': 'world-model+imag update steps/sec (B32xL32x64x64x3)', 'value': sps, 'unit': 'steps/s',
+               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * dt / args.steps,
+               'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
+               'data': 'synthetic (seeded uint8 64x64 RGB replay, random-init weights, stub text embedding)',
+               'config': {'workload': 'configs[1]: full WM + 2x connector + imag-behaviour update, video_text_reward, '
+                                      f'batch {B} x seq {T}, 64x64x3, horizon 16, A=10',
+                          'global_batch': B, 'seq_len': T, 'parallelism': f'dp{world}'},
+               'algorithmic_gflop_per_step': fl['total'],
+               'step_roofline': {'bound': 'mfma', 'achieved': fl['total'] * sps / 1e3 / world, 'peak': PEAK_F32_MFMA_TFLOPS,
+                                 'unit': 'TFLOP/s', 'frac': fl['total'] * sps / 1e3 / world / PEAK_F32_MFMA_TFLOPS},
+               'final_model_loss': loss}
+    # ---- kernel roofline: HIP events around every launch of the fp32-MFMA GEMM kernel in one extra step
+    if rank == 0 and not args.no_kernel_profile:
+        ops.gemm_profile = []
+        one_step(ag, batch)
+        torch.cuda.synchronize()
+        prof, ops.gemm_profile = ops.gemm_profile, None
+        tot_ms = sum(p_[3].elapsed_time(p_[4]) for p_ in prof)
+        tot_fl = sum(2.0 * p_[0] * p_[1] * p_[2] for p_ in prof)
+        if args.dump_gemm:
+            agg = {}
+            for (m, n, k, e0, e1, mode) in prof:
+                a = agg.setdefault((m, n, k, mode), [0, 0.0])
+                a[0] += 1; a[1] += e0.elapsed_time(e1)
+            rows = sorted(([m, n, k, mode, c, ms] for (m, n, k, mode), (c, ms) in agg.items()), key=lambda r: -r[5])
+            os.makedirs(os.path.dirname(args.dump_gemm) or '.', exist_ok=True)
+            json.dump(rows, open(args.dump_gemm, 'w'))
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                           'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                           'kernel': 'sgemm_kernel<BM,BN,*> (gemm.hip, v_mfma_f32_32x32x2_f32), all instantiations',
+                           'launches_per_step': len(prof), 'avg_launch_us': 1e3 * tot_ms / len(prof),
+                           'gemm_gflop_per_step': tot_fl / 1e9, 'gemm_ms_per_step': tot_ms}
+    elif rank == 0:
+        out['roofline'] = None
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -42,6 +42,9 @@ def lib():
         if not os.path.exists(SO):
             raise GenrlHipError(f'{SO} is missing: build it with `python -m genrl_amd.build` '
                                 '(there is no CPU fallback for the hot path)')
+        # torch bundles its own libamdhip64; it must be resident BEFORE this library is dlopen'ed so
+        # that both share ONE HIP runtime (two runtimes in a process -> "no ROCm-capable device").
+        import torch  # noqa: F401
         L = ctypes.CDLL(SO)
         for name, (ret, args) in parse_header().items():
             fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
@@ -53,4 +56,12 @@ def lib():
 
 def check(code, what):
     if code != 0:
-        raise GenrlHipError(f'{what} failed with status {code}')
+        detail = ''
+        if code == 2:
+            try:
+                fn = _lib.genrl_last_error
+                fn.restype = ctypes.c_char_p
+                detail = ': ' + fn().decode()
+            except Exception:
+                pass
+        raise GenrlHipError(f'{what} failed with status {code}{detail}')

@@ -10,10 +10,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GENRL_EINVAL 1
 #define GENRL_ELAUNCH 2
 
+// hipGetLastError() is sticky per thread: clear whatever an earlier, unrelated HIP call left
+// behind so that GENRL_CHECK_LAUNCH reports only this entry point's launches.
+#define GENRL_ENTER() (void)hipGetLastError()
+
+extern "C" void genrl_set_last_error(int code);
 #define GENRL_CHECK_LAUNCH()                                   \
   do {                                                         \
     hipError_t e__ = hipGetLastError();                        \
-    if (e__ != hipSuccess) return GENRL_ELAUNCH;               \
+    if (e__ != hipSuccess) {                                   \
+      genrl_set_last_error((int)e__);                          \
+      return GENRL_ELAUNCH;                                    \
+    }                                                          \
   } while (0)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -128,6 +128,7 @@ extern "C" {
 
 // in_mode: 0 f32 NHWC, 1 f32 NCHW, 2 u8 NCHW (+preprocess). cols is [N*Ho*Wo, C*k*k].
 int genrl_im2col_s2(const void* in, float* cols, int Nimg, int Hi, int Wi, int C, int k, int in_mode, void* stream) {
+  GENRL_ENTER();
   const int Ho = (Hi - k) / 2 + 1, Wo = (Wi - k) / 2 + 1;
   const long M = (long)Nimg * Ho * Wo;
   if (M <= 0) return GENRL_OK;
@@ -149,6 +150,7 @@ int genrl_im2col_s2(const void* in, float* cols, int Nimg, int Hi, int Wi, int C
 // rows/cols were not covered by any window).
 int genrl_col2im_s2(const float* cols, const float* bias, float* out, int Nimg, int Ha, int Wa, int C, int k,
                     int Ho_override, int Wo_override, int out_nchw, void* stream) {
+  GENRL_ENTER();
   const int Ho = Ho_override > 0 ? Ho_override : 2 * (Ha - 1) + k;
   const int Wo = Wo_override > 0 ? Wo_override : 2 * (Wa - 1) + k;
   const long M = (long)Nimg * Ho * Wo;
@@ -163,6 +165,7 @@ int genrl_col2im_s2(const float* cols, const float* bias, float* out, int Nimg, 
 }
 
 int genrl_transpose_last2(const float* in, float* out, long B, int P, int C, void* stream) {
+  GENRL_ENTER();
   const long n = B * P * C;
   if (n <= 0) return GENRL_OK;
   hipLaunchKernelGGL(transpose_last2_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, B, P, C);

@@ -398,6 +398,7 @@ extern "C" {
 
 int genrl_onehot_fwd(const float* logits, const float* q, float* sample, float* probs, long G, int K, float unimix,
                      void* stream) {
+  GENRL_ENTER();
   if (G <= 0) return GENRL_OK;
   return dispatch_w(K, [&](auto w) {
     constexpr int W = decltype(w)::value;
@@ -410,6 +411,7 @@ int genrl_onehot_fwd(const float* logits, const float* q, float* sample, float* 
 
 int genrl_onehot_bwd(const float* logits, const float* gsample, float* dlogits, long G, int K, float unimix,
                      int accumulate, void* stream) {
+  GENRL_ENTER();
   if (G <= 0) return GENRL_OK;
   return dispatch_w(K, [&](auto w) {
     constexpr int W = decltype(w)::value;
@@ -422,6 +424,7 @@ int genrl_onehot_bwd(const float* logits, const float* gsample, float* dlogits, 
 
 int genrl_cat_kl_fwd(const float* lp, const float* lq, float* kl, float* ent_p, float* ent_q, long R, int S, int K,
                      float unimix, void* stream) {
+  GENRL_ENTER();
   if (R <= 0) return GENRL_OK;
   return dispatch_w(K, [&](auto w) {
     constexpr int W = decltype(w)::value;
@@ -434,6 +437,7 @@ int genrl_cat_kl_fwd(const float* lp, const float* lq, float* kl, float* ent_p, 
 
 int genrl_cat_kl_bwd(const float* lp, const float* lq, const float* gp, const float* gq, float* dlp, float* dlq, long R,
                      int S, int K, float unimix, void* stream) {
+  GENRL_ENTER();
   if (R <= 0) return GENRL_OK;
   const long G = R * S;
   return dispatch_w(K, [&](auto w) {
@@ -447,6 +451,7 @@ int genrl_cat_kl_bwd(const float* lp, const float* lq, const float* gp, const fl
 
 int genrl_twohot_fwd(const float* logits, const float* x, const float* buckets, float* out, long R, int mode,
                      void* stream) {
+  GENRL_ENTER();
   if (R <= 0) return GENRL_OK;
   hipLaunchKernelGGL(twohot_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, logits, x, buckets, out, R,
                      mode);
@@ -456,6 +461,7 @@ int genrl_twohot_fwd(const float* logits, const float* x, const float* buckets, 
 
 int genrl_twohot_bwd(const float* logits, const float* x, const float* buckets, const float* gout, float* dlogits,
                      long R, int mode, void* stream) {
+  GENRL_ENTER();
   if (R <= 0) return GENRL_OK;
   hipLaunchKernelGGL(twohot_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, logits, x, buckets, gout,
                      dlogits, R, mode);
@@ -465,6 +471,7 @@ int genrl_twohot_bwd(const float* logits, const float* x, const float* buckets, 
 
 int genrl_lambda_return_fwd(const float* reward, const float* value, float* ret, int H, long N, float disc, float lam,
                             void* stream) {
+  GENRL_ENTER();
   if (N <= 0) return GENRL_OK;
   hipLaunchKernelGGL(lambda_return_fwd_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, reward, value,
                      ret, H, N, disc, lam);
@@ -474,6 +481,7 @@ int genrl_lambda_return_fwd(const float* reward, const float* value, float* ret,
 
 int genrl_lambda_return_bwd(const float* gret, float* dreward, float* dvalue, int H, long N, float disc, float lam,
                             void* stream) {
+  GENRL_ENTER();
   if (N <= 0) return GENRL_OK;
   hipLaunchKernelGGL(lambda_return_bwd_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, gret, dreward,
                      dvalue, H, N, disc, lam);
@@ -482,6 +490,7 @@ int genrl_lambda_return_bwd(const float* gret, float* dreward, float* dvalue, in
 }
 
 int genrl_mse_fwd(const float* mean, const uint8_t* obs, float* like, long Nimg, int E, void* stream) {
+  GENRL_ENTER();
   if (Nimg <= 0) return GENRL_OK;
   hipLaunchKernelGGL(mse_fwd_kernel, dim3(Nimg), dim3(256), 0, (hipStream_t)stream, mean, obs, like, E);
   GENRL_CHECK_LAUNCH();
@@ -490,6 +499,7 @@ int genrl_mse_fwd(const float* mean, const uint8_t* obs, float* like, long Nimg,
 
 int genrl_mse_bwd(const float* mean, const uint8_t* obs, const float* glike, float* dmean, long Nimg, int E,
                   void* stream) {
+  GENRL_ENTER();
   const long total = Nimg * E;
   if (total <= 0) return GENRL_OK;
   hipLaunchKernelGGL(mse_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, mean, obs, glike, dmean,
@@ -499,6 +509,7 @@ int genrl_mse_bwd(const float* mean, const uint8_t* obs, const float* glike, flo
 }
 
 int genrl_maxcos_fwd(const float* u, const float* v, const long* urow, float* out, long R, int E, void* stream) {
+  GENRL_ENTER();
   if (R <= 0) return GENRL_OK;
   hipLaunchKernelGGL(maxcos_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, u, v, urow, out, R, E);
   GENRL_CHECK_LAUNCH();
@@ -507,6 +518,7 @@ int genrl_maxcos_fwd(const float* u, const float* v, const long* urow, float* ou
 
 int genrl_maxcos_bwd(const float* u, const float* v, const long* urow, const float* gout, float* dv, long R, int E,
                      void* stream) {
+  GENRL_ENTER();
   if (R <= 0) return GENRL_OK;
   hipLaunchKernelGGL(maxcos_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, u, v, urow, gout, dv, R,
                      E);
@@ -515,6 +527,7 @@ int genrl_maxcos_bwd(const float* u, const float* v, const long* urow, const flo
 }
 
 int genrl_align_index(const float* ct, const float* ca, long* urow, int T, long N, int E, int nf, void* stream) {
+  GENRL_ENTER();
   if (N <= 0) return GENRL_OK;
   hipLaunchKernelGGL(align_index_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, ct, ca, urow, T, N, E,
                      nf);

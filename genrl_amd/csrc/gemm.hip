@@ -34,8 +34,8 @@ constexpr int BK = 16;
 template <int BM, int BN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void sgemm_kernel(
     const float* __restrict__ A, long a_ld, const float* __restrict__ B, long b_ld,
-    float* __restrict__ C, long ldc, const float* __restrict__ bias, int M, int N, int K,
-    int accumulate, int a_vec, int b_vec, int tiles_n, int ntiles) {
+    float* __restrict__ C, long ldc, const float* __restrict__ bias, int M, int N, int Ktot,
+    int accumulate, int a_vec, int b_vec, int tiles_n, int ntiles, int k_per_split, float* __restrict__ ws) {
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int AV = BM * BK / 4 / 256, BV = BN * BK / 4 / 256;   // float4 loads per thread per tile
@@ -49,6 +49,15 @@ __global__ __launch_bounds__(256) void sgemm_kernel(
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
   }
   const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+  // split-K: blockIdx.y owns k in [kbeg, K) and writes a partial tile to ws[blockIdx.y][M][N]
+  const int kbeg = blockIdx.y * k_per_split;
+  const int K = min(Ktot, kbeg + k_per_split);
+  if (ws) {
+    C = ws + (long)blockIdx.y * M * N;
+    ldc = N;
+    bias = nullptr;
+    accumulate = 0;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
 
@@ -112,11 +121,11 @@ __global__ __launch_bounds__(256) void sgemm_kernel(
     }
   };
 
-  const int nk = (K + BK - 1) / BK;
+  const int nk = (K - kbeg + BK - 1) / BK;
 #pragma unroll
-  for (int i = 0; i < AV; ++i) load_tile(A, a_ld, a_vec, M, m0, 0, A_KC, BM, ra[i], tid + i * 256);
+  for (int i = 0; i < AV; ++i) load_tile(A, a_ld, a_vec, M, m0, kbeg, A_KC, BM, ra[i], tid + i * 256);
 #pragma unroll
-  for (int i = 0; i < BV; ++i) load_tile(B, b_ld, b_vec, N, n0, 0, B_KC, BN, rb[i], tid + i * 256);
+  for (int i = 0; i < BV; ++i) load_tile(B, b_ld, b_vec, N, n0, kbeg, B_KC, BN, rb[i], tid + i * 256);
 #pragma unroll
   for (int i = 0; i < AV; ++i) store_tile(As[0], LDA, A_KC, BM, ra[i], tid + i * 256);
 #pragma unroll
@@ -129,10 +138,10 @@ __global__ __launch_bounds__(256) void sgemm_kernel(
     if (kt + 1 < nk) {
 #pragma unroll
       for (int i = 0; i < AV; ++i)
-        load_tile(A, a_ld, a_vec, M, m0, (kt + 1) * BK, A_KC, BM, ra[i], tid + i * 256);
+        load_tile(A, a_ld, a_vec, M, m0, kbeg + (kt + 1) * BK, A_KC, BM, ra[i], tid + i * 256);
 #pragma unroll
       for (int i = 0; i < BV; ++i)
-        load_tile(B, b_ld, b_vec, N, n0, (kt + 1) * BK, B_KC, BN, rb[i], tid + i * 256);
+        load_tile(B, b_ld, b_vec, N, n0, kbeg + (kt + 1) * BK, B_KC, BN, rb[i], tid + i * 256);
     }
     const float* as = As[cur];
     const float* bs = Bs[cur];
@@ -179,18 +188,54 @@ __global__ __launch_bounds__(256) void sgemm_kernel(
     }
 }
 
+// C[m,n] = sum_s ws[s][m][n] (+bias[n]) (+C[m,n])
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, long ldc,
+                                     const float* __restrict__ bias, int M, int N, int splits, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long MN = (long)M * N;
+  if (i >= MN) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += ws[(long)k * MN + i];
+  const int m = (int)(i / N), n = (int)(i % N);
+  if (bias) s += bias[n];
+  float* c = C + (long)m * ldc + n;
+  *c = accumulate ? *c + s : s;
+}
+
+// Split-K plan: GEMMs whose output has too few 64x64 tiles to fill 256 CUs with several
+// workgroups each (M=N=1024 -> 256 tiles; the conv weight gradients -> 1..54 tiles with K up to
+// ~10^6) split the reduction over blockIdx.y into a caller-provided workspace and are summed by a
+// second, deterministic pass.
+struct SplitPlan {
+  int splits, k_per_split;
+};
+inline SplitPlan plan_split(int M, int N, int K) {
+  const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
+  SplitPlan p{1, K};
+  if (tiles >= 768 || K < 512) return p;
+  long s = cdiv(1024, tiles);
+  const long smax = K / 256;          // at least 256 k per split (16 k-tiles)
+  if (s > smax) s = smax;
+  if (s <= 1) return p;
+  int kps = cdiv(cdiv(K, s), BK) * BK;
+  p.k_per_split = kps;
+  p.splits = cdiv(K, kps);
+  return p;
+}
+
 template <int BM, int BN>
 int launch_cfg(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks, float* C,
-               long ldc, const float* bias, int M, int N, int K, int accumulate, hipStream_t s) {
+               long ldc, const float* bias, int M, int N, int K, int accumulate, int splits, int kps, float* ws,
+               hipStream_t s) {
   const bool a_kc = (a_ks == 1), b_kc = (b_ks == 1);
   const long a_ld = a_kc ? a_rs : a_ks, b_ld = b_kc ? b_rs : b_ks;
   const int a_vec = ((a_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   const int b_vec = ((b_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
   const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN), ntiles = tiles_m * tiles_n;
-  dim3 grid(ntiles), block(256);
+  dim3 grid(ntiles, splits), block(256);
 #define GO(AK, BKC)                                                                             \
   hipLaunchKernelGGL((sgemm_kernel<BM, BN, AK, BKC>), grid, block, 0, s, A, a_ld, B, b_ld, C, ldc, \
-                     bias, M, N, K, accumulate, a_vec, b_vec, tiles_n, ntiles)
+                     bias, M, N, K, accumulate, a_vec, b_vec, tiles_n, ntiles, kps, ws)
   if (a_kc && b_kc) GO(true, true);
   else if (a_kc && !b_kc) GO(true, false);
   else if (!a_kc && b_kc) GO(false, true);
@@ -202,15 +247,38 @@ int launch_cfg(const float* A, long a_rs, long a_ks, const float* B, long b_rs, 
 
 }  // namespace
 
+static int g_last_error = 0;
+extern "C" void genrl_set_last_error(int code) { g_last_error = code; }
+// text of the HIP error behind the most recent status-2 return (diagnostics only)
+extern "C" const char* genrl_last_error(void) { return hipGetErrorString((hipError_t)g_last_error); }
+
+extern "C" long genrl_sgemm_ws_floats(int M, int N, int K) {
+  const SplitPlan p = plan_split(M, N, K);
+  return p.splits > 1 ? (long)p.splits * M * N : 0;
+}
+
 extern "C" int genrl_sgemm(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks,
                            float* C, long ldc, const float* bias, int M, int N, int K,
-                           int accumulate, void* stream) {
+                           int accumulate, float* ws, long ws_floats, void* stream) {
+  GENRL_ENTER();
   if (M <= 0 || N <= 0) return GENRL_OK;
   if (K <= 0 || (a_rs != 1 && a_ks != 1) || (b_rs != 1 && b_ks != 1)) return GENRL_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // 128x128 tiles only when they still give >= 2 workgroups per CU; otherwise 64x64 to keep the
-  // 256 CUs busy on the M=1024 GEMMs of the imagination phase.
+  // 128x128 tiles only when they still give >= 2 workgroups per CU; otherwise 64x64 (+ split-K)
+  // to keep the 256 CUs busy on the M=1024 GEMMs of the imagination phase.
   const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
-  if (t128 >= 512) return launch_cfg<128, 128>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, s);
-  return launch_cfg<64, 64>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, s);
+  if (t128 >= 512)
+    return launch_cfg<128, 128>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, 1, K, nullptr, s);
+  const SplitPlan p = plan_split(M, N, K);
+  if (p.splits > 1 && ws && ws_floats >= (long)p.splits * M * N) {
+    int rc = launch_cfg<64, 64>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, p.splits,
+                                p.k_per_split, ws, s);
+    if (rc) return rc;
+    const long MN = (long)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(MN, 256)), dim3(256), 0, s, ws, C, ldc, bias, M, N, p.splits,
+                       accumulate);
+    GENRL_CHECK_LAUNCH();
+    return GENRL_OK;
+  }
+  return launch_cfg<64, 64>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, 1, K, nullptr, s);
 }

@@ -68,6 +68,7 @@ long genrl_sqnorm_ws_floats(long n) { return 1024; }
 
 // norm_out[0] = scale * ||g||_2 ; ws >= 1024 floats
 int genrl_grad_norm(const float* g, long n, float* norm_out, float* ws, float scale, void* stream) {
+  GENRL_ENTER();
   hipStream_t s = (hipStream_t)stream;
   int nb = cdiv(n, 256 * 4 * 8);
   nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
@@ -81,6 +82,7 @@ int genrl_grad_norm(const float* g, long n, float* norm_out, float* ws, float sc
 // genrl_grad_norm (already including gscale); gscale multiplies g before use (1/world_size).
 int genrl_adam_step(float* p, const float* g, float* m, float* v, long n, const float* norm, float gscale, float clip,
                     float lr, float b1, float b2, float eps, float wd, int step, void* stream) {
+  GENRL_ENTER();
   if (n <= 0) return GENRL_OK;
   const float bc1 = 1.0f - powf(b1, (float)step);
   const float sqrt_bc2 = sqrtf(1.0f - powf(b2, (float)step));
@@ -91,6 +93,7 @@ int genrl_adam_step(float* p, const float* g, float* m, float* v, long n, const 
 }
 
 int genrl_scale(float* p, long n, float s, void* stream) {
+  GENRL_ENTER();
   if (n <= 0) return GENRL_OK;
   hipLaunchKernelGGL(scale_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, n, s);
   GENRL_CHECK_LAUNCH();

@@ -270,6 +270,7 @@ extern "C" {
 
 int genrl_ln_act_fwd(const float* x, long ldx, const float* gamma, const float* beta, float* y, long ldy,
                      float* mean, float* rstd, int M, int N, float eps, int act, void* stream) {
+  GENRL_ENTER();
   if (M <= 0) return GENRL_OK;
   hipLaunchKernelGGL(ln_act_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma,
                      beta, y, ldy, mean, rstd, M, N, eps, act);
@@ -284,6 +285,7 @@ int genrl_ln_act_bwd(const float* dy, long lddy, const float* x, long ldx, const
                      const float* beta, const float* mean, const float* rstd, float* dx, long lddx,
                      float* dgamma, float* dbeta, float* ws, int M, int N, int act, int accumulate_params,
                      void* stream) {
+  GENRL_ENTER();
   if (M <= 0) return GENRL_OK;
   hipStream_t s = (hipStream_t)stream;
   if (dgamma) {
@@ -309,6 +311,7 @@ int genrl_ln_act_bwd(const float* dy, long lddy, const float* x, long ldx, const
 long genrl_colsum_ws_floats(int M, int N) { return (long)chunks_for(M) * N; }
 
 int genrl_colsum(const float* x, long ldx, float* out, float* ws, int M, int N, int accumulate, void* stream) {
+  GENRL_ENTER();
   hipStream_t s = (hipStream_t)stream;
   const int nchunk = chunks_for(M);
   const int rpc = cdiv(M, nchunk);
@@ -320,6 +323,7 @@ int genrl_colsum(const float* x, long ldx, float* out, float* ws, int M, int N, 
 
 int genrl_gru_gates_fwd(const float* pre, const float* h, long ldh, const float* gamma, const float* beta,
                         float* hout, long ldo, float* mean, float* rstd, int R, int D, float eps, void* stream) {
+  GENRL_ENTER();
   if (R <= 0) return GENRL_OK;
   hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, pre, h, ldh, gamma,
                      beta, hout, ldo, mean, rstd, R, D, eps);
@@ -333,6 +337,7 @@ int genrl_gru_gates_bwd(const float* dhout, long lddo, const float* pre, const f
                         const float* gamma, const float* beta, const float* mean, const float* rstd,
                         float* dpre, float* dh, long lddh, float* dgamma, float* dbeta, float* ws, int R, int D,
                         int dh_accumulate, int accumulate_params, void* stream) {
+  GENRL_ENTER();
   if (R <= 0) return GENRL_OK;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, dhout, lddo, pre, h, ldh, gamma, beta,
@@ -344,6 +349,7 @@ int genrl_gru_gates_bwd(const float* dhout, long lddo, const float* pre, const f
 
 int genrl_actor_head_fwd(const float* raw, const float* eps, float* action, float* mean, float* std, long R, int A,
                          float min_std, float max_std, void* stream) {
+  GENRL_ENTER();
   const long n = R * A;
   if (n <= 0) return GENRL_OK;
   hipLaunchKernelGGL(actor_head_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, raw, eps, action,
@@ -354,6 +360,7 @@ int genrl_actor_head_fwd(const float* raw, const float* eps, float* action, floa
 
 int genrl_actor_head_bwd(const float* daction, const float* raw, const float* eps, float* draw, long R, int A,
                          float min_std, float max_std, void* stream) {
+  GENRL_ENTER();
   const long n = R * A;
   if (n <= 0) return GENRL_OK;
   hipLaunchKernelGGL(actor_head_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, daction, raw, eps,
@@ -364,6 +371,7 @@ int genrl_actor_head_bwd(const float* daction, const float* raw, const float* ep
 
 int genrl_copy2d(const float* src, long lds_, float* dst, long ldd, long rows, int cols, const float* rowscale,
                  int accumulate, void* stream) {
+  GENRL_ENTER();
   const long n = rows * cols;
   if (n <= 0) return GENRL_OK;
   hipLaunchKernelGGL(copy2d_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, src, lds_, dst, ldd, rows,

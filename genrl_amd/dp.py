@@ -1,0 +1,83 @@
+"""Replay-batch data parallelism: one process per GPU, `torch.distributed` (backend "nccl" is RCCL
+over xGMI on ROCm).  The batch dimension B is sharded across ranks (sequences are independent,
+SURVEY.md §8e); every optimiser group lives in ONE flat gradient buffer
+(agent/dreamer_utils.FlatGroup), so a step issues exactly one sum-all-reduce per group
+(world model, connector x2, actor, critic) right after its backward — the clip-norm and Adam
+kernels then consume the reduced buffer with the 1/world factor folded in.  The RewardEMA
+quantiles are taken over the all-gathered lambda-returns so every rank normalises identically.
+Works with gloo on CPU tensors too (used by the world_size-2 tests)."""
+import os
+import torch
+import torch.distributed as dist
+
+
+def init(backend=None):
+    """Initialise from the torchrun environment.  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_batch(batch, rank, world):
+    """Rank r takes sequences [r*B/P, (r+1)*B/P) of the replay batch."""
+    if world == 1:
+        return batch
+    out = {}
+    for k, v in batch.items():
+        B = v.shape[0]
+        assert B % world == 0, f'batch {B} not divisible by world {world}'
+        per = B // world
+        out[k] = v[rank * per:(rank + 1) * per].contiguous()
+    return out
+
+
+def shard_rows(x, rank, world, dim):
+    """Slice of a noise tensor whose `dim` enumerates global rows b-major (b*rows_per_b + i)."""
+    if world == 1:
+        return x
+    n = x.shape[dim]
+    per = n // world
+    return x.narrow(dim, rank * per, per).contiguous()
+
+
+def grad_reduce(flat_grad):
+    """Sum-all-reduce one flat gradient buffer in place; returns the divisor (world size)."""
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    return dist.get_world_size()
+
+
+def all_gather_flat(x):
+    out = [torch.empty_like(x) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, x.contiguous())
+    return torch.cat(out)
+
+
+def install(optimizer_cls, reward_ema_cls):
+    """Hook the collectives into the product classes (no-op for world size 1)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        optimizer_cls.grad_reduce = staticmethod(grad_reduce)
+        reward_ema_cls.all_gather = staticmethod(all_gather_flat)
+
+
+def uninstall(optimizer_cls, reward_ema_cls):
+    optimizer_cls.grad_reduce = None
+    reward_ema_cls.all_gather = None
+
+
+def barrier_max(seconds, device):
+    """max over ranks of a host-measured duration"""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,59 @@
+"""Algorithmic FLOP model of one GenRL training iteration: 2*MAC, forward + dgrad
+where the input needs a gradient + wgrad where the weight is trained in that phase; reward
+projections de-duplicated, no slow-critic wgrad.  Reproduces the SURVEY table (c2: 3288 GF)."""
+
+
+def conv_macs(img, depth, kernels):
+    size, cin, out = img, 3, []
+    for i, k in enumerate(kernels):
+        size = (size - k) // 2 + 1
+        co = 2 ** i * depth
+        out.append(size * size * co * cin * k * k)
+        cin = co
+    return out, size, cin
+
+
+def deconv_macs(depth, kernels, S):
+    n = len(kernels)
+    size, cin, out = 1, 32 * depth, [S * 32 * depth]
+    for i, k in enumerate(kernels):
+        co = 3 if i == n - 1 else 2 ** (n - i - 2) * depth
+        out.append(size * size * cin * co * k * k)
+        size = 2 * (size - 1) + k
+        cin = co
+    return out
+
+
+def per_unit_macs(A=10, S=1024, D=1024, Hd=1024, U=1024, img=64, depth=48, enc_k=(4, 4, 4, 4), dec_k=(5, 5, 6, 6),
+                  clip=512):
+    enc, last, cl = conv_macs(img, depth, enc_k)
+    E = cl * last * last
+    dec = deconv_macs(depth, dec_k, S)
+    F = S + D
+    m = dict(enc=sum(enc), conv1=enc[0], dec=sum(dec), conv_in=dec[0],
+             post=E * Hd + Hd * S,
+             img_step=(S + A) * Hd + (Hd + D) * 3 * D + D * Hd + Hd * S,
+             mlp_dense0=F * U, mlp_body=F * U + 3 * U * U)
+    m['reward'] = m['mlp_body'] + U * 255
+    m['critic'] = m['reward']
+    m['actor'] = m['mlp_body'] + 2 * A * U
+    ca = clip + 8
+    m['conn_step'] = (S + ca) * Hd + (Hd + D) * 3 * D + D * Hd + Hd * S
+    h = clip // 2
+    m['aligner'] = clip * clip + 2 * clip * h + 2 * h * h + (2 * h) * clip + 2 * (2 * clip) * clip
+    return m
+
+
+def iteration_gflop(N, H=16, connector_steps=2, **kw):
+    m = per_unit_macs(**kw)
+    wm_fwd = m['enc'] + m['post'] + m['img_step'] + m['dec'] + m['reward']
+    wm_bwd = 2 * wm_fwd - m['conv1'] - m['mlp_dense0']
+    conn = 3 * (m['conn_step'] + m['aligner'])
+    d0 = m['mlp_dense0']
+    imag_fwd = (H + 1) * m['actor'] + H * m['img_step'] + 2 * (H + 1) * m['conv_in'] + (H + 1) * m['critic'] \
+        + (H - 1) * m['actor'] + H * m['critic']
+    imag_bwd = H * m['img_step'] + H * (2 * m['actor'] - d0) + (H + 1) * m['critic'] + (H + 1) * m['conv_in'] \
+        + (H - 1) * (2 * m['actor'] - d0) + H * (2 * m['critic'] - d0)
+    g = lambda macs: 2.0 * macs * N / 1e9
+    return dict(wm=g(wm_fwd + wm_bwd), connector=g(conn) * connector_steps, imag=g(imag_fwd + imag_bwd),
+                total=g(wm_fwd + wm_bwd) + g(conn) * connector_steps + g(imag_fwd + imag_bwd))

@@ -7,6 +7,7 @@ from torch.autograd import Function
 from ._lib import lib, check, GenrlHipError
 
 UNIMIX = 0.99
+gemm_profile = None      # set to a list to record (M, N, K, start_event, end_event) per sgemm launch
 
 
 def _stream():
@@ -37,8 +38,16 @@ def _ws(n, dev):
 
 def sgemm(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate=False, a_off=0, b_off=0, c_off=0):
     """C[m,n] (+)= sum_k A[m*a_rs+k*a_ks] B[n*b_rs+k*b_ks] (+bias[n]); offsets in elements."""
+    if gemm_profile is not None:        # bench.py: HIP events around every launch of the GEMM kernel
+        e0 = torch.cuda.Event(enable_timing=True); e0.record()
+    nws = lib().genrl_sgemm_ws_floats(M, N, K)
+    ws = torch.empty(nws, dtype=torch.float32, device=C.device) if nws > 0 else None
     check(lib().genrl_sgemm(A.data_ptr() + 4 * a_off, a_rs, a_ks, B.data_ptr() + 4 * b_off, b_rs, b_ks,
-                            C.data_ptr() + 4 * c_off, ldc, _p(bias), M, N, K, int(accumulate), _stream()), 'sgemm')
+                            C.data_ptr() + 4 * c_off, ldc, _p(bias), M, N, K, int(accumulate), _p(ws), nws,
+                            _stream()), 'sgemm')
+    if gemm_profile is not None:
+        e1 = torch.cuda.Event(enable_timing=True); e1.record()
+        gemm_profile.append((M, N, K, e0, e1, ('k' if a_ks == 1 else 'r') + ('k' if b_ks == 1 else 'r')))
 
 
 def colsum(x2d, out=None, accumulate=False):

@@ -20,9 +20,13 @@ extern "C" {
 
 /* ---- dense products: nn.Linear fwd/dgrad/wgrad (agent/dreamer_utils.py:339-346,734,760,798)
  * C[m,n] = sum_k A[m*a_rs+k*a_ks] * B[n*b_rs+k*b_ks] (+bias[n]) (+C if accumulate);
- * one stride of each operand must be 1.  fp32 MFMA (v_mfma_f32_32x32x2_f32). */
+ * one stride of each operand must be 1.  fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * Shapes with few output tiles and a long reduction (the M=N=1024 GEMMs, the conv weight
+ * gradients) are split over K into `ws` (>= genrl_sgemm_ws_floats(M,N,K) floats; pass NULL/0 to
+ * disable) and reduced deterministically. */
+long genrl_sgemm_ws_floats(int M, int N, int K);
 int genrl_sgemm(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks, float* C, long ldc,
-                const float* bias, int M, int N, int K, int accumulate, void* stream);
+                const float* bias, int M, int N, int K, int accumulate, float* ws, long ws_floats, void* stream);
 
 /* ---- LayerNorm(+SiLU): NormLayer + act (agent/dreamer_utils.py:844-859,462-463,745) and, on NHWC
  * activations, ImgChLayerNorm (:1031-1040).  act: 0 none, 1 SiLU. */

@@ -45,7 +45,7 @@ def compare(hip_fn, ref_fn, inputs, rtol=2e-5, atol=2e-5, grad_mask=None, nondif
 
 
 @pytest.mark.parametrize('M,N,K', [(64, 64, 16), (1, 1, 1), (37, 53, 29), (130, 70, 1034), (32, 255, 96),
-                                   (1024, 1024, 256), (2048, 4096, 64), (96, 16, 26)])
+                                   (1024, 1024, 256), (2048, 4096, 64), (96, 16, 26), (9000, 48, 64), (640, 200, 2050)])
 def test_linear(ops, M, N, K):
     x = torch.randn(M, K, generator=g(1)); W = torch.randn(N, K, generator=g(2)) / K ** 0.5
     b = torch.randn(N, generator=g(3))
