@@ -9,8 +9,10 @@
 //                                          y[n,oh,ow,co] = bias[co] + sum_{kh,kw} cols[(n,(oh-kh)/2,(ow-kw)/2),(co,kh,kw)]
 //
 // The two kernels here are the patch gather (im2col) and its adjoint in gather form (col2im): both
-// pure data movement, HBM-bound, no atomics, deterministic.  The reference's weight layouts
-// (Cout,Cin,kh,kw) / (Cin,Cout,kh,kw) are used as-is: the K order of `cols` is (c,kh,kw).
+// pure data movement, HBM-bound, no atomics, deterministic.  The K order of `cols` is (kh,kw,c) —
+// channel fastest — so that both kernels move contiguous C-runs (coalesced); the reference's weight
+// layouts (Cout,Cin,kh,kw) / (Cin,Cout,kh,kw) are permuted once per step to (.., kh,kw, c) by
+// transpose_last2 (tiny: <= 10 M floats) and their gradients permuted back by its adjoint.
 // Index arithmetic is hoisted: per block a K-entry offset table and per-pixel bases live in LDS,
 // so the inner loops contain no integer division.
 #include "common.h"
@@ -19,7 +21,7 @@ namespace {
 
 constexpr int RP = 32;  // output pixels per workgroup
 
-// cols[(n,a,b), (c,kh,kw)] = in[n, 2a+kh, 2b+kw, c]
+// cols[(n,a,b), (kh,kw,c)] = in[n, 2a+kh, 2b+kw, c]
 // MODE 0: in = f32 NHWC ; MODE 1: in = f32 NCHW ; MODE 2: in = u8 NCHW with x/255-0.5 fused
 // (WorldModel.preprocess, agent/dreamer.py:294-295).
 template <int MODE>
@@ -31,7 +33,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ in
   long* base = reinterpret_cast<long*>(smem + ((K * 4 + 15) / 16) * 16);
   const int tid = threadIdx.y * 64 + threadIdx.x;
   for (int kk = tid; kk < K; kk += 256) {
-    const int c = kk / (k * k), r = kk % (k * k), kh = r / k, kw = r % k;
+    const int r = kk / C, c = kk % C, kh = r / k, kw = r % k;
     in_off[kk] = (MODE == 0) ? (kh * Wi + kw) * C + c : (c * Hi + kh) * Wi + kw;
   }
   const long m0 = (long)blockIdx.x * RP;
@@ -61,22 +63,23 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ in
   }
 }
 
-// out[n,y,x,c] = bias[c] + sum_{kh=y mod 2.., kw=x mod 2..} cols[(n,(y-kh)/2,(x-kw)/2), (c,kh,kw)]
-// cols rows are (n,a,b) over Ha x Wa; out is Ho x Wo with Ho = 2*(Ha-1)+k.
+// out[n,y,x,c] = bias[c] + sum_{kh=y mod 2.., kw=x mod 2..} cols[(n,(y-kh)/2,(x-kw)/2), (kh,kw,c)]
+// cols rows are (n,a,b) over Ha x Wa; out is Ho x Wo with Ho = 2*(Ha-1)+k (or given).
+// A workgroup owns `rp` output pixels (rp*C >= ~1024 work items so that C = 3 still fills the
+// lanes); work items (pixel, c) are flattened c-fastest: loads and stores are contiguous C-runs.
 // OUT_NCHW: write out[n,c,y,x] instead of NHWC.
 template <bool OUT_NCHW>
 __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ cols, const float* __restrict__ bias,
                                                      float* __restrict__ out, long Mout, int Ha, int Wa, int C, int k,
-                                                     int Ho, int Wo) {
-  __shared__ long rowoff[RP][9];
-  __shared__ int kofs[RP][9];
-  __shared__ int nterm[RP];
-  const int tid = threadIdx.y * 64 + threadIdx.x;
-  const int kk = k * k;
-  const long Kc = (long)C * kk;
-  const long m0 = (long)blockIdx.x * RP;
-  if (tid < RP) {
-    const long m = m0 + tid;
+                                                     int Ho, int Wo, int rp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  long* rowoff = reinterpret_cast<long*>(smem);                 // [rp][9]
+  int* kofs = reinterpret_cast<int*>(smem + (size_t)rp * 9 * 8);  // [rp][9]
+  int* nterm = kofs + rp * 9;                                   // [rp]
+  const long Kc = (long)C * k * k;
+  const long m0 = (long)blockIdx.x * rp;
+  for (int t = threadIdx.x; t < rp; t += 256) {
+    const long m = m0 + t;
     int nt = 0;
     if (m < Mout) {
       const long n = m / (Ho * Wo);
@@ -87,28 +90,29 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ c
         for (int kw = x & 1; kw < k; kw += 2) {
           const int b = (x - kw) / 2;
           if (x - kw < 0 || b >= Wa) continue;
-          rowoff[tid][nt] = ((n * Ha + a) * Wa + b) * Kc;
-          kofs[tid][nt] = kh * k + kw;
+          rowoff[t * 9 + nt] = ((n * Ha + a) * Wa + b) * Kc;
+          kofs[t * 9 + nt] = (kh * k + kw) * C;
           ++nt;
         }
       }
     }
-    nterm[tid] = nt;
+    nterm[t] = nt;
   }
   __syncthreads();
-  for (int pix = threadIdx.y; pix < RP; pix += 4) {
+  const int items = rp * C;
+  for (int w = threadIdx.x; w < items; w += 256) {
+    const int pix = w / C, c = w - pix * C;
     const long m = m0 + pix;
     if (m >= Mout) break;
     const int nt = nterm[pix];
-    const long n = m / (Ho * Wo);
-    const int p = (int)(m % (Ho * Wo));
-    for (int c = threadIdx.x; c < C; c += 64) {
-      float acc = bias ? bias[c] : 0.f;
-      for (int t = 0; t < nt; ++t) acc += cols[rowoff[pix][t] + (long)c * kk + kofs[pix][t]];
-      if (OUT_NCHW)
-        out[(n * C + c) * (long)(Ho * Wo) + p] = acc;
-      else
-        out[m * C + c] = acc;
+    float acc = bias ? bias[c] : 0.f;
+    for (int t = 0; t < nt; ++t) acc += cols[rowoff[pix * 9 + t] + kofs[pix * 9 + t] + c];
+    if (OUT_NCHW) {
+      const long n = m / (Ho * Wo);
+      const int p = (int)(m % (Ho * Wo));
+      out[(n * C + c) * (long)(Ho * Wo) + p] = acc;
+    } else {
+      out[m * C + c] = acc;
     }
   }
 }
@@ -156,10 +160,13 @@ int genrl_col2im_s2(const float* cols, const float* bias, float* out, int Nimg, 
   const long M = (long)Nimg * Ho * Wo;
   if (M <= 0) return GENRL_OK;
   if (k > 6 || k < 1) return GENRL_EINVAL;
-  dim3 grid(cdiv(M, RP)), block(64, 4);
+  int rp = cdiv(1024, C);
+  rp = rp < 32 ? 32 : (rp > 512 ? 512 : rp);
+  const size_t smem = (size_t)rp * 9 * 8 + (size_t)rp * 9 * 4 + (size_t)rp * 4;
+  dim3 grid(cdiv(M, rp)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (out_nchw) hipLaunchKernelGGL((col2im_kernel<true>), grid, block, 0, s, cols, bias, out, M, Ha, Wa, C, k, Ho, Wo);
-  else hipLaunchKernelGGL((col2im_kernel<false>), grid, block, 0, s, cols, bias, out, M, Ha, Wa, C, k, Ho, Wo);
+  if (out_nchw) hipLaunchKernelGGL((col2im_kernel<true>), grid, block, smem, s, cols, bias, out, M, Ha, Wa, C, k, Ho, Wo, rp);
+  else hipLaunchKernelGGL((col2im_kernel<false>), grid, block, smem, s, cols, bias, out, M, Ha, Wa, C, k, Ho, Wo, rp);
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }

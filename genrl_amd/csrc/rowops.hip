@@ -115,6 +115,46 @@ __global__ void reduce_chunks_kernel(const float* __restrict__ part, float* __re
   out[j] = accumulate ? out[j] + s : s;
 }
 
+// (dgamma | dbeta) (+)= sum_c part[c][2][N].  Two-level so that a few hundred partial rows do not
+// become a serial chain: stage A (grid.y = G groups of chunks) -> tmp[G][2N]; stage B sums G rows.
+__global__ __launch_bounds__(256) void reduce_chunksA_kernel(const float* __restrict__ part, float* __restrict__ tmp,
+                                                             int nchunk, int N2, int per_group) {
+  __shared__ float sm[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int sub = threadIdx.x >> 6;
+  const int c0 = blockIdx.y * per_group, c1 = min(nchunk, c0 + per_group);
+  float a = 0.f;
+  if (c < N2)
+    for (int r = c0 + sub; r < c1; r += 4) a += part[(long)r * N2 + c];
+  sm[sub][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (sub == 0 && c < N2) {
+    const int l = threadIdx.x;
+    tmp[(long)blockIdx.y * N2 + c] = sm[0][l] + sm[1][l] + sm[2][l] + sm[3][l];
+  }
+}
+__global__ void reduce_chunks2_kernel(const float* __restrict__ part, float* __restrict__ out0,
+                                      float* __restrict__ out1, int nchunk, int N, int accumulate) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= 2 * N) return;
+  float s = 0.f;
+  for (int c = 0; c < nchunk; ++c) s += part[(long)c * 2 * N + j];
+  float* o = j < N ? out0 + j : out1 + (j - N);
+  *o = accumulate ? *o + s : s;
+}
+// helper: part[nchunk][2N] -> (out0 | out1); `tmp` must hold 16*2N floats when nchunk > 16
+static inline void reduce_params(const float* part, float* tmp, float* out0, float* out1, int nchunk, int N,
+                                 int accumulate, hipStream_t s) {
+  if (nchunk > 16) {
+    const int G = 16, per = cdiv(nchunk, G);
+    hipLaunchKernelGGL(reduce_chunksA_kernel, dim3(cdiv(2 * N, 64), G), dim3(256), 0, s, part, tmp, nchunk, 2 * N, per);
+    hipLaunchKernelGGL(reduce_chunks2_kernel, dim3(cdiv(2L * N, 256)), dim3(256), 0, s, tmp, out0, out1, G, N, accumulate);
+  } else {
+    hipLaunchKernelGGL(reduce_chunks2_kernel, dim3(cdiv(2L * N, 256)), dim3(256), 0, s, part, out0, out1, nchunk, N,
+                       accumulate);
+  }
+}
+
 // column sums of a [M,N] matrix over row chunks (bias gradients): part[nchunk][N]
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long ldx,
                                                              float* __restrict__ part, int M, int N,
@@ -131,81 +171,6 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   if (sub == 0 && c < N) {
     const int l = threadIdx.x;
     part[(long)blockIdx.y * N + c] = sm[0][l] + sm[1][l] + sm[2][l] + sm[3][l];
-  }
-}
-
-// ------------------------------------------------------------------ GRU gate block
-// parts = LN_3D(pre) ; r = sig(parts[0:D]) ; c = tanh(r * parts[D:2D]) ; u = sig(parts[2D:3D] - 1)
-// h' = u*c + (1-u)*h          ref: GRUCell.forward, agent/dreamer_utils.py:771-785
-__global__ __launch_bounds__(256) void gru_gates_fwd_kernel(
-    const float* __restrict__ pre, const float* __restrict__ h, long ldh, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float* __restrict__ hout, long ldo, float* __restrict__ mean_out,
-    float* __restrict__ rstd_out, int R, int D, float eps) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= R) return;
-  const int N = 3 * D;
-  const float* xr = pre + (long)row * N;
-  float s = 0.f;
-  for (int j = lane; j < N; j += 64) s += xr[j];
-  const float mean = wave_sum(s) / N;
-  float v = 0.f;
-  for (int j = lane; j < N; j += 64) {
-    const float d = xr[j] - mean;
-    v += d * d;
-  }
-  const float rstd = 1.0f / sqrtf(wave_sum(v) / N + eps);
-  const float* hr = h + (long)row * ldh;
-  float* ho = hout + (long)row * ldo;
-  for (int j = lane; j < D; j += 64) {
-    const float pr = (xr[j] - mean) * rstd * gamma[j] + beta[j];
-    const float pc = (xr[D + j] - mean) * rstd * gamma[D + j] + beta[D + j];
-    const float pu = (xr[2 * D + j] - mean) * rstd * gamma[2 * D + j] + beta[2 * D + j];
-    const float r = sigmoidf_(pr);
-    const float c = tanhf(r * pc);
-    const float u = sigmoidf_(pu - 1.0f);
-    ho[j] = u * c + (1.0f - u) * hr[j];
-  }
-  if (lane == 0) {
-    mean_out[row] = mean;
-    rstd_out[row] = rstd;
-  }
-}
-
-// Backward of the gate block: writes dparts (gradient w.r.t. the *normalised* 3D vector, i.e. the
-// "dz" of the LayerNorm) and dh_direct.  The LayerNorm backward proper is then ln_act_bwd_* with
-// act = 0 on (dz = dparts, x = pre).
-__global__ __launch_bounds__(256) void gru_gates_bwd_kernel(
-    const float* __restrict__ dhout, long lddo, const float* __restrict__ pre, const float* __restrict__ h,
-    long ldh, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ mean_in, const float* __restrict__ rstd_in, float* __restrict__ dparts,
-    float* __restrict__ dh, long lddh, int R, int D, int dh_accumulate) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= R) return;
-  const int N = 3 * D;
-  const float* xr = pre + (long)row * N;
-  const float mean = mean_in[row], rstd = rstd_in[row];
-  const float* hr = h + (long)row * ldh;
-  const float* gr = dhout + (long)row * lddo;
-  float* dp = dparts + (long)row * N;
-  float* dhr = dh + (long)row * lddh;
-  for (int j = lane; j < D; j += 64) {
-    const float pr = (xr[j] - mean) * rstd * gamma[j] + beta[j];
-    const float pc = (xr[D + j] - mean) * rstd * gamma[D + j] + beta[D + j];
-    const float pu = (xr[2 * D + j] - mean) * rstd * gamma[2 * D + j] + beta[2 * D + j];
-    const float r = sigmoidf_(pr);
-    const float c = tanhf(r * pc);
-    const float u = sigmoidf_(pu - 1.0f);
-    const float g = gr[j];
-    const float du = g * (c - hr[j]);
-    const float dc = g * u;
-    const float drc = dc * (1.0f - c * c);
-    dp[j] = drc * pc * r * (1.0f - r);
-    dp[D + j] = drc * r;
-    dp[2 * D + j] = du * u * (1.0f - u);
-    const float d = g * (1.0f - u);
-    dhr[j] = dh_accumulate ? dhr[j] + d : d;
   }
 }
 
@@ -254,6 +219,360 @@ __global__ void copy2d_kernel(const float* __restrict__ src, long lds_, float* _
   *d = accumulate ? *d + v : v;
 }
 
+
+// ====================================================================== block-per-row fast paths
+// For the wide rows of this model (N = 1024 LayerNorms, 3*1024 GRU gate rows) one 256-thread
+// workgroup owns a row: the row lives in registers as float4s (one HBM/L2 read, 16-B coalesced
+// accesses), the two LayerNorm moments are block reductions (shuffles + 4 LDS words).  Backward
+// kernels also accumulate the dgamma/dbeta partial sums of the rows they own in registers and emit
+// one partial row per workgroup (reduced by reduce_chunks_kernel), so LayerNorm backward is one
+// pass over dy and x.
+struct Sum2 {
+  float a, b;
+};
+__device__ __forceinline__ Sum2 block_sum2_256(float a, float b, float* red /* >= 8 floats */) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) {
+    red[w] = a;
+    red[4 + w] = b;
+  }
+  __syncthreads();
+  Sum2 r;
+  r.a = red[0] + red[1] + red[2] + red[3];
+  r.b = red[4] + red[5] + red[6] + red[7];
+  return r;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_act_fwd_blk_kernel(const float* __restrict__ x, long ldx,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ y,
+                                                             long ldy, float* __restrict__ mean_out,
+                                                             float* __restrict__ rstd_out, int M, int N, float eps,
+                                                             int act) {
+  __shared__ float red[8];
+  const int nv = N >> 2;
+  for (int row = blockIdx.x; row < M; row += gridDim.x) {
+    const float4* xr = reinterpret_cast<const float4*>(x + (long)row * ldx);
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int j = threadIdx.x + i * 256;
+      v[i] = j < nv ? xr[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mean = block_sum2_256(s, 0.f, red).a / N;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int j = threadIdx.x + i * 256;
+      if (j < nv) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += a * a + b * b + c * c + d * d;
+      }
+    }
+    const float rstd = 1.0f / sqrtf(block_sum2_256(q, 0.f, red).a / N + eps);
+    float4* yr = reinterpret_cast<float4*>(y + (long)row * ldy);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int j = threadIdx.x + i * 256;
+      if (j < nv) {
+        const float4 g = reinterpret_cast<const float4*>(gamma)[j], b = reinterpret_cast<const float4*>(beta)[j];
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * g.x + b.x;
+        o.y = (v[i].y - mean) * rstd * g.y + b.y;
+        o.z = (v[i].z - mean) * rstd * g.z + b.z;
+        o.w = (v[i].w - mean) * rstd * g.w + b.w;
+        if (act) {
+          o.x = siluf_(o.x); o.y = siluf_(o.y); o.z = siluf_(o.z); o.w = siluf_(o.w);
+        }
+        yr[j] = o;
+      }
+    }
+    if (threadIdx.x == 0) {
+      mean_out[row] = mean;
+      rstd_out[row] = rstd;
+    }
+  }
+}
+
+// dx (may alias dy) + per-workgroup dgamma/dbeta partials: part[blockIdx.x][2][N] (if part != null)
+template <int NV>
+__global__ __launch_bounds__(256) void ln_act_bwd_blk_kernel(const float* dy, long lddy, const float* __restrict__ x,
+                                                             long ldx, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ mean_in,
+                                                             const float* __restrict__ rstd_in, float* dx, long lddx,
+                                                             float* __restrict__ part, int M, int N, int act) {
+  __shared__ float red[8];
+  const int nv = N >> 2;
+  float4 g[NV], b[NV], ag[NV], ab[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = threadIdx.x + i * 256;
+    g[i] = j < nv ? reinterpret_cast<const float4*>(gamma)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    b[i] = j < nv ? reinterpret_cast<const float4*>(beta)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int row = blockIdx.x; row < M; row += gridDim.x) {
+    const float4* xr = reinterpret_cast<const float4*>(x + (long)row * ldx);
+    const float4* dr = reinterpret_cast<const float4*>(dy + (long)row * lddy);
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float4 xh[NV], dz[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int j = threadIdx.x + i * 256;
+      if (j < nv) {
+        const float4 xv = xr[j];
+        float4 d = dr[j];
+        float4 h;
+        h.x = (xv.x - mean) * rstd; h.y = (xv.y - mean) * rstd; h.z = (xv.z - mean) * rstd; h.w = (xv.w - mean) * rstd;
+        if (act) {
+          d.x *= dsiluf_(h.x * g[i].x + b[i].x); d.y *= dsiluf_(h.y * g[i].y + b[i].y);
+          d.z *= dsiluf_(h.z * g[i].z + b[i].z); d.w *= dsiluf_(h.w * g[i].w + b[i].w);
+        }
+        xh[i] = h; dz[i] = d;
+        ag[i].x += d.x * h.x; ag[i].y += d.y * h.y; ag[i].z += d.z * h.z; ag[i].w += d.w * h.w;
+        ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+        const float e0 = d.x * g[i].x, e1 = d.y * g[i].y, e2 = d.z * g[i].z, e3 = d.w * g[i].w;
+        s1 += e0 + e1 + e2 + e3;
+        s2 += e0 * h.x + e1 * h.y + e2 * h.z + e3 * h.w;
+      } else {
+        xh[i] = make_float4(0.f, 0.f, 0.f, 0.f); dz[i] = xh[i];
+      }
+    }
+    const Sum2 r = block_sum2_256(s1, s2, red);
+    const float m1 = r.a / N, m2 = r.b / N;
+    if (dx) {
+      float4* dxr = reinterpret_cast<float4*>(dx + (long)row * lddx);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int j = threadIdx.x + i * 256;
+        if (j < nv) {
+          float4 o;
+          o.x = rstd * (dz[i].x * g[i].x - m1 - xh[i].x * m2);
+          o.y = rstd * (dz[i].y * g[i].y - m1 - xh[i].y * m2);
+          o.z = rstd * (dz[i].z * g[i].z - m1 - xh[i].z * m2);
+          o.w = rstd * (dz[i].w * g[i].w - m1 - xh[i].w * m2);
+          dxr[j] = o;
+        }
+      }
+    }
+  }
+  if (part) {
+    float4* pg = reinterpret_cast<float4*>(part + (long)blockIdx.x * 2 * N);
+    float4* pb = reinterpret_cast<float4*>(part + (long)blockIdx.x * 2 * N + N);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int j = threadIdx.x + i * 256;
+      if (j < nv) {
+        pg[j] = ag[i];
+        pb[j] = ab[i];
+      }
+    }
+  }
+}
+
+// GRU gate block, one workgroup per row, D = 4*256*DV at most; the 3D pre-activation row is read
+// once.  Thread t owns gate elements j in {4*(t+256*i)..+3}: r, c~ and u of the same j come from the
+// three D-sections, so no cross-thread traffic beyond the two LayerNorm moments.
+template <int DV>
+__global__ __launch_bounds__(256) void gru_gates_fwd_blk_kernel(
+    const float* __restrict__ pre, const float* __restrict__ h, long ldh, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ hout, long ldo, float* __restrict__ hout2,
+    const float* __restrict__ hout2_scale, float* __restrict__ mean_out, float* __restrict__ rstd_out, int R, int D,
+    float eps) {
+  __shared__ float red[8];
+  const int dv = D >> 2, N = 3 * D;
+  for (int row = blockIdx.x; row < R; row += gridDim.x) {
+    const float4* xr = reinterpret_cast<const float4*>(pre + (long)row * N);
+    float4 v[3][DV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < DV; ++i) {
+      const int j = threadIdx.x + i * 256;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        v[c][i] = j < dv ? xr[c * dv + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += v[c][i].x + v[c][i].y + v[c][i].z + v[c][i].w;
+      }
+    }
+    const float mean = block_sum2_256(s, 0.f, red).a / N;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < DV; ++i) {
+      const int j = threadIdx.x + i * 256;
+      if (j < dv) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float a = v[c][i].x - mean, b = v[c][i].y - mean, cc = v[c][i].z - mean, d = v[c][i].w - mean;
+          q += a * a + b * b + cc * cc + d * d;
+        }
+      }
+    }
+    const float rstd = 1.0f / sqrtf(block_sum2_256(q, 0.f, red).a / N + eps);
+    const float sc2 = (hout2 && hout2_scale) ? hout2_scale[row] : 1.0f;
+    const float4* hr = reinterpret_cast<const float4*>(h + (long)row * ldh);
+    float4* ho = reinterpret_cast<float4*>(hout + (long)row * ldo);
+#pragma unroll
+    for (int i = 0; i < DV; ++i) {
+      const int j = threadIdx.x + i * 256;
+      if (j < dv) {
+        const float4* g4 = reinterpret_cast<const float4*>(gamma);
+        const float4* b4 = reinterpret_cast<const float4*>(beta);
+        const float4 gr = g4[j], gc = g4[dv + j], gu = g4[2 * dv + j];
+        const float4 br = b4[j], bc = b4[dv + j], bu = b4[2 * dv + j];
+        const float4 hv = hr[j];
+        float4 o;
+#define GATE(f)                                                           \
+  {                                                                       \
+    const float pr = (v[0][i].f - mean) * rstd * gr.f + br.f;             \
+    const float pc = (v[1][i].f - mean) * rstd * gc.f + bc.f;             \
+    const float pu = (v[2][i].f - mean) * rstd * gu.f + bu.f;             \
+    const float r = sigmoidf_(pr), c = tanhf(r * pc), u = sigmoidf_(pu - 1.0f); \
+    o.f = u * c + (1.0f - u) * hv.f;                                      \
+  }
+        GATE(x) GATE(y) GATE(z) GATE(w)
+#undef GATE
+        ho[j] = o;
+        if (hout2) {
+          o.x *= sc2; o.y *= sc2; o.z *= sc2; o.w *= sc2;
+          reinterpret_cast<float4*>(hout2 + (long)row * D)[j] = o;
+        }
+      }
+    }
+    if (threadIdx.x == 0) {
+      mean_out[row] = mean;
+      rstd_out[row] = rstd;
+    }
+  }
+}
+
+// Backward of the gate block fused with the LayerNorm backward: writes dpre (gradient w.r.t. the
+// pre-LayerNorm projection), dh (direct path, times hmask) and per-workgroup dgamma/dbeta partials.
+template <int DV>
+__global__ __launch_bounds__(256) void gru_gates_bwd_blk_kernel(
+    const float* __restrict__ dhout, long lddo, const float* __restrict__ dhout2,
+    const float* __restrict__ dhout2_scale, const float* __restrict__ pre, const float* __restrict__ h, long ldh, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ mean_in, const float* __restrict__ rstd_in, float* __restrict__ dpre,
+    float* __restrict__ dh, long lddh, float* __restrict__ part, int R, int D) {
+  __shared__ float red[8];
+  const int dv = D >> 2, N = 3 * D;
+  float4 ag[3][DV], ab[3][DV];
+#pragma unroll
+  for (int i = 0; i < DV; ++i)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      ag[c][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      ab[c][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+  for (int row = blockIdx.x; row < R; row += gridDim.x) {
+    const float4* xr = reinterpret_cast<const float4*>(pre + (long)row * N);
+    const float4* hr = reinterpret_cast<const float4*>(h + (long)row * ldh);
+    const float4* gr_ = reinterpret_cast<const float4*>(dhout + (long)row * lddo);
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float4 xh[3][DV], dz[3][DV], gam[3][DV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < DV; ++i) {
+      const int j = threadIdx.x + i * 256;
+      if (j < dv) {
+        float4 xv[3], bb[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          xv[c] = xr[c * dv + j];
+          gam[c][i] = g4[c * dv + j];
+          bb[c] = b4[c * dv + j];
+        }
+        const float4 hv = hr[j];
+        float4 go = gr_[j];
+        if (dhout2) {
+          const float4 g2 = reinterpret_cast<const float4*>(dhout2 + (long)row * D)[j];
+          const float sc = dhout2_scale ? dhout2_scale[row] : 1.0f;
+          go.x += g2.x * sc; go.y += g2.y * sc; go.z += g2.z * sc; go.w += g2.w * sc;
+        }
+        float4 dd;
+#define GBWD(f)                                                                   \
+  {                                                                               \
+    const float hr_ = (xv[0].f - mean) * rstd, hc_ = (xv[1].f - mean) * rstd, hu_ = (xv[2].f - mean) * rstd; \
+    const float pr = hr_ * gam[0][i].f + bb[0].f, pc = hc_ * gam[1][i].f + bb[1].f, pu = hu_ * gam[2][i].f + bb[2].f; \
+    const float r = sigmoidf_(pr), c = tanhf(r * pc), u = sigmoidf_(pu - 1.0f);   \
+    const float g = go.f;                                                         \
+    const float du = g * (c - hv.f), drc = g * u * (1.0f - c * c);                \
+    xh[0][i].f = hr_; xh[1][i].f = hc_; xh[2][i].f = hu_;                         \
+    dz[0][i].f = drc * pc * r * (1.0f - r);                                       \
+    dz[1][i].f = drc * r;                                                         \
+    dz[2][i].f = du * u * (1.0f - u);                                             \
+    dd.f = g * (1.0f - u);                                                        \
+  }
+        GBWD(x) GBWD(y) GBWD(z) GBWD(w)
+#undef GBWD
+        reinterpret_cast<float4*>(dh + (long)row * lddh)[j] = dd;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float4 d = dz[c][i], hh = xh[c][i], gm = gam[c][i];
+          ag[c][i].x += d.x * hh.x; ag[c][i].y += d.y * hh.y; ag[c][i].z += d.z * hh.z; ag[c][i].w += d.w * hh.w;
+          ab[c][i].x += d.x; ab[c][i].y += d.y; ab[c][i].z += d.z; ab[c][i].w += d.w;
+          const float e0 = d.x * gm.x, e1 = d.y * gm.y, e2 = d.z * gm.z, e3 = d.w * gm.w;
+          s1 += e0 + e1 + e2 + e3;
+          s2 += e0 * hh.x + e1 * hh.y + e2 * hh.z + e3 * hh.w;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          xh[c][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          dz[c][i] = xh[c][i];
+          gam[c][i] = xh[c][i];
+        }
+      }
+    }
+    const Sum2 r = block_sum2_256(s1, s2, red);
+    const float m1 = r.a / N, m2 = r.b / N;
+    float4* dp = reinterpret_cast<float4*>(dpre + (long)row * N);
+#pragma unroll
+    for (int i = 0; i < DV; ++i) {
+      const int j = threadIdx.x + i * 256;
+      if (j < dv) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float4 o;
+          o.x = rstd * (dz[c][i].x * gam[c][i].x - m1 - xh[c][i].x * m2);
+          o.y = rstd * (dz[c][i].y * gam[c][i].y - m1 - xh[c][i].y * m2);
+          o.z = rstd * (dz[c][i].z * gam[c][i].z - m1 - xh[c][i].z * m2);
+          o.w = rstd * (dz[c][i].w * gam[c][i].w - m1 - xh[c][i].w * m2);
+          dp[c * dv + j] = o;
+        }
+      }
+    }
+  }
+  if (part) {
+    float4* pg = reinterpret_cast<float4*>(part + (long)blockIdx.x * 2 * N);
+    float4* pb = reinterpret_cast<float4*>(part + (long)blockIdx.x * 2 * N + N);
+#pragma unroll
+    for (int i = 0; i < DV; ++i) {
+      const int j = threadIdx.x + i * 256;
+      if (j < dv) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          pg[c * dv + j] = ag[c][i];
+          pb[c * dv + j] = ab[c][i];
+        }
+      }
+    }
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+constexpr int BLK_GRID = 512;   // workgroups of the block-per-row kernels (2 per CU); rows are grid-strided
+
 inline int chunks_for(int M) {
   int rc = 64;  // rows per chunk
   int n = cdiv(M, rc);
@@ -272,14 +591,30 @@ int genrl_ln_act_fwd(const float* x, long ldx, const float* gamma, const float* 
                      float* mean, float* rstd, int M, int N, float eps, int act, void* stream) {
   GENRL_ENTER();
   if (M <= 0) return GENRL_OK;
-  hipLaunchKernelGGL(ln_act_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma,
-                     beta, y, ldy, mean, rstd, M, N, eps, act);
+  hipStream_t s = (hipStream_t)stream;
+  const bool fast = N > 256 && N <= 4096 && (N & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && aligned16(x) &&
+                    aligned16(y) && aligned16(gamma) && aligned16(beta);
+  if (fast) {
+    const int grid = M < 4 * BLK_GRID ? M : 4 * BLK_GRID;
+    const int nv = cdiv(N, 1024);
+#define GO(NV) hipLaunchKernelGGL((ln_act_fwd_blk_kernel<NV>), dim3(grid), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, mean, rstd, M, N, eps, act)
+    if (nv == 1) GO(1); else if (nv == 2) GO(2); else if (nv == 3) GO(3); else GO(4);
+#undef GO
+  } else {
+    hipLaunchKernelGGL(ln_act_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, mean, rstd,
+                       M, N, eps, act);
+  }
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }
 
+static inline int blk_grid_for(int M) { return M < BLK_GRID ? M : BLK_GRID; }
+
 // workspace: >= genrl_ln_ws_floats(M, N) floats
-long genrl_ln_ws_floats(int M, int N) { return (long)(chunks_for(M) + 1) * 2 * N; }
+long genrl_ln_ws_floats(int M, int N) {
+  const int a = chunks_for(M), b = blk_grid_for(M);
+  return (long)((a > b ? a : b) + 16) * 2 * N;
+}
 
 int genrl_ln_act_bwd(const float* dy, long lddy, const float* x, long ldx, const float* gamma,
                      const float* beta, const float* mean, const float* rstd, float* dx, long lddx,
@@ -288,18 +623,26 @@ int genrl_ln_act_bwd(const float* dy, long lddy, const float* x, long ldx, const
   GENRL_ENTER();
   if (M <= 0) return GENRL_OK;
   hipStream_t s = (hipStream_t)stream;
+  const bool fast = N > 256 && N <= 4096 && (N & 3) == 0 && (lddy & 3) == 0 && (ldx & 3) == 0 &&
+                    (!dx || ((lddx & 3) == 0 && aligned16(dx))) && aligned16(dy) && aligned16(x) &&
+                    aligned16(gamma) && aligned16(beta) && (!dgamma || aligned16(ws));
+  if (fast) {
+    const int grid = blk_grid_for(M);
+    const int nv = cdiv(N, 1024);
+    float* part = dgamma ? ws : nullptr;
+#define GO(NV) hipLaunchKernelGGL((ln_act_bwd_blk_kernel<NV>), dim3(grid), dim3(256), 0, s, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, part, M, N, act)
+    if (nv == 1) GO(1); else if (nv == 2) GO(2); else if (nv == 3) GO(3); else GO(4);
+#undef GO
+    if (dgamma) reduce_params(ws, ws + (long)grid * 2 * N, dgamma, dbeta, grid, N, accumulate_params, s);
+    GENRL_CHECK_LAUNCH();
+    return GENRL_OK;
+  }
   if (dgamma) {
     const int nchunk = chunks_for(M);
     const int rpc = cdiv(M, nchunk);
     hipLaunchKernelGGL(ln_act_bwd_params_kernel, dim3(cdiv(N, 64), nchunk), dim3(256), 0, s, dy, lddy, x, ldx,
                        gamma, beta, mean, rstd, ws, M, N, act, rpc);
-    // ws layout [nchunk][2][N]; dgamma and dbeta may be non-adjacent -> two strided reductions
-    hipLaunchKernelGGL(reduce_chunks_kernel, dim3(cdiv(2L * N, 256)), dim3(256), 0, s, ws, ws + (long)nchunk * 2 * N,
-                       nchunk, 2L * N, 0);
-    hipLaunchKernelGGL(copy2d_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, ws + (long)nchunk * 2 * N, (long)N, dgamma,
-                       (long)N, 1L, N, (const float*)nullptr, accumulate_params);
-    hipLaunchKernelGGL(copy2d_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, ws + (long)nchunk * 2 * N + N, (long)N,
-                       dbeta, (long)N, 1L, N, (const float*)nullptr, accumulate_params);
+    reduce_params(ws, ws + (long)nchunk * 2 * N, dgamma, dbeta, nchunk, N, accumulate_params, s);
   }
   if (dx)
     hipLaunchKernelGGL(ln_act_bwd_dx_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, dy, lddy, x, ldx, gamma, beta, mean,
@@ -321,30 +664,52 @@ int genrl_colsum(const float* x, long ldx, float* out, float* ws, int M, int N, 
   return GENRL_OK;
 }
 
+// h' = GRU gates(LN(pre), h).  Optionally also writes hout2[R,D] = h' * hout2_scale[row] (the next
+// step's is_first-reset state of a sequence scan; scale may be NULL = 1).  D % 4 == 0, D <= 4096.
 int genrl_gru_gates_fwd(const float* pre, const float* h, long ldh, const float* gamma, const float* beta,
-                        float* hout, long ldo, float* mean, float* rstd, int R, int D, float eps, void* stream) {
+                        float* hout, long ldo, float* hout2, const float* hout2_scale, float* mean, float* rstd,
+                        int R, int D, float eps, void* stream) {
   GENRL_ENTER();
   if (R <= 0) return GENRL_OK;
-  hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, pre, h, ldh, gamma,
-                     beta, hout, ldo, mean, rstd, R, D, eps);
+  if ((D & 3) || D > 4096 || (ldh & 3) || (ldo & 3) || !aligned16(pre) || !aligned16(h) || !aligned16(hout) ||
+      !aligned16(gamma) || !aligned16(beta) || (hout2 && !aligned16(hout2)))
+    return GENRL_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = R < 4 * BLK_GRID ? R : 4 * BLK_GRID;
+  const int dvn = cdiv(D, 1024);
+#define GO(DV) hipLaunchKernelGGL((gru_gates_fwd_blk_kernel<DV>), dim3(grid), dim3(256), 0, s, pre, h, ldh, gamma, beta, hout, ldo, hout2, hout2_scale, mean, rstd, R, D, eps)
+  if (dvn == 1) GO(1); else if (dvn == 2) GO(2); else if (dvn == 3) GO(3); else GO(4);
+#undef GO
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }
 
-// dpre[R,3D] receives the gradient w.r.t. the pre-LayerNorm GRU projection; dh the direct path.
-// ws >= genrl_ln_ws_floats(R, 3D) + 2*3D floats.
-int genrl_gru_gates_bwd(const float* dhout, long lddo, const float* pre, const float* h, long ldh,
-                        const float* gamma, const float* beta, const float* mean, const float* rstd,
-                        float* dpre, float* dh, long lddh, float* dgamma, float* dbeta, float* ws, int R, int D,
-                        int dh_accumulate, int accumulate_params, void* stream) {
+long genrl_gru_ws_floats(int R, int D) { return (long)(blk_grid_for(R) + 16) * 2 * 3 * D; }
+
+// Backward of the gate block *including* its LayerNorm: dpre[R,3D] is the gradient w.r.t. the
+// pre-LayerNorm projection, dh[R,D] the direct path to the (masked) previous state.  The upstream
+// gradient is dhout + dhout2 * dhout2_scale[row] (dhout2 / its scale may be NULL): the recurrent
+// term of a sequence scan.  `h` is the masked state used in the forward (hm_out).
+int genrl_gru_gates_bwd(const float* dhout, long lddo, const float* dhout2, const float* dhout2_scale,
+                        const float* pre, const float* h, long ldh, const float* gamma, const float* beta,
+                        const float* mean, const float* rstd, float* dpre, float* dh, long lddh, float* dgamma,
+                        float* dbeta, float* ws, int R, int D, int accumulate_params, void* stream) {
   GENRL_ENTER();
   if (R <= 0) return GENRL_OK;
+  if ((D & 3) || D > 4096 || (ldh & 3) || (lddo & 3) || (lddh & 3) || !aligned16(pre) || !aligned16(h) ||
+      !aligned16(dhout) || !aligned16(dpre) || !aligned16(dh) || (dhout2 && !aligned16(dhout2)) ||
+      (dgamma && !aligned16(ws)))
+    return GENRL_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, dhout, lddo, pre, h, ldh, gamma, beta,
-                     mean, rstd, dpre, dh, lddh, R, D, dh_accumulate);
+  const int grid = blk_grid_for(R);
+  const int dvn = cdiv(D, 1024);
+  float* part = dgamma ? ws : nullptr;
+#define GO(DV) hipLaunchKernelGGL((gru_gates_bwd_blk_kernel<DV>), dim3(grid), dim3(256), 0, s, dhout, lddo, dhout2, dhout2_scale, pre, h, ldh, gamma, beta, mean, rstd, dpre, dh, lddh, part, R, D)
+  if (dvn == 1) GO(1); else if (dvn == 2) GO(2); else if (dvn == 3) GO(3); else GO(4);
+#undef GO
+  if (dgamma) reduce_params(ws, ws + (long)grid * 6 * D, dgamma, dbeta, grid, 3 * D, accumulate_params, s);
   GENRL_CHECK_LAUNCH();
-  return genrl_ln_act_bwd(dpre, 3L * D, pre, 3L * D, gamma, beta, mean, rstd, dpre, 3L * D, dgamma, dbeta, ws, R, 3 * D,
-                          0, accumulate_params, stream);
+  return GENRL_OK;
 }
 
 int genrl_actor_head_fwd(const float* raw, const float* eps, float* action, float* mean, float* std, long R, int A,

@@ -162,8 +162,8 @@ class _LNAct(Function):
         dy2 = dy.reshape(M, N).contiguous()
         need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
-        dg = torch.empty(N, device=dy.device) if need_p else None
-        db = torch.empty(N, device=dy.device) if need_p else None
+        gb = torch.empty(2, N, device=dy.device) if need_p else None
+        dg, db = (gb[0], gb[1]) if need_p else (None, None)
         ws = _ws(lib().genrl_ln_ws_floats(M, N), dy.device) if need_p else None
         check(lib().genrl_ln_act_bwd(_p(dy2), N, _p(x2), N, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dx), N,
                                      _p(dg), _p(db), _p(ws), M, N, ctx.act, 0, _stream()), 'ln_act_bwd')
@@ -176,6 +176,18 @@ def ln_act(x, gamma, beta, eps=1e-5, act=True):
 
 # ------------------------------------------------------------------ GRU gates
 
+def _gru_fwd_raw(pre_ptr, h_ptr, gamma, beta, out_ptr, out2_ptr, scale2_ptr, mean_ptr, rstd_ptr, R, D):
+    check(lib().genrl_gru_gates_fwd(pre_ptr, h_ptr, D, _p(gamma), _p(beta), out_ptr, D, out2_ptr, scale2_ptr, mean_ptr,
+                                    rstd_ptr, R, D, 1e-5, _stream()), 'gru_gates_fwd')
+
+
+def _gru_bwd_raw(dout_ptr, dout2_ptr, scale2_ptr, pre_ptr, h_ptr, gamma, beta, mean_ptr, rstd_ptr, dpre_ptr, dh_ptr,
+                 dg, db, ws, R, D, accumulate):
+    check(lib().genrl_gru_gates_bwd(dout_ptr, D, dout2_ptr, scale2_ptr, pre_ptr, h_ptr, D, _p(gamma), _p(beta),
+                                    mean_ptr, rstd_ptr, dpre_ptr, dh_ptr, D, _p(dg), _p(db), _p(ws), R, D,
+                                    int(accumulate), _stream()), 'gru_gates_bwd')
+
+
 class _GRUGates(Function):
     @staticmethod
     def forward(ctx, pre, h, gamma, beta):
@@ -183,8 +195,7 @@ class _GRUGates(Function):
         R, D = h.shape
         out = torch.empty_like(h)
         mean = torch.empty(R, device=h.device); rstd = torch.empty(R, device=h.device)
-        check(lib().genrl_gru_gates_fwd(_p(pre), _p(h), D, _p(gamma), _p(beta), _p(out), D, _p(mean), _p(rstd), R, D,
-                                        1e-5, _stream()), 'gru_gates_fwd')
+        _gru_fwd_raw(_p(pre), _p(h), gamma, beta, _p(out), None, None, _p(mean), _p(rstd), R, D)
         ctx.save_for_backward(pre, h, gamma, beta, mean, rstd)
         return out
 
@@ -195,13 +206,11 @@ class _GRUGates(Function):
         dout = dout.contiguous()
         dpre = torch.empty_like(pre); dh = torch.empty_like(h)
         need_p = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
-        dg = torch.empty(3 * D, device=h.device) if need_p else None
-        db = torch.empty(3 * D, device=h.device) if need_p else None
-        ws = _ws(lib().genrl_ln_ws_floats(R, 3 * D), h.device) if need_p else None
-        check(lib().genrl_gru_gates_bwd(_p(dout), D, _p(pre), _p(h), D, _p(gamma), _p(beta), _p(mean), _p(rstd),
-                                        _p(dpre), _p(dh), D, _p(dg), _p(db), _p(ws), R, D, 0, 0, _stream()),
-              'gru_gates_bwd')
-        return dpre, dh, dg, db
+        gb = torch.empty(2, 3 * D, device=h.device) if need_p else None
+        ws = _ws(lib().genrl_gru_ws_floats(R, D), h.device) if need_p else None
+        _gru_bwd_raw(_p(dout), None, None, _p(pre), _p(h), gamma, beta, _p(mean), _p(rstd), _p(dpre), _p(dh),
+                     gb[0] if need_p else None, gb[1] if need_p else None, ws, R, D, False)
+        return dpre, dh, (gb[0] if need_p else None), (gb[1] if need_p else None)
 
 
 def gru_gates(pre, h, gamma, beta):
@@ -467,31 +476,31 @@ def _col2im(cols, bias, Nimg, Ha, Wa, C, k, Ho=0, Wo=0, nchw=False):
 
 
 class _Conv2dS2(Function):
-    """nn.Conv2d(k, stride 2).  x: f32 NHWC (N,H,W,C) or u8 NCHW (N,C,H,W) [preprocess fused];
-    W (Co,Ci,k,k); returns NHWC (N,Ho,Wo,Co)."""
+    """nn.Conv2d(k, stride 2) as patch-gather + GEMM.  x: f32 NHWC (N,H,W,C) or u8 NCHW (N,C,H,W)
+    [preprocess fused]; Wp (Co, k*k*Ci) = weight permuted to (co, kh, kw, ci); returns NHWC."""
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, Wp, b, k):
         u8 = x.dtype == torch.uint8
         x = x.contiguous()
         if u8:
             Nimg, C, Hi, Wi = x.shape
         else:
             Nimg, Hi, Wi, C = x.shape
-        Co, _, k, _ = W.shape
+        Co = Wp.shape[0]
         cols = _im2col(x, Nimg, Hi, Wi, C, k, 2 if u8 else 0)
         M, K = cols.shape
         y = torch.empty(M, Co, device=x.device)
-        sgemm(cols, K, 1, W, K, 1, y, Co, b, M, Co, K)
-        ctx.save_for_backward(x, W)
+        sgemm(cols, K, 1, Wp, K, 1, y, Co, b, M, Co, K)
+        ctx.save_for_backward(x, Wp)
         ctx.dims = (Nimg, Hi, Wi, C, k, u8)
         Ho, Wo = (Hi - k) // 2 + 1, (Wi - k) // 2 + 1
         return y.reshape(Nimg, Ho, Wo, Co)
 
     @staticmethod
     def backward(ctx, dy):
-        x, W = ctx.saved_tensors
+        x, Wp = ctx.saved_tensors
         Nimg, Hi, Wi, C, k, u8 = ctx.dims
-        Co = W.shape[0]
+        Co = Wp.shape[0]
         K = C * k * k
         Ho, Wo = (Hi - k) // 2 + 1, (Wi - k) // 2 + 1
         M = Nimg * Ho * Wo
@@ -501,39 +510,44 @@ class _Conv2dS2(Function):
             cols = _im2col(x, Nimg, Hi, Wi, C, k, 2 if u8 else 0)     # recomputed, not stored
             dW = torch.empty(Co, K, device=dy.device)
             sgemm(dy2, 1, Co, cols, 1, K, dW, K, None, Co, K, M)
-            dW = dW.reshape(W.shape)
             del cols
         if ctx.needs_input_grad[2]:
             db = colsum(dy2)
         if (not u8) and ctx.needs_input_grad[0]:
             dcols = torch.empty(M, K, device=dy.device)
-            sgemm(dy2, Co, 1, W, 1, K, dcols, K, None, M, K, Co)      # dcols = dy W
+            sgemm(dy2, Co, 1, Wp, 1, K, dcols, K, None, M, K, Co)     # dcols = dy W
             dx = _col2im(dcols, None, Nimg, Ho, Wo, C, k, Hi, Wi)
-        return dx, dW, db
+        return dx, dW, db, None
 
 
 def conv2d_s2(x, W, b):
-    return _Conv2dS2.apply(x, W, b)
+    """W (Co,Ci,k,k) in the reference layout; permuted per call to (Co, kh*kw*Ci) (gradient flows back
+    through the permute)."""
+    Co, Ci, k, _ = W.shape
+    Wp = transpose_last2(W.reshape(Co, Ci, k * k)).reshape(Co, k * k * Ci)
+    return _Conv2dS2.apply(x, Wp, b, k)
 
 
 class _ConvT2dS2(Function):
-    """nn.ConvTranspose2d(k, stride 2).  x NHWC (N,Hi,Wi,Ci); W (Ci,Co,k,k); returns NHWC."""
+    """nn.ConvTranspose2d(k, stride 2) as GEMM + gather-form col2im.  x NHWC (N,Hi,Wi,Ci);
+    Wp (Ci, k*k*Co) = weight permuted to (ci, kh, kw, co); returns NHWC."""
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, Wp, b, k):
         x = _f32(x).contiguous()
         Nimg, Hi, Wi, Ci = x.shape
-        _, Co, k, _ = W.shape
-        M, Nw = Nimg * Hi * Wi, Co * k * k
+        Nw = Wp.shape[1]
+        Co = Nw // (k * k)
+        M = Nimg * Hi * Wi
         cols = torch.empty(M, Nw, device=x.device)
-        sgemm(x, Ci, 1, W, 1, Nw, cols, Nw, None, M, Nw, Ci)          # cols = x W
+        sgemm(x, Ci, 1, Wp, 1, Nw, cols, Nw, None, M, Nw, Ci)         # cols = x W
         y = _col2im(cols, b, Nimg, Hi, Wi, Co, k)
-        ctx.save_for_backward(x, W)
+        ctx.save_for_backward(x, Wp)
         ctx.dims = (Nimg, Hi, Wi, Ci, Co, k)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, W = ctx.saved_tensors
+        x, Wp = ctx.saved_tensors
         Nimg, Hi, Wi, Ci, Co, k = ctx.dims
         Ho, Wo = 2 * (Hi - 1) + k, 2 * (Wi - 1) + k
         M, Nw = Nimg * Hi * Wi, Co * k * k
@@ -542,19 +556,21 @@ class _ConvT2dS2(Function):
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, Ci, device=dy.device)
-            sgemm(dcols, Nw, 1, W, Nw, 1, dx, Ci, None, M, Ci, Nw)    # dx = dcols W^T
+            sgemm(dcols, Nw, 1, Wp, Nw, 1, dx, Ci, None, M, Ci, Nw)   # dx = dcols W^T
             dx = dx.reshape(Nimg, Hi, Wi, Ci)
         if ctx.needs_input_grad[1]:
             dW = torch.empty(Ci, Nw, device=dy.device)
             sgemm(x, 1, Ci, dcols, 1, Nw, dW, Nw, None, Ci, Nw, M)    # dW = x^T dcols
-            dW = dW.reshape(W.shape)
         if ctx.needs_input_grad[2]:
             db = colsum(dy.reshape(-1, Co))
-        return dx, dW, db
+        return dx, dW, db, None
 
 
 def convT2d_s2(x, W, b):
-    return _ConvT2dS2.apply(x, W, b)
+    """W (Ci,Co,k,k) in the reference layout; permuted per call to (Ci, kh*kw*Co)."""
+    Ci, Co, k, _ = W.shape
+    Wp = transpose_last2(W.reshape(Ci, Co, k * k)).reshape(Ci, k * k * Co)
+    return _ConvT2dS2.apply(x, Wp, b, k)
 
 
 class _TransposeLast2(Function):
@@ -653,8 +669,7 @@ class _GRUStep(Function):
         sgemm(h, D, 1, W, K, 1, pre, 3 * D, None, R, 3 * D, D, accumulate=True, b_off=I)
         out = torch.empty_like(h)
         mean = torch.empty(R, device=x.device); rstd = torch.empty(R, device=x.device)
-        check(lib().genrl_gru_gates_fwd(_p(pre), _p(h), D, _p(gamma), _p(beta), _p(out), D, _p(mean), _p(rstd), R, D,
-                                        1e-5, _stream()), 'gru_gates_fwd')
+        _gru_fwd_raw(_p(pre), _p(h), gamma, beta, _p(out), None, None, _p(mean), _p(rstd), R, D)
         ctx.save_for_backward(x, h, W, gamma, beta, pre, mean, rstd)
         return out
 
@@ -667,12 +682,10 @@ class _GRUStep(Function):
         dout = dout.contiguous()
         dpre = torch.empty_like(pre); dh = torch.empty_like(h)
         need_p = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
-        dg = torch.empty(3 * D, device=h.device) if need_p else None
-        db = torch.empty(3 * D, device=h.device) if need_p else None
-        ws = _ws(lib().genrl_ln_ws_floats(R, 3 * D), h.device) if need_p else None
-        check(lib().genrl_gru_gates_bwd(_p(dout), D, _p(pre), _p(h), D, _p(gamma), _p(beta), _p(mean), _p(rstd),
-                                        _p(dpre), _p(dh), D, _p(dg), _p(db), _p(ws), R, D, 0, 0, _stream()),
-              'gru_gates_bwd')
+        gb = torch.empty(2, 3 * D, device=h.device) if need_p else None
+        ws = _ws(lib().genrl_gru_ws_floats(R, D), h.device) if need_p else None
+        _gru_bwd_raw(_p(dout), None, None, _p(pre), _p(h), gamma, beta, _p(mean), _p(rstd), _p(dpre), _p(dh),
+                     gb[0] if need_p else None, gb[1] if need_p else None, ws, R, D, False)
         dx = dW = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -685,7 +698,7 @@ class _GRUStep(Function):
             dW = torch.empty(3 * D, K, device=h.device)
             sgemm(dpre, 1, 3 * D, x, 1, I, dW, K, None, 3 * D, I, R)
             sgemm(dpre, 1, 3 * D, h, 1, D, dW, K, None, 3 * D, D, R, c_off=I)
-        return dx, dh, dW, dg, db
+        return dx, dh, dW, (gb[0] if need_p else None), (gb[1] if need_p else None)
 
 
 def gru_step(x, h, W, gamma, beta):
@@ -695,8 +708,9 @@ def gru_step(x, h, W, gamma, beta):
 class _GRUSeq(Function):
     """The whole GRU recurrence of EnsembleRSSM.observe / VideoSSM.update over T steps with the
     non-recurrent half hoisted: pre_x = x W_x^T for all T at once; per step only
-    h_{t-1} W_h^T (+ LayerNorm + gates) is sequential.  x (T,B,I); mask (T,B) multiplies h_{t-1}
-    (is_first reset, agent/dreamer_utils.py:433-434) or None; h0 (B,D).  Returns deter (T,B,D)."""
+    h_{t-1} W_h^T (+ LayerNorm + gates) is sequential: two launches per step.  x (T,B,I); mask (T,B)
+    multiplies h_{t-1} (is_first reset, agent/dreamer_utils.py:433-434) or None; h0 (B,D).
+    Returns deter (T,B,D)."""
     @staticmethod
     def forward(ctx, x, mask, h0, W, gamma, beta):
         x = _f32(x).contiguous()
@@ -706,61 +720,81 @@ class _GRUSeq(Function):
         dev = x.device
         pre = torch.empty(T, B, 3 * D, device=dev)
         sgemm(x, I, 1, W, K, 1, pre, 3 * D, None, T * B, 3 * D, I)
-        hm = torch.empty(T, B, D, device=dev)           # masked previous state per step
         out = torch.empty(T, B, D, device=dev)
         mean = torch.empty(T, B, device=dev); rstd = torch.empty(T, B, device=dev)
-        L = lib(); s = _stream()
         h0 = _f32(h0).contiguous()
+        if mask is not None:
+            mask = mask.contiguous()
+            hm = torch.empty(T, B, D, device=dev)       # masked previous state of every step
+            copy2d(h0, D, hm, D, B, D, mask[0])
+        else:
+            hm = None
+        BD, B3D = B * D, B * 3 * D
         for t in range(T):
-            src, soff = (h0, 0) if t == 0 else (out, (t - 1) * B * D)
-            check(L.genrl_copy2d(src.data_ptr() + 4 * soff, D, hm.data_ptr() + 4 * t * B * D, D, B, D,
-                                 (mask.data_ptr() + 4 * t * B) if mask is not None else None, 0, s), 'copy2d')
-            sgemm(hm, D, 1, W, K, 1, pre, 3 * D, None, B, 3 * D, D, accumulate=True, a_off=t * B * D, b_off=I,
-                  c_off=t * B * 3 * D)
-            check(L.genrl_gru_gates_fwd(pre.data_ptr() + 4 * t * B * 3 * D, hm.data_ptr() + 4 * t * B * D, D, _p(gamma),
-                                        _p(beta), out.data_ptr() + 4 * t * B * D, D, mean.data_ptr() + 4 * t * B,
-                                        rstd.data_ptr() + 4 * t * B, B, D, 1e-5, s), 'gru_gates_fwd')
-        ctx.save_for_backward(x, mask if mask is not None else x.new_empty(0), W, gamma, beta, pre, hm, mean, rstd)
+            if hm is not None:
+                hprev, hoff = hm, t * BD
+            else:
+                hprev, hoff = (h0, 0) if t == 0 else (out, (t - 1) * BD)
+            sgemm(hprev, D, 1, W, K, 1, pre, 3 * D, None, B, 3 * D, D, accumulate=True, a_off=hoff, b_off=I,
+                  c_off=t * B3D)
+            nxt = hm is not None and t + 1 < T
+            _gru_fwd_raw(pre.data_ptr() + 4 * t * B3D, hprev.data_ptr() + 4 * hoff, gamma, beta,
+                         out.data_ptr() + 4 * t * BD, (hm.data_ptr() + 4 * (t + 1) * BD) if nxt else None,
+                         (mask.data_ptr() + 4 * (t + 1) * B) if nxt else None,
+                         mean.data_ptr() + 4 * t * B, rstd.data_ptr() + 4 * t * B, B, D)
+        ctx.save_for_backward(x, mask if mask is not None else x.new_empty(0), h0, W, gamma, beta, pre, out,
+                              hm if hm is not None else x.new_empty(0), mean, rstd)
         ctx.has_mask = mask is not None
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, mask, W, gamma, beta, pre, hm, mean, rstd = ctx.saved_tensors
+        x, mask, h0, W, gamma, beta, pre, out, hm, mean, rstd = ctx.saved_tensors
         T, B, I = x.shape
-        D = hm.shape[2]
+        D = out.shape[2]
         K = I + D
         dev = x.device
         dout = dout.contiguous()
         dpre = torch.empty_like(pre)
-        dh = torch.zeros(B, D, device=dev)               # gradient flowing into h_{t} from step t+1
-        dhm = torch.empty(B, D, device=dev)
-        gsum = torch.empty(B, D, device=dev)
-        dg = torch.zeros(3 * D, device=dev); db = torch.zeros(3 * D, device=dev)
-        ws = _ws(lib().genrl_ln_ws_floats(B, 3 * D), dev)
-        L = lib(); s = _stream()
+        dha = torch.empty(B, D, device=dev); dhb = torch.empty(B, D, device=dev)   # ping-pong d(hm_t)
+        gb = torch.zeros(2, 3 * D, device=dev)
+        ws = _ws(lib().genrl_gru_ws_floats(B, D), dev)
+        BD, B3D = B * D, B * 3 * D
+        cur, nxt = dha, None
         for t in range(T - 1, -1, -1):
-            # total gradient on h_t = external + recurrent
-            check(L.genrl_copy2d(dout.data_ptr() + 4 * t * B * D, D, gsum.data_ptr(), D, B, D, None, 0, s), 'copy2d')
-            check(L.genrl_copy2d(dh.data_ptr(), D, gsum.data_ptr(), D, B, D, None, 1, s), 'copy2d')
-            check(L.genrl_gru_gates_bwd(gsum.data_ptr(), D, pre.data_ptr() + 4 * t * B * 3 * D,
-                                        hm.data_ptr() + 4 * t * B * D, D, _p(gamma), _p(beta),
-                                        mean.data_ptr() + 4 * t * B, rstd.data_ptr() + 4 * t * B,
-                                        dpre.data_ptr() + 4 * t * B * 3 * D, dhm.data_ptr(), D, _p(dg), _p(db), _p(ws),
-                                        B, D, 0, 1, s), 'gru_gates_bwd')
-            sgemm(dpre, 3 * D, 1, W, 1, K, dhm, D, None, B, D, 3 * D, accumulate=True, a_off=t * B * 3 * D, b_off=I)
-            check(L.genrl_copy2d(dhm.data_ptr(), D, dh.data_ptr(), D, B, D,
-                                 (mask.data_ptr() + 4 * t * B) if ctx.has_mask else None, 0, s), 'copy2d')
-        dx = dW = None
+            if ctx.has_mask:
+                hprev, hoff = hm, t * BD
+            else:
+                hprev, hoff = (h0, 0) if t == 0 else (out, (t - 1) * BD)
+            # upstream = dout[t] + d(hm_{t+1}) * mask[t+1]
+            _gru_bwd_raw(dout.data_ptr() + 4 * t * BD, nxt.data_ptr() if nxt is not None else None,
+                         (mask.data_ptr() + 4 * (t + 1) * B) if (nxt is not None and ctx.has_mask) else None,
+                         pre.data_ptr() + 4 * t * B3D, hprev.data_ptr() + 4 * hoff, gamma, beta,
+                         mean.data_ptr() + 4 * t * B, rstd.data_ptr() + 4 * t * B, dpre.data_ptr() + 4 * t * B3D,
+                         cur.data_ptr(), gb[0], gb[1], ws, B, D, True)
+            sgemm(dpre, 3 * D, 1, W, 1, K, cur, D, None, B, D, 3 * D, accumulate=True, a_off=t * B3D, b_off=I)
+            nxt, cur = cur, (dhb if cur is dha else dha)
+        dx = dW = dh0 = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             sgemm(dpre, 3 * D, 1, W, 1, K, dx, I, None, T * B, I, 3 * D)
         if ctx.needs_input_grad[3]:
             dW = torch.empty(3 * D, K, device=dev)
             sgemm(dpre, 1, 3 * D, x, 1, I, dW, K, None, 3 * D, I, T * B)
-            sgemm(dpre, 1, 3 * D, hm, 1, D, dW, K, None, 3 * D, D, T * B, c_off=I)
-        dh0 = dh if ctx.needs_input_grad[2] else None
-        return dx, None, dh0, dW, dg, db
+            if ctx.has_mask:
+                sgemm(dpre, 1, 3 * D, hm, 1, D, dW, K, None, 3 * D, D, T * B, c_off=I)
+            else:   # h_{t-1} = [h0, out[:-1]]
+                sgemm(dpre, 1, 3 * D, h0, 1, D, dW, K, None, 3 * D, D, B, c_off=I)
+                if T > 1:
+                    ws2 = dW.new_empty(0)
+                    nws = lib().genrl_sgemm_ws_floats(3 * D, D, (T - 1) * B)
+                    ws2 = torch.empty(nws, device=dev) if nws > 0 else None
+                    check(lib().genrl_sgemm(dpre.data_ptr() + 4 * B3D, 1, 3 * D, out.data_ptr(), 1, D,
+                                            dW.data_ptr() + 4 * I, K, None, 3 * D, D, (T - 1) * B, 1, _p(ws2), nws,
+                                            _stream()), 'sgemm')
+        if ctx.needs_input_grad[2]:
+            dh0 = nxt * mask[0].unsqueeze(-1) if ctx.has_mask else nxt.clone()
+        return dx, None, dh0, dW, gb[0], gb[1]
 
 
 def gru_seq(x, mask, h0, W, gamma, beta):

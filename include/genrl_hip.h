@@ -40,13 +40,17 @@ int genrl_ln_act_bwd(const float* dy, long lddy, const float* x, long ldx, const
 long genrl_colsum_ws_floats(int M, int N);
 int genrl_colsum(const float* x, long ldx, float* out, float* ws, int M, int N, int accumulate, void* stream);
 
-/* ---- GRU gate block: GRUCell.forward after the projection (agent/dreamer_utils.py:778-785) */
-int genrl_gru_gates_fwd(const float* pre, const float* h, long ldh, const float* gamma, const float* beta, float* hout,
-                        long ldo, float* mean, float* rstd, int R, int D, float eps, void* stream);
-int genrl_gru_gates_bwd(const float* dhout, long lddo, const float* pre, const float* h, long ldh, const float* gamma,
-                        const float* beta, const float* mean, const float* rstd, float* dpre, float* dh, long lddh,
-                        float* dgamma, float* dbeta, float* ws, int R, int D, int dh_accumulate, int accumulate_params,
-                        void* stream);
+/* ---- GRU gate block: GRUCell.forward after the projection (agent/dreamer_utils.py:778-785), with the
+ * is_first reset of the next step's previous state (:433-434) fused as a scaled second output; the
+ * backward includes the LayerNorm backward and the recurrent-gradient add of a sequence scan. */
+int genrl_gru_gates_fwd(const float* pre, const float* h, long ldh, const float* gamma, const float* beta,
+                        float* hout, long ldo, float* hout2, const float* hout2_scale, float* mean, float* rstd,
+                        int R, int D, float eps, void* stream);
+long genrl_gru_ws_floats(int R, int D);
+int genrl_gru_gates_bwd(const float* dhout, long lddo, const float* dhout2, const float* dhout2_scale,
+                        const float* pre, const float* h, long ldh, const float* gamma, const float* beta,
+                        const float* mean, const float* rstd, float* dpre, float* dh, long lddh, float* dgamma,
+                        float* dbeta, float* ws, int R, int D, int accumulate_params, void* stream);
 
 /* ---- actor Normal head: DistLayer 'normal' + rsample (agent/dreamer_utils.py:814-819) */
 int genrl_actor_head_fwd(const float* raw, const float* eps, float* action, float* mean, float* std, long R, int A,

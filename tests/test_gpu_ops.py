@@ -87,6 +87,31 @@ def test_gru_gates(ops, R, D):
     compare(ops.gru_gates, ref, [pre, h, ga, be], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize('T,B,I,D,masked', [(5, 3, 8, 12, True), (4, 32, 64, 1024, True), (6, 2, 16, 32, False)])
+def test_gru_seq_and_step(ops, T, B, I, D, masked):
+    x = torch.randn(T, B, I, generator=g(1)); h0 = torch.randn(B, D, generator=g(2))
+    W = torch.randn(3 * D, I + D, generator=g(3)) / (I + D) ** .5
+    ga = 1 + 0.1 * torch.randn(3 * D, generator=g(4)); be = 0.1 * torch.randn(3 * D, generator=g(5))
+    mask = (torch.rand(T, B, generator=g(6)) > 0.3).float() if masked else None
+
+    def cell(x, h, W, ga, be):
+        parts = F.layer_norm(F.linear(torch.cat([x, h], -1), W), (3 * D,), ga, be, 1e-5)
+        r, c, u = torch.chunk(parts, 3, -1)
+        r = torch.sigmoid(r); c = torch.tanh(r * c); u = torch.sigmoid(u - 1.0)
+        return u * c + (1 - u) * h
+
+    def ref(x, h0, W, ga, be):
+        h, outs = h0, []
+        for t in range(T):
+            if mask is not None:
+                h = h * mask[t][:, None]
+            h = cell(x[t], h, W, ga, be); outs.append(h)
+        return torch.stack(outs, 0)
+    compare(lambda x, h0, W, ga, be: ops.gru_seq(x, mask.cuda() if masked else None, h0, W, ga, be), ref,
+            [x, h0, W, ga, be], rtol=2e-4, atol=2e-5)
+    compare(ops.gru_step, cell, [x[0], h0, W, ga, be], rtol=2e-4, atol=2e-5)
+
+
 @pytest.mark.parametrize('R,S,K', [(9, 4, 4), (64, 32, 32), (5, 3, 7)])
 def test_onehot_and_kl(ops, R, S, K):
     lg = torch.randn(R, S, K, generator=g(1)) * 2; lq = torch.randn(R, S, K, generator=g(2)) * 2
