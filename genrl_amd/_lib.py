@@ -6,7 +6,7 @@ import ctypes, os, re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'genrl_hip.h')
-SO = os.path.join(HERE, 'libgenrl_hip.so')
+SO = os.environ.get('GENRL_HIP_SO', os.path.join(HERE, 'libgenrl_hip.so'))   # override: kernel experiments
 
 _CT = {'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float}
 

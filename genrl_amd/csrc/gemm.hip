@@ -13,14 +13,23 @@
 // gfx950 has no TF32/xf32 path, so this is the roofline the dense part of the GenRL hot path
 // is measured against (157.3 TFLOP/s).
 //
-// Tiling: 256 threads = 4 waves (2x2); block tile BMxBN, BK=16; each wave owns (BM/2)x(BN/2) as
-// TMxTN 32x32 MFMA tiles.  Operand tiles are staged in LDS k-major ([k][row]) so that a wave's
-// fragment read is two contiguous 32-float rows (conflict-free ds_read_b32); global->LDS goes
-// through registers with the next tile's loads issued before the MFMA loop (register double
-// buffer) and LDS double-buffered: one barrier per k-tile.  fp32 MFMA needs only one float per
-// operand per lane per 64-cycle instruction, so LDS bandwidth is a non-issue; what matters is
-// keeping >= 256 workgroups in flight (64x64 tiles for the M=1024 GEMMs of this path) and hiding
-// global latency.
+// Tiling.  A workgroup owns a BMxBN output tile and has KG "k-groups" of 4 waves (2x2 over the
+// tile, each wave TMxTN 32x32 MFMA tiles).  A BK-deep operand tile is staged in LDS k-major
+// ([k][row]: a wave's fragment read is two contiguous 32-float rows, conflict-free); k-group g
+// multiplies the g-th BK/KG slice of it into its own accumulators, and the KG partial tiles are
+// summed through LDS at the end.  Two shapes are instantiated:
+//   128x128, BK=16, KG=1 (256 threads)  - problems with >= 512 such tiles (M >= ~16K rows);
+//    64x 64, BK=64, KG=4 (1024 threads) - everything else.  The GEMMs of this workload are mostly
+//        M=N=1024 (256 tiles): one workgroup per CU; the 16 waves (4 per SIMD) are what hides the
+//        global->LDS latency, which a 4-wave workgroup per CU cannot (measured 26 -> 52 TF/s with
+//        a global split-K, which in turn costs a reduce pass; the in-workgroup k-groups do not).
+// Global->LDS goes through registers with the next tile's loads issued before the MFMA loop and
+// LDS double-buffered: one barrier per BK.  fp32 MFMA needs one float per operand per lane per
+// 64-cycle instruction, so LDS bandwidth is a non-issue; what matters is waves in flight.
+//
+// Split-K over blockIdx.y (deterministic two-pass through a caller workspace) remains for outputs
+// with very few tiles and long reductions (conv weight gradients: 1..54 tiles, K up to ~10^6; the
+// M=32 GEMMs of the observe scan).
 //
 // Workgroup -> tile mapping is XCD-aware: the dispatcher places block b on XCD b%8, so blocks are
 // remapped such that each XCD walks a contiguous range of tiles (neighbouring tiles share the A
@@ -29,18 +38,25 @@
 
 namespace {
 
-constexpr int BK = 16;
-
-template <int BM, int BN, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void sgemm_kernel(
+template <int BM, int BN, int BK, int KG, int PD, bool FAST, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256 * KG) void sgemm_kernel(
     const float* __restrict__ A, long a_ld, const float* __restrict__ B, long b_ld,
     float* __restrict__ C, long ldc, const float* __restrict__ bias, int M, int N, int Ktot,
     int accumulate, int a_vec, int b_vec, int tiles_n, int ntiles, int k_per_split, float* __restrict__ ws) {
-  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int NT = 256 * KG;
+  // k-contiguous operands are written to LDS with scalar (transposing) stores: an odd leading
+  // dimension keeps those at <= 2-way bank conflicts; row-contiguous operands use 16-B stores.
+  constexpr int LDA = A_KC ? BM + 1 : BM + 4, LDB = B_KC ? BN + 1 : BN + 4;
   constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int AV = BM * BK / 4 / 256, BV = BN * BK / 4 / 256;   // float4 loads per thread per tile
-  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+  constexpr int AV = BM * BK / 4 / NT, BV = BN * BK / 4 / NT;   // float4 loads per thread per tile
+  static_assert(AV >= 1 && BV >= 1, "tile too small for the thread count");
+  constexpr int KS = BK / KG;                                   // k-slice per k-group
+  constexpr int A_SZ = BK * LDA, B_SZ = BK * LDB;
+  constexpr int RED_SZ = (KG - 1) * 4 * TM * TN * 16 * 64;
+  constexpr int LDS_FLOATS = (2 * (A_SZ + B_SZ) > RED_SZ) ? 2 * (A_SZ + B_SZ) : RED_SZ;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  float* As = lds;                 // [2][A_SZ]
+  float* Bs = lds + 2 * A_SZ;      // [2][B_SZ]
 
   // XCD-aware bijective remap (guide T1): XCD x gets tiles [start_x, start_x + cnt_x)
   int bid = blockIdx.x;
@@ -59,7 +75,8 @@ __global__ __launch_bounds__(256) void sgemm_kernel(
     accumulate = 0;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+  const int kg = wave >> 2, w4 = wave & 3;
+  const int wm0 = (w4 >> 1) * (BM / 2), wn0 = (w4 & 1) * (BN / 2);
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -69,16 +86,17 @@ __global__ __launch_bounds__(256) void sgemm_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[AV], rb[BV];
+  float4 ra[PD][AV], rb[PD][BV];  // PD register stages: tiles are fetched PD BK-steps ahead
+  bool ia[PD][AV], ib[PD][BV];    // FAST: in-bounds flag of each staged vector
 
   // ---- global -> register loaders (zero-filled out of bounds) ----
   auto load_tile = [&](const float* __restrict__ P, long ld, int vec_ok, int rows_total, int r0,
                        int k0, bool kc, int bdim, float4& out, int v) {
-    // kc: vector runs along k: v -> (row = v/4, kq = (v%4)*4)
+    // kc: vector runs along k: v -> (row = v/(BK/4), kq = (v%(BK/4))*4)   [BK*4 contiguous bytes/row]
     // !kc: vector runs along rows: v -> (k = v/(bdim/4), rq = (v%(bdim/4))*4)
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (kc) {
-      const int row = r0 + (v >> 2), k = k0 + ((v & 3) << 2);
+      const int row = r0 + v / (BK / 4), k = k0 + ((v % (BK / 4)) << 2);
       if (row < rows_total) {
         const float* p = P + (long)row * ld + k;
         if (vec_ok && k + 3 < K) {
@@ -107,9 +125,32 @@ __global__ __launch_bounds__(256) void sgemm_kernel(
     }
     out = o;
   };
+  // FAST: both operands are 16-B vectorisable and every float4 is either entirely inside or entirely
+  // outside the matrix (K % 4 == 0; row counts of row-contiguous operands % 4 == 0).  The load is then
+  // unconditional from a clamped (always valid) address and zeroed by a select: no divergent branch,
+  // so hipcc keeps the prefetched tiles in flight with counted vmcnt waits instead of vmcnt(0).
+  auto load_fast = [&](const float* __restrict__ P, long ld, int rows_total, int r0, int k0, bool kc, int bdim,
+                       float4& out, int v) -> bool {
+    float4 o;
+    bool inb;
+    if (kc) {
+      const int row = r0 + v / (BK / 4), k = k0 + ((v % (BK / 4)) << 2);
+      inb = k < K;                                         // rows beyond M/N only feed unstored outputs
+      const int rc = min(row, rows_total - 1), kc_ = min(k, Ktot - 4);
+      o = *reinterpret_cast<const float4*>(P + (long)rc * ld + kc_);
+    } else {
+      const int per = bdim >> 2;
+      const int k = k0 + v / per, row = r0 + ((v % per) << 2);
+      inb = (k < K) && (row < rows_total);
+      const int kc_ = min(k, Ktot - 1), rc = min(row, rows_total - 4);
+      o = *reinterpret_cast<const float4*>(P + (long)kc_ * ld + rc);
+    }
+    out = o;          // raw; zeroing by `inb` happens when the registers are staged into LDS, so
+    return inb;       // that nothing consumes the load result while it is in flight
+  };
   auto store_tile = [&](float* S, int lds_ld, bool kc, int bdim, const float4& val, int v) {
     if (kc) {
-      const int row = v >> 2, kq = (v & 3) << 2;
+      const int row = v / (BK / 4), kq = (v % (BK / 4)) << 2;
       S[(kq + 0) * lds_ld + row] = val.x;
       S[(kq + 1) * lds_ld + row] = val.y;
       S[(kq + 2) * lds_ld + row] = val.z;
@@ -122,31 +163,38 @@ __global__ __launch_bounds__(256) void sgemm_kernel(
   };
 
   const int nk = (K - kbeg + BK - 1) / BK;
-#pragma unroll
-  for (int i = 0; i < AV; ++i) load_tile(A, a_ld, a_vec, M, m0, kbeg, A_KC, BM, ra[i], tid + i * 256);
-#pragma unroll
-  for (int i = 0; i < BV; ++i) load_tile(B, b_ld, b_vec, N, n0, kbeg, B_KC, BN, rb[i], tid + i * 256);
-#pragma unroll
-  for (int i = 0; i < AV; ++i) store_tile(As[0], LDA, A_KC, BM, ra[i], tid + i * 256);
-#pragma unroll
-  for (int i = 0; i < BV; ++i) store_tile(Bs[0], LDB, B_KC, BN, rb[i], tid + i * 256);
-  __syncthreads();
-
   const int lrow = lane & 31, lk = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
+  auto fetch = [&](int s, int kt) {      // global -> register stage s
 #pragma unroll
-      for (int i = 0; i < AV; ++i)
-        load_tile(A, a_ld, a_vec, M, m0, kbeg + (kt + 1) * BK, A_KC, BM, ra[i], tid + i * 256);
-#pragma unroll
-      for (int i = 0; i < BV; ++i)
-        load_tile(B, b_ld, b_vec, N, n0, kbeg + (kt + 1) * BK, B_KC, BN, rb[i], tid + i * 256);
+    for (int i = 0; i < AV; ++i) {
+      if (FAST) ia[s][i] = load_fast(A, a_ld, M, m0, kbeg + kt * BK, A_KC, BM, ra[s][i], tid + i * NT);
+      else load_tile(A, a_ld, a_vec, M, m0, kbeg + kt * BK, A_KC, BM, ra[s][i], tid + i * NT);
     }
-    const float* as = As[cur];
-    const float* bs = Bs[cur];
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
+    for (int i = 0; i < BV; ++i) {
+      if (FAST) ib[s][i] = load_fast(B, b_ld, N, n0, kbeg + kt * BK, B_KC, BN, rb[s][i], tid + i * NT);
+      else load_tile(B, b_ld, b_vec, N, n0, kbeg + kt * BK, B_KC, BN, rb[s][i], tid + i * NT);
+    }
+  };
+  auto stage = [&](int s, int buf) {     // register stage s -> LDS buffer buf
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      float4 v = ra[s][i];
+      if (FAST && !ia[s][i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      store_tile(As + buf * A_SZ, LDA, A_KC, BM, v, tid + i * NT);
+    }
+#pragma unroll
+    for (int i = 0; i < BV; ++i) {
+      float4 v = rb[s][i];
+      if (FAST && !ib[s][i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      store_tile(Bs + buf * B_SZ, LDB, B_KC, BN, v, tid + i * NT);
+    }
+  };
+  auto compute = [&](int buf) {
+    const float* as = As + buf * A_SZ + kg * KS * LDA;
+    const float* bs = Bs + buf * B_SZ + kg * KS * LDB;
+#pragma unroll
+    for (int kk = 0; kk < KS / 2; ++kk) {
       float a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[i] = as[(2 * kk + lk) * LDA + wm0 + i * 32 + lrow];
@@ -158,13 +206,62 @@ __global__ __launch_bounds__(256) void sgemm_kernel(
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) {
+  };
+
+  // Software pipeline (register stages alternate, LDS double-buffered, one barrier per BK):
+  //   step kt: issue global loads of tile kt+2 | MFMA on LDS[kt&1] | registers(tile kt+1) -> LDS[(kt+1)&1]
+  // so a global load has a whole step plus an MFMA phase to land before it is consumed.
+  if (PD == 2) {
+    fetch(0, 0);
+    stage(0, 0);
+    if (nk > 1) fetch(0, 1);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+      if (kt + 2 < nk) fetch(1, kt + 2);
+      compute(0);
+      if (kt + 1 < nk) stage(0, 1);
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      if (kt + 3 < nk) fetch(0, kt + 3);
+      compute(1);
+      if (kt + 2 < nk) stage(1, 0);
+      __syncthreads();
+    }
+  } else {   // one tile ahead (fewer registers: keeps the 128x128 shape at 3 waves/SIMD)
+    fetch(0, 0);
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) fetch(0, kt + 1);
+      compute(kt & 1);
+      if (kt + 1 < nk) stage(0, (kt + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- sum the KG partial tiles through LDS (the operand buffers are dead after the last barrier)
+  if (KG > 1) {
+    float* red = lds;
+    if (kg > 0) {
 #pragma unroll
-      for (int i = 0; i < AV; ++i) store_tile(As[cur ^ 1], LDA, A_KC, BM, ra[i], tid + i * 256);
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int i = 0; i < BV; ++i) store_tile(Bs[cur ^ 1], LDB, B_KC, BN, rb[i], tid + i * 256);
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            red[((((kg - 1) * 4 + w4) * TM * TN + i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
     }
     __syncthreads();
+    if (kg > 0) return;
+#pragma unroll
+    for (int g = 1; g < KG; ++g)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            acc[i][j][r] += red[((((g - 1) * 4 + w4) * TM * TN + i * TN + j) * 16 + r) * 64 + lane];
   }
 
   // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -202,28 +299,39 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __rest
   *c = accumulate ? *c + s : s;
 }
 
-// Split-K plan: GEMMs whose output has too few 64x64 tiles to fill 256 CUs with several
-// workgroups each (M=N=1024 -> 256 tiles; the conv weight gradients -> 1..54 tiles with K up to
-// ~10^6) split the reduction over blockIdx.y into a caller-provided workspace and are summed by a
-// second, deterministic pass.
+#ifndef GENRL_SMALL_PD
+#define GENRL_SMALL_PD 2
+#endif
+#ifndef GENRL_SMALL_BK
+#define GENRL_SMALL_BK 64
+#define GENRL_SMALL_KG 4
+#endif
+#ifndef GENRL_BIG_BK
+#define GENRL_BIG_BK 16
+#define GENRL_BIG_KG 1
+#endif
+constexpr int SMALL_BK = GENRL_SMALL_BK, SMALL_KG = GENRL_SMALL_KG;
+
+// Split-K plan for the 64x64 configuration: only outputs with too few tiles to give every CU a
+// workgroup split the reduction over blockIdx.y.
 struct SplitPlan {
   int splits, k_per_split;
 };
 inline SplitPlan plan_split(int M, int N, int K) {
   const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
   SplitPlan p{1, K};
-  if (tiles >= 768 || K < 512) return p;
-  long s = cdiv(1024, tiles);
-  const long smax = K / 256;          // at least 256 k per split (16 k-tiles)
+  if (tiles >= 192 || K < 1024) return p;
+  long s = cdiv(512, tiles);
+  const long smax = K / 512;          // at least 512 k (8 BK-steps) per split
   if (s > smax) s = smax;
   if (s <= 1) return p;
-  int kps = cdiv(cdiv(K, s), BK) * BK;
+  int kps = cdiv(cdiv(K, s), SMALL_BK) * SMALL_BK;
   p.k_per_split = kps;
   p.splits = cdiv(K, kps);
   return p;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK, int KG, int PD>
 int launch_cfg(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks, float* C,
                long ldc, const float* bias, int M, int N, int K, int accumulate, int splits, int kps, float* ws,
                hipStream_t s) {
@@ -232,14 +340,24 @@ int launch_cfg(const float* A, long a_rs, long a_ks, const float* B, long b_rs, 
   const int a_vec = ((a_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   const int b_vec = ((b_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
   const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN), ntiles = tiles_m * tiles_n;
-  dim3 grid(ntiles, splits), block(256);
-#define GO(AK, BKC)                                                                             \
-  hipLaunchKernelGGL((sgemm_kernel<BM, BN, AK, BKC>), grid, block, 0, s, A, a_ld, B, b_ld, C, ldc, \
-                     bias, M, N, K, accumulate, a_vec, b_vec, tiles_n, ntiles, kps, ws)
-  if (a_kc && b_kc) GO(true, true);
-  else if (a_kc && !b_kc) GO(true, false);
-  else if (!a_kc && b_kc) GO(false, true);
-  else GO(false, false);
+  dim3 grid(ntiles, splits), block(256 * KG);
+  // branch-free loader preconditions (see load_fast)
+  const bool fast = a_vec && b_vec && (K % 4 == 0) && K >= 4 && (a_kc || (M % 4 == 0 && M >= 4)) &&
+                    (b_kc || (N % 4 == 0 && N >= 4));
+#define GO(F, AK, BKC)                                                                                   \
+  hipLaunchKernelGGL((sgemm_kernel<BM, BN, BK, KG, PD, F, AK, BKC>), grid, block, 0, s, A, a_ld, B, b_ld, C, \
+                     ldc, bias, M, N, K, accumulate, a_vec, b_vec, tiles_n, ntiles, kps, ws)
+  if (fast) {
+    if (a_kc && b_kc) GO(true, true, true);
+    else if (a_kc && !b_kc) GO(true, true, false);
+    else if (!a_kc && b_kc) GO(true, false, true);
+    else GO(true, false, false);
+  } else {
+    if (a_kc && b_kc) GO(false, true, true);
+    else if (a_kc && !b_kc) GO(false, true, false);
+    else if (!a_kc && b_kc) GO(false, false, true);
+    else GO(false, false, false);
+  }
 #undef GO
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
@@ -253,6 +371,7 @@ extern "C" void genrl_set_last_error(int code) { g_last_error = code; }
 extern "C" const char* genrl_last_error(void) { return hipGetErrorString((hipError_t)g_last_error); }
 
 extern "C" long genrl_sgemm_ws_floats(int M, int N, int K) {
+  if ((long)cdiv(M, 128) * cdiv(N, 128) >= 512) return 0;
   const SplitPlan p = plan_split(M, N, K);
   return p.splits > 1 ? (long)p.splits * M * N : 0;
 }
@@ -264,15 +383,14 @@ extern "C" int genrl_sgemm(const float* A, long a_rs, long a_ks, const float* B,
   if (M <= 0 || N <= 0) return GENRL_OK;
   if (K <= 0 || (a_rs != 1 && a_ks != 1) || (b_rs != 1 && b_ks != 1)) return GENRL_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // 128x128 tiles only when they still give >= 2 workgroups per CU; otherwise 64x64 (+ split-K)
-  // to keep the 256 CUs busy on the M=1024 GEMMs of the imagination phase.
   const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
   if (t128 >= 512)
-    return launch_cfg<128, 128>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, 1, K, nullptr, s);
+    return launch_cfg<128, 128, GENRL_BIG_BK, GENRL_BIG_KG, 1>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, 1, K,
+                                       nullptr, s);
   const SplitPlan p = plan_split(M, N, K);
   if (p.splits > 1 && ws && ws_floats >= (long)p.splits * M * N) {
-    int rc = launch_cfg<64, 64>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, p.splits,
-                                p.k_per_split, ws, s);
+    int rc = launch_cfg<64, 64, SMALL_BK, SMALL_KG, GENRL_SMALL_PD>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate,
+                                                    p.splits, p.k_per_split, ws, s);
     if (rc) return rc;
     const long MN = (long)M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(MN, 256)), dim3(256), 0, s, ws, C, ldc, bias, M, N, p.splits,
@@ -280,5 +398,6 @@ extern "C" int genrl_sgemm(const float* A, long a_rs, long a_ks, const float* B,
     GENRL_CHECK_LAUNCH();
     return GENRL_OK;
   }
-  return launch_cfg<64, 64>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, 1, K, nullptr, s);
+  return launch_cfg<64, 64, SMALL_BK, SMALL_KG, GENRL_SMALL_PD>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, 1, K,
+                                                nullptr, s);
 }
