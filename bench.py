@@ -95,6 +95,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--dump-gemm', default='')
+    ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
+                    help='replay the iteration as one captured hipGraph (single GPU)')
     args = ap.parse_args()
 
     from genrl_amd import build, config, dp, ops, flops_model
@@ -103,6 +105,8 @@ def main():
         raise SystemExit('bench.py needs an MI355X (the hot path has no CPU fallback)')
     rank, world, local = dp.init()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    ndev = torch.cuda.device_count()
+    local = local % ndev                          # (test rigs may oversubscribe one GPU with gloo)
     torch.cuda.set_device(local)
     dev = f'cuda:{local}'
     from genrl_amd.agent import dreamer_utils as common
@@ -114,19 +118,29 @@ def main():
     ag = config.make_agent(cfg)
     ag.wm.viclip_model = TextStub()
     full = synth_batch(B, T)
-    batch = {k: torch.from_numpy(v).to(dev) for k, v in dp.shard_batch({k: torch.from_numpy(v) for k, v in full.items()}, rank, world).items()} \
-        if world > 1 else {k: torch.from_numpy(v).to(dev) for k, v in full.items()}
+    batch = {k: v.to(dev) for k, v in dp.shard_batch({k: torch.from_numpy(v) for k, v in full.items()}, rank, world).items()}
     torch.manual_seed(1234 + rank)               # per-rank sampling noise
 
+    graphed = None
+    if args.graph != 'off' and world == 1:
+        try:
+            from genrl_amd.graph import GraphedStep
+            graphed = GraphedStep(ag, batch, one_step, warmup=2)
+        except Exception as e:                      # capture unsupported -> eager launches
+            if args.graph == 'on':
+                raise
+            print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
+            graphed = None
+    run_step = (lambda: graphed()) if graphed is not None else (lambda: one_step(ag, batch))
     for _ in range(args.warmup):
-        mets = one_step(ag, batch)
+        mets = run_step()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        mets = one_step(ag, batch)
+        mets = run_step()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -145,7 +159,8 @@ def main():
                'data': 'synthetic (seeded uint8 64x64 RGB replay, random-init weights, stub text embedding)',
                'config': {'workload': 'configs[1]: full WM + 2x connector + imag-behaviour update, video_text_reward, '
                                       f'batch {B} x seq {T}, 64x64x3, horizon 16, A=10',
-                          'global_batch': B, 'seq_len': T, 'parallelism': f'dp{world}'},
+                          'global_batch': B, 'seq_len': T, 'parallelism': f'dp{world}',
+                          'launch': 'hipGraph replay of the captured iteration' if graphed is not None else 'eager'},
                'algorithmic_gflop_per_step': fl['total'],
                'step_roofline': {'bound': 'mfma', 'achieved': fl['total'] * sps / 1e3 / world, 'peak': PEAK_F32_MFMA_TFLOPS,
                                  'unit': 'TFLOP/s', 'frac': fl['total'] * sps / 1e3 / world / PEAK_F32_MFMA_TFLOPS},

@@ -322,7 +322,8 @@ class ActorCritic(Module):  # ref :323-462
             critic_loss, mets4 = self.critic_loss(seq, target)
             metrics.update(self.critic_opt(critic_loss, self.critic.parameters()))
         metrics.update(**mets1, **mets2, **mets3, **mets4)
-        self.update_slow_target()
+        if not getattr(self, '_defer_slow_target', False):     # hipGraph mode: the driver calls it per replay
+            self.update_slow_target()
         return {f'{self.name}_{k}'.strip('_'): v for k, v in metrics.items()}
 
     def actor_loss(self, seq, target, baseline):  # ref :392-429 (actor_grad 'dynamics')

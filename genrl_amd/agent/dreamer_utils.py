@@ -183,10 +183,9 @@ class ImgChLayerNorm(nn.Module):  # ref :1031-1040 (parameter holder; applied on
 
 def _dense_ln_silu(x, lin, norm, x2=None):
     """Linear (+ second concatenated input) + LayerNorm + SiLU with the reference's layer objects."""
-    y = ops.linear(x, lin.weight, lin.bias) if x2 is None else ops.linear2(x, x2, lin.weight, lin.bias)
     if norm._layer is None:
-        return ops_silu(y)
-    return ops.ln_act(y, norm._layer.weight, norm._layer.bias, norm._layer.eps, act=True)
+        return ops_silu(None)
+    return ops.dense_ln_act(x, x2, lin.weight, lin.bias, norm._layer.weight, norm._layer.bias, norm._layer.eps)
 
 
 def ops_silu(x):
@@ -542,6 +541,7 @@ class FlatGroup:
         self.m = torch.zeros(n, device=dev)
         self.v = torch.zeros(n, device=dev)
         self.step = 0
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)   # device-side Adam step (graph replay)
         off = 0
         for p in self.params:
             k = p.numel()
@@ -623,8 +623,9 @@ class Optimizer:
         ops.grad_norm(group.grad, group.norm, gscale)
         metrics[f'{self._name}_grad_norm'] = group.norm[0].clone()
         group.step += 1
+        group.step_dev.add_(1)
         ops.adam_step(group.flat, group.grad, group.m, group.v, group.norm, gscale, float(self._clip or 0.0),
-                      self._lr, self._eps, float(self._wd or 0.0), group.step)
+                      self._lr, self._eps, float(self._wd or 0.0), group.step, step_dev=group.step_dev)
         if self._wd:
             live_ids = {id(p) for p in live}
             for p in params:

@@ -239,6 +239,10 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(
     }
   }
 
+#ifdef GENRL_DBG_NO_EPILOGUE
+  if (acc[0][0][0] == 12345.678f) C[0] = acc[0][0][1];
+  return;
+#endif
   // ---- sum the KG partial tiles through LDS (the operand buffers are dead after the last barrier)
   if (KG > 1) {
     float* red = lds;

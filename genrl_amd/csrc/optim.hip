@@ -37,7 +37,13 @@ __global__ __launch_bounds__(256) void sqnorm_final_kernel(const float* __restri
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n,
                                                    const float* __restrict__ norm, float gscale, float clip, float lr,
-                                                   float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2) {
+                                                   float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2,
+                                                   const int* __restrict__ step_dev) {
+  if (step_dev) {   // step counter lives on the device (hipGraph replay: host scalars would be frozen)
+    const float st = (float)step_dev[0];
+    bc1 = 1.0f - powf(b1, st);
+    sqrt_bc2 = sqrtf(1.0f - powf(b2, st));
+  }
   // torch clip_grad_norm_: coef = clamp(clip / (norm + 1e-6), max=1)
   const float coef = gscale * (clip > 0.f ? fminf(clip / (norm[0] + 1e-6f), 1.0f) : 1.0f);
   const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -80,14 +86,16 @@ int genrl_grad_norm(const float* g, long n, float* norm_out, float* ws, float sc
 
 // One fused step over a flat parameter group. `norm` is the device scalar written by
 // genrl_grad_norm (already including gscale); gscale multiplies g before use (1/world_size).
+// `step` is the 1-based Adam step; if step_dev != NULL the (already incremented) count is read from
+// device memory instead, so that a captured hipGraph replays with the right bias correction.
 int genrl_adam_step(float* p, const float* g, float* m, float* v, long n, const float* norm, float gscale, float clip,
-                    float lr, float b1, float b2, float eps, float wd, int step, void* stream) {
+                    float lr, float b1, float b2, float eps, float wd, int step, const int* step_dev, void* stream) {
   GENRL_ENTER();
   if (n <= 0) return GENRL_OK;
   const float bc1 = 1.0f - powf(b1, (float)step);
   const float sqrt_bc2 = sqrtf(1.0f - powf(b2, (float)step));
   hipLaunchKernelGGL(adam_kernel, dim3(cdiv(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, norm, gscale,
-                     clip, lr, b1, b2, eps, wd, bc1, sqrt_bc2);
+                     clip, lr, b1, b2, eps, wd, bc1, sqrt_bc2, step_dev);
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }

@@ -134,24 +134,27 @@ __global__ __launch_bounds__(256) void reduce_chunksA_kernel(const float* __rest
   }
 }
 __global__ void reduce_chunks2_kernel(const float* __restrict__ part, float* __restrict__ out0,
-                                      float* __restrict__ out1, int nchunk, int N, int accumulate) {
+                                      float* __restrict__ out1, float* __restrict__ out2, int nchunk, int N, int np,
+                                      int accumulate) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= 2 * N) return;
+  if (j >= np * N) return;
   float s = 0.f;
-  for (int c = 0; c < nchunk; ++c) s += part[(long)c * 2 * N + j];
-  float* o = j < N ? out0 + j : out1 + (j - N);
+  for (int c = 0; c < nchunk; ++c) s += part[(long)c * np * N + j];
+  float* o = j < N ? out0 + j : (j < 2 * N ? out1 + (j - N) : out2 + (j - 2 * N));
   *o = accumulate ? *o + s : s;
 }
 // helper: part[nchunk][2N] -> (out0 | out1); `tmp` must hold 16*2N floats when nchunk > 16
 static inline void reduce_params(const float* part, float* tmp, float* out0, float* out1, int nchunk, int N,
-                                 int accumulate, hipStream_t s) {
+                                 int accumulate, hipStream_t s, float* out2 = nullptr) {
+  const int np = out2 ? 3 : 2;
   if (nchunk > 16) {
     const int G = 16, per = cdiv(nchunk, G);
-    hipLaunchKernelGGL(reduce_chunksA_kernel, dim3(cdiv(2 * N, 64), G), dim3(256), 0, s, part, tmp, nchunk, 2 * N, per);
-    hipLaunchKernelGGL(reduce_chunks2_kernel, dim3(cdiv(2L * N, 256)), dim3(256), 0, s, tmp, out0, out1, G, N, accumulate);
+    hipLaunchKernelGGL(reduce_chunksA_kernel, dim3(cdiv(np * N, 64), G), dim3(256), 0, s, part, tmp, nchunk, np * N, per);
+    hipLaunchKernelGGL(reduce_chunks2_kernel, dim3(cdiv((long)np * N, 256)), dim3(256), 0, s, tmp, out0, out1, out2, G, N,
+                       np, accumulate);
   } else {
-    hipLaunchKernelGGL(reduce_chunks2_kernel, dim3(cdiv(2L * N, 256)), dim3(256), 0, s, part, out0, out1, nchunk, N,
-                       accumulate);
+    hipLaunchKernelGGL(reduce_chunks2_kernel, dim3(cdiv((long)np * N, 256)), dim3(256), 0, s, part, out0, out1, out2,
+                       nchunk, N, np, accumulate);
   }
 }
 
@@ -300,17 +303,19 @@ __global__ __launch_bounds__(256) void ln_act_fwd_blk_kernel(const float* __rest
   }
 }
 
-// dx (may alias dy) + per-workgroup dgamma/dbeta partials: part[blockIdx.x][2][N] (if part != null)
+// dx (may alias dy) + per-workgroup partials part[blockIdx.x][NP][N] (if part != null):
+// NP = 2: (dgamma, dbeta);  NP = 3: (dgamma, dbeta, column sums of dx = the bias gradient of the
+// Linear layer that produced x).
 template <int NV>
 __global__ __launch_bounds__(256) void ln_act_bwd_blk_kernel(const float* dy, long lddy, const float* __restrict__ x,
                                                              long ldx, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
                                                              const float* __restrict__ mean_in,
                                                              const float* __restrict__ rstd_in, float* dx, long lddx,
-                                                             float* __restrict__ part, int M, int N, int act) {
+                                                             float* __restrict__ part, int M, int N, int act, int np) {
   __shared__ float red[8];
   const int nv = N >> 2;
-  float4 g[NV], b[NV], ag[NV], ab[NV];
+  float4 g[NV], b[NV], ag[NV], ab[NV], ax[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int j = threadIdx.x + i * 256;
@@ -318,6 +323,7 @@ __global__ __launch_bounds__(256) void ln_act_bwd_blk_kernel(const float* dy, lo
     b[i] = j < nv ? reinterpret_cast<const float4*>(beta)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ax[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   for (int row = blockIdx.x; row < M; row += gridDim.x) {
     const float4* xr = reinterpret_cast<const float4*>(x + (long)row * ldx);
@@ -349,8 +355,8 @@ __global__ __launch_bounds__(256) void ln_act_bwd_blk_kernel(const float* dy, lo
     }
     const Sum2 r = block_sum2_256(s1, s2, red);
     const float m1 = r.a / N, m2 = r.b / N;
-    if (dx) {
-      float4* dxr = reinterpret_cast<float4*>(dx + (long)row * lddx);
+    {
+      float4* dxr = dx ? reinterpret_cast<float4*>(dx + (long)row * lddx) : nullptr;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int j = threadIdx.x + i * 256;
@@ -360,20 +366,23 @@ __global__ __launch_bounds__(256) void ln_act_bwd_blk_kernel(const float* dy, lo
           o.y = rstd * (dz[i].y * g[i].y - m1 - xh[i].y * m2);
           o.z = rstd * (dz[i].z * g[i].z - m1 - xh[i].z * m2);
           o.w = rstd * (dz[i].w * g[i].w - m1 - xh[i].w * m2);
-          dxr[j] = o;
+          if (dxr) dxr[j] = o;
+          ax[i].x += o.x; ax[i].y += o.y; ax[i].z += o.z; ax[i].w += o.w;
         }
       }
     }
   }
   if (part) {
-    float4* pg = reinterpret_cast<float4*>(part + (long)blockIdx.x * 2 * N);
-    float4* pb = reinterpret_cast<float4*>(part + (long)blockIdx.x * 2 * N + N);
+    float4* pg = reinterpret_cast<float4*>(part + (long)blockIdx.x * np * N);
+    float4* pb = reinterpret_cast<float4*>(part + (long)blockIdx.x * np * N + N);
+    float4* px = reinterpret_cast<float4*>(part + (long)blockIdx.x * np * N + 2 * N);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int j = threadIdx.x + i * 256;
       if (j < nv) {
         pg[j] = ag[i];
         pb[j] = ab[i];
+        if (np == 3) px[j] = ax[i];
       }
     }
   }
@@ -613,13 +622,15 @@ static inline int blk_grid_for(int M) { return M < BLK_GRID ? M : BLK_GRID; }
 // workspace: >= genrl_ln_ws_floats(M, N) floats
 long genrl_ln_ws_floats(int M, int N) {
   const int a = chunks_for(M), b = blk_grid_for(M);
-  return (long)((a > b ? a : b) + 16) * 2 * N;
+  return (long)((a > b ? a : b) + 16) * 3 * N;
 }
 
+// dcolsum (optional, needs dgamma/dbeta too): column sums of dx, i.e. the bias gradient of the Linear
+// layer in front of this LayerNorm.
 int genrl_ln_act_bwd(const float* dy, long lddy, const float* x, long ldx, const float* gamma,
                      const float* beta, const float* mean, const float* rstd, float* dx, long lddx,
-                     float* dgamma, float* dbeta, float* ws, int M, int N, int act, int accumulate_params,
-                     void* stream) {
+                     float* dgamma, float* dbeta, float* dcolsum, float* ws, int M, int N, int act,
+                     int accumulate_params, void* stream) {
   GENRL_ENTER();
   if (M <= 0) return GENRL_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -630,10 +641,11 @@ int genrl_ln_act_bwd(const float* dy, long lddy, const float* x, long ldx, const
     const int grid = blk_grid_for(M);
     const int nv = cdiv(N, 1024);
     float* part = dgamma ? ws : nullptr;
-#define GO(NV) hipLaunchKernelGGL((ln_act_bwd_blk_kernel<NV>), dim3(grid), dim3(256), 0, s, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, part, M, N, act)
+    const int np = dcolsum ? 3 : 2;
+#define GO(NV) hipLaunchKernelGGL((ln_act_bwd_blk_kernel<NV>), dim3(grid), dim3(256), 0, s, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, part, M, N, act, np)
     if (nv == 1) GO(1); else if (nv == 2) GO(2); else if (nv == 3) GO(3); else GO(4);
 #undef GO
-    if (dgamma) reduce_params(ws, ws + (long)grid * 2 * N, dgamma, dbeta, grid, N, accumulate_params, s);
+    if (dgamma) reduce_params(ws, ws + (long)grid * np * N, dgamma, dbeta, grid, N, accumulate_params, s, dcolsum);
     GENRL_CHECK_LAUNCH();
     return GENRL_OK;
   }
@@ -647,6 +659,13 @@ int genrl_ln_act_bwd(const float* dy, long lddy, const float* x, long ldx, const
   if (dx)
     hipLaunchKernelGGL(ln_act_bwd_dx_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, dy, lddy, x, ldx, gamma, beta, mean,
                        rstd, dx, lddx, M, N, act);
+  if (dcolsum && dx) {   // generic path: separate column-sum pass over dx
+    const int nchunk = chunks_for(M);
+    const int rpc = cdiv(M, nchunk);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), nchunk), dim3(256), 0, s, dx, lddx, ws, M, N, rpc);
+    hipLaunchKernelGGL(reduce_chunks_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, ws, dcolsum, nchunk, (long)N,
+                       accumulate_params);
+  }
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }

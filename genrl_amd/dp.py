@@ -21,7 +21,7 @@ def init(backend=None):
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('GENRL_DP_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -166,7 +166,7 @@ class _LNAct(Function):
         dg, db = (gb[0], gb[1]) if need_p else (None, None)
         ws = _ws(lib().genrl_ln_ws_floats(M, N), dy.device) if need_p else None
         check(lib().genrl_ln_act_bwd(_p(dy2), N, _p(x2), N, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dx), N,
-                                     _p(dg), _p(db), _p(ws), M, N, ctx.act, 0, _stream()), 'ln_act_bwd')
+                                     _p(dg), _p(db), None, _p(ws), M, N, ctx.act, 0, _stream()), 'ln_act_bwd')
         return (dx.reshape(ctx.xshape) if dx is not None else None), dg, db, None, None
 
 
@@ -596,9 +596,9 @@ def grad_norm(g_flat, out, scale=1.0):
     return out
 
 
-def adam_step(p, g, m, v, norm, gscale, clip, lr, eps, wd, step, b1=0.9, b2=0.999):
+def adam_step(p, g, m, v, norm, gscale, clip, lr, eps, wd, step, b1=0.9, b2=0.999, step_dev=None):
     check(lib().genrl_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(norm), gscale, clip, lr, b1, b2, eps, wd,
-                                step, _stream()), 'adam_step')
+                                step, _p(step_dev), _stream()), 'adam_step')
 
 
 def scale_(p, s):
@@ -799,3 +799,69 @@ class _GRUSeq(Function):
 
 def gru_seq(x, mask, h0, W, gamma, beta):
     return _GRUSeq.apply(x, mask, h0, W, gamma, beta)
+
+
+
+class _DenseLNAct(Function):
+    """y = SiLU(LayerNorm([x1, x2] W^T + b)) as one autograd node (Linear + NormLayer + act,
+    agent/dreamer_utils.py:739-747,462-463).  The backward runs the LayerNorm backward once and gets
+    dgamma, dbeta AND the Linear's bias gradient from the same pass, then the dgrad / wgrad GEMMs."""
+    @staticmethod
+    def forward(ctx, x1, x2, W, b, gamma, beta, eps):
+        a = _f32(x1).reshape(-1, x1.shape[-1]).contiguous()
+        c = _f32(x2).reshape(-1, x2.shape[-1]).contiguous() if x2 is not None else None
+        M, K1 = a.shape
+        K2 = c.shape[1] if c is not None else 0
+        N, K = W.shape
+        assert K == K1 + K2
+        pre = torch.empty(M, N, device=a.device)
+        sgemm(a, K1, 1, W, K, 1, pre, N, b, M, N, K1)
+        if c is not None:
+            sgemm(c, K2, 1, W, K, 1, pre, N, None, M, N, K2, accumulate=True, b_off=K1)
+        y = torch.empty_like(pre)
+        mean = torch.empty(M, device=a.device); rstd = torch.empty(M, device=a.device)
+        check(lib().genrl_ln_act_fwd(_p(pre), N, _p(gamma), _p(beta), _p(y), N, _p(mean), _p(rstd), M, N, eps, 1,
+                                     _stream()), 'ln_act_fwd')
+        ctx.save_for_backward(a, c if c is not None else a.new_empty(0), W, gamma, beta, pre, mean, rstd)
+        ctx.has2 = c is not None
+        ctx.has_bias = b is not None
+        ctx.shapes = (x1.shape, x2.shape if x2 is not None else None)
+        return y.reshape(*x1.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, c, W, gamma, beta, pre, mean, rstd = ctx.saved_tensors
+        M, K1 = a.shape
+        K2 = c.shape[1] if ctx.has2 else 0
+        N, K = W.shape
+        dev = dy.device
+        dpre = dy.reshape(M, N).contiguous()
+        if dpre.data_ptr() == dy.data_ptr():
+            dpre = dpre.clone()               # the LN backward below writes in place
+        need_p = ctx.needs_input_grad[2] or ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        gb = torch.empty(3, N, device=dev) if need_p else None
+        ws = _ws(lib().genrl_ln_ws_floats(M, N), dev) if need_p else None
+        check(lib().genrl_ln_act_bwd(_p(dpre), N, _p(pre), N, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dpre), N,
+                                     _p(gb[0]) if need_p else None, _p(gb[1]) if need_p else None,
+                                     _p(gb[2]) if need_p else None, _p(ws), M, N, 1, 0, _stream()), 'ln_act_bwd')
+        d1 = d2 = dW = None
+        if ctx.needs_input_grad[0]:
+            d1 = torch.empty(M, K1, device=dev)
+            sgemm(dpre, N, 1, W, 1, K, d1, K1, None, M, K1, N)
+            d1 = d1.reshape(ctx.shapes[0])
+        if ctx.has2 and ctx.needs_input_grad[1]:
+            d2 = torch.empty(M, K2, device=dev)
+            sgemm(dpre, N, 1, W, 1, K, d2, K2, None, M, K2, N, b_off=K1)
+            d2 = d2.reshape(ctx.shapes[1])
+        if ctx.needs_input_grad[2]:
+            dW = torch.empty(N, K, device=dev)
+            sgemm(dpre, 1, N, a, 1, K1, dW, K, None, N, K1, M)
+            if ctx.has2:
+                sgemm(dpre, 1, N, c, 1, K2, dW, K, None, N, K2, M, c_off=K1)
+        if need_p:
+            return d1, d2, dW, (gb[2] if ctx.has_bias else None), gb[0], gb[1], None
+        return d1, d2, dW, None, None, None, None
+
+
+def dense_ln_act(x1, x2, W, b, gamma, beta, eps=1e-5):
+    return _DenseLNAct.apply(x1, x2, W, b, gamma, beta, float(eps))

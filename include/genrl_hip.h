@@ -34,8 +34,8 @@ int genrl_ln_act_fwd(const float* x, long ldx, const float* gamma, const float* 
                      float* rstd, int M, int N, float eps, int act, void* stream);
 long genrl_ln_ws_floats(int M, int N);
 int genrl_ln_act_bwd(const float* dy, long lddy, const float* x, long ldx, const float* gamma, const float* beta,
-                     const float* mean, const float* rstd, float* dx, long lddx, float* dgamma, float* dbeta, float* ws,
-                     int M, int N, int act, int accumulate_params, void* stream);
+                     const float* mean, const float* rstd, float* dx, long lddx, float* dgamma, float* dbeta,
+                     float* dcolsum, float* ws, int M, int N, int act, int accumulate_params, void* stream);
 /* column sums (bias gradients) */
 long genrl_colsum_ws_floats(int M, int N);
 int genrl_colsum(const float* x, long ldx, float* out, float* ws, int M, int N, int accumulate, void* stream);
@@ -109,7 +109,7 @@ int genrl_transpose_last2(const float* in, float* out, long B, int P, int C, voi
 long genrl_sqnorm_ws_floats(long n);
 int genrl_grad_norm(const float* g, long n, float* norm_out, float* ws, float scale, void* stream);
 int genrl_adam_step(float* p, const float* g, float* m, float* v, long n, const float* norm, float gscale, float clip,
-                    float lr, float b1, float b2, float eps, float wd, int step, void* stream);
+                    float lr, float b1, float b2, float eps, float wd, int step, const int* step_dev, void* stream);
 int genrl_scale(float* p, long n, float s, void* stream);
 
 #ifdef __cplusplus

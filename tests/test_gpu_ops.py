@@ -74,6 +74,19 @@ def test_ln_act(ops, M, N, act):
     compare(lambda x, ga, be: ops.ln_act(x, ga, be, 1e-3, act), ref, [x, ga, be], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize('M,K1,K2,N', [(9, 16, 10, 32), (300, 1024, 10, 1024), (64, 512, 0, 512)])
+def test_dense_ln_act(ops, M, K1, K2, N):
+    x1 = torch.randn(M, K1, generator=g(1)); x2 = torch.randn(M, K2, generator=g(2))
+    W = torch.randn(N, K1 + K2, generator=g(3)) / (K1 + K2) ** .5; b = torch.randn(N, generator=g(4))
+    ga = 1 + 0.1 * torch.randn(N, generator=g(5)); be = 0.1 * torch.randn(N, generator=g(6))
+    if K2:
+        ref = lambda x1, x2, W, b, ga, be: F.silu(F.layer_norm(F.linear(torch.cat([x1, x2], -1), W, b), (N,), ga, be, 1e-5))
+        compare(lambda x1, x2, W, b, ga, be: ops.dense_ln_act(x1, x2, W, b, ga, be), ref, [x1, x2, W, b, ga, be], rtol=2e-4, atol=2e-5)
+    else:
+        ref = lambda x1, W, b, ga, be: F.silu(F.layer_norm(F.linear(x1, W, b), (N,), ga, be, 1e-5))
+        compare(lambda x1, W, b, ga, be: ops.dense_ln_act(x1, None, W, b, ga, be), ref, [x1, W, b, ga, be], rtol=2e-4, atol=2e-5)
+
+
 @pytest.mark.parametrize('R,D', [(7, 12), (128, 1024)])
 def test_gru_gates(ops, R, D):
     pre = torch.randn(R, 3 * D, generator=g(1)); h = torch.randn(R, D, generator=g(2))
