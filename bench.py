@@ -95,8 +95,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--dump-gemm', default='')
+    ap.add_argument('--no-overlap', action='store_true', help='keep the connector updates on the main stream')
     ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
-                    help='replay the iteration as one captured hipGraph (single GPU)')
+                    help='replay the iteration as captured hipGraphs (collectives stay eager between graphs)')
     args = ap.parse_args()
 
     from genrl_amd import build, config, dp, ops, flops_model
@@ -114,7 +115,7 @@ def main():
 
     B, T = args.batch, args.length
     torch.manual_seed(0)                         # identical random-init weights on every rank
-    cfg = config.default_cfg(B // world, T, device=dev)
+    cfg = config.default_cfg(B // world, T, device=dev, overlap_detached=(world == 1 and not args.no_overlap))
     ag = config.make_agent(cfg)
     ag.wm.viclip_model = TextStub()
     full = synth_batch(B, T)
@@ -122,7 +123,7 @@ def main():
     torch.manual_seed(1234 + rank)               # per-rank sampling noise
 
     graphed = None
-    if args.graph != 'off' and world == 1:
+    if args.graph != 'off':
         try:
             from genrl_amd.graph import GraphedStep
             graphed = GraphedStep(ag, batch, one_step, warmup=2)
@@ -131,6 +132,8 @@ def main():
                 raise
             print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
             graphed = None
+            ag._imag_behavior._defer_slow_target = False
+            torch.cuda.synchronize()
     run_step = (lambda: graphed()) if graphed is not None else (lambda: one_step(ag, batch))
     for _ in range(args.warmup):
         mets = run_step()
@@ -160,7 +163,7 @@ def main():
                'config': {'workload': 'configs[1]: full WM + 2x connector + imag-behaviour update, video_text_reward, '
                                       f'batch {B} x seq {T}, 64x64x3, horizon 16, A=10',
                           'global_batch': B, 'seq_len': T, 'parallelism': f'dp{world}',
-                          'launch': 'hipGraph replay of the captured iteration' if graphed is not None else 'eager'},
+                          'launch': f'hipGraph replay ({sum(1 for k_, _ in graphed.items if k_ == "graph")} graphs per iteration)' if graphed is not None else 'eager'},
                'algorithmic_gflop_per_step': fl['total'],
                'step_roofline': {'bound': 'mfma', 'achieved': fl['total'] * sps / 1e3 / world, 'peak': PEAK_F32_MFMA_TFLOPS,
                                  'unit': 'TFLOP/s', 'frac': fl['total'] * sps / 1e3 / world / PEAK_F32_MFMA_TFLOPS},

@@ -1,6 +1,7 @@
 """MI355X-native `agent/dreamer.py`: DreamerAgent, WorldModel, ActorCritic with the reference's
 API (mazpie/genrl agent/dreamer.py) on top of the HIP kernels.  Same attribute / method /
 metric names; see SURVEY.md §8b for the call contract with train.py."""
+import contextlib
 from collections import OrderedDict
 
 import numpy as np
@@ -8,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from . import dreamer_utils as common
-from .. import noise, ops
+from .. import noise, ops, streams
 from ..tools.genrl_utils import *          # reward functions resolved through globals(), ref :9
 
 
@@ -149,6 +150,7 @@ class WorldModel(Module):  # ref :120-321
         self.model_opt = common.Optimizer('model', self.parameters(), **self.cfg.model_opt, use_amp=self._use_amp)
 
     def update(self, data, state=None):  # ref :166-187
+        streams.join()
         self.train()
         with common.RequiresGrad(self):
             assert not (getattr(self.cfg, 'freeze_decoder', False) or getattr(self.cfg, 'freeze_post', False)
@@ -163,13 +165,18 @@ class WorldModel(Module):  # ref :120-321
 
     def update_additional_detached_modules(self, data, outputs, metrics):  # ref :189-200
         detached_loss = 0
-        for k in self.detached_update_fns:
-            detached_module = getattr(self, k)
-            with common.RequiresGrad(detached_module):
-                add_loss, add_metrics = self.detached_update_fns[k](self, k, data, outputs, metrics)
-                metrics.update(add_metrics)
-                opt_metrics = self.model_opt(add_loss, detached_module.parameters())
-                metrics.update({f'{k}_{m}': opt_metrics[m] for m in opt_metrics})
+        # cfg.overlap_detached: enqueue these updates on a side stream (genrl_amd/streams.py); they are
+        # joined before update_imag_behavior returns / before the next update_wm starts.
+        overlap = getattr(self.cfg, 'overlap_detached', False) and common.Optimizer.grad_reduce is None
+        ctx = streams.fork('detached') if overlap else contextlib.nullcontext()
+        with ctx:
+            for k in self.detached_update_fns:
+                detached_module = getattr(self, k)
+                with common.RequiresGrad(detached_module):
+                    add_loss, add_metrics = self.detached_update_fns[k](self, k, data, outputs, metrics)
+                    metrics.update(add_metrics)
+                    opt_metrics = self.model_opt(add_loss, detached_module.parameters())
+                    metrics.update({f'{k}_{m}': opt_metrics[m] for m in opt_metrics})
         return detached_loss, metrics
 
     def update_additional_e2e_modules(self, data, outputs, model_loss, metrics):  # ref :202-208

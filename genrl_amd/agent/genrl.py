@@ -5,6 +5,7 @@ import torch
 from .dreamer import DreamerAgent, ActorCritic, stop_gradient, env_reward
 from . import dreamer_utils as common
 from . import video_utils
+from .. import streams
 from ..tools.genrl_utils import *          # reward fns looked up through globals(), ref :5,122
 
 
@@ -89,4 +90,5 @@ class GenRLAgent(DreamerAgent):  # ref :27-124
         start = {k: stop_gradient(v) for k, v in post.items()}
         imag_reward_fn = lambda seq: globals()[self.cfg.imag_reward_fn](self, seq, **self.cfg.imag_reward_args)
         metrics.update(self._imag_behavior.update(self.wm, start, is_terminal, imag_reward_fn))
+        streams.join()          # side-stream connector updates (cfg.overlap_detached) are ordered from here on
         return start, metrics

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(
   static_assert(AV >= 1 && BV >= 1, "tile too small for the thread count");
   constexpr int KS = BK / KG;                                   // k-slice per k-group
   constexpr int A_SZ = BK * LDA, B_SZ = BK * LDB;
-  constexpr int RED_SZ = (KG - 1) * 4 * TM * TN * 16 * 64;
+  constexpr int RED_SZ = (KG - 1) * 4 * TM * TN * 16 * 64;       // KG owners x (KG-1) slots x 16/KG regs
   constexpr int LDS_FLOATS = (2 * (A_SZ + B_SZ) > RED_SZ) ? 2 * (A_SZ + B_SZ) : RED_SZ;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   float* As = lds;                 // [2][A_SZ]
@@ -244,28 +244,40 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(
   return;
 #endif
   // ---- sum the KG partial tiles through LDS (the operand buffers are dead after the last barrier)
+  // and store.  Every k-group takes part: group g owns accumulator registers [g*16/KG, (g+1)*16/KG)
+  // of each 32x32 tile (= a set of output rows), receives the other groups' partials for them
+  // through LDS and writes them to C, so the epilogue is spread over all 4*KG waves.
+  constexpr int RPG = 16 / KG;      // accumulator registers (row groups) owned per k-group
   if (KG > 1) {
-    float* red = lds;
-    if (kg > 0) {
+    float* red = lds;               // [owner g][src slot (KG-1)][w4][TM*TN][RPG][64]
+#pragma unroll
+    for (int o = 0; o < KG; ++o) {
+      if (o == kg) continue;
+      const int slot = kg < o ? kg : kg - 1;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            red[((((kg - 1) * 4 + w4) * TM * TN + i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+          for (int r = 0; r < RPG; ++r)
+            red[(((((o * (KG - 1) + slot) * 4 + w4) * TM * TN + i * TN + j) * RPG + r) * 64) + lane] =
+                acc[i][j][o * RPG + r];
     }
     __syncthreads();
-    if (kg > 0) return;
 #pragma unroll
-    for (int g = 1; g < KG; ++g)
+    for (int slot = 0; slot < KG - 1; ++slot)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            acc[i][j][r] += red[((((g - 1) * 4 + w4) * TM * TN + i * TN + j) * 16 + r) * 64 + lane];
+          for (int r = 0; r < RPG; ++r) {
+            const float v = red[(((((kg * (KG - 1) + slot) * 4 + w4) * TM * TN + i * TN + j) * RPG + r) * 64) + lane];
+            // static register index: select the owned register with a compile-time unrolled loop
+#pragma unroll
+            for (int o = 0; o < KG; ++o)
+              if (o == kg) acc[i][j][o * RPG + r] += v;
+          }
   }
 
   // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -278,6 +290,7 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(
       const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+        if (KG > 1 && (r / RPG) != kg) continue;
         const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (row < M) {
           float* c = C + (long)row * ldc + col;

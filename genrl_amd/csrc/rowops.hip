@@ -143,6 +143,17 @@ __global__ void reduce_chunks2_kernel(const float* __restrict__ part, float* __r
   float* o = j < N ? out0 + j : (j < 2 * N ? out1 + (j - N) : out2 + (j - 2 * N));
   *o = accumulate ? *o + s : s;
 }
+// helper: part[nchunk][N] -> out[N]; `tmp` must hold 16*N floats when nchunk > 16
+static inline void reduce_cols(const float* part, float* tmp, float* out, int nchunk, int N, int accumulate,
+                               hipStream_t s) {
+  if (nchunk > 16) {
+    const int G = 16, per = cdiv(nchunk, G);
+    hipLaunchKernelGGL(reduce_chunksA_kernel, dim3(cdiv(N, 64), G), dim3(256), 0, s, part, tmp, nchunk, N, per);
+    hipLaunchKernelGGL(reduce_chunks_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, tmp, out, G, (long)N, accumulate);
+  } else {
+    hipLaunchKernelGGL(reduce_chunks_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, part, out, nchunk, (long)N, accumulate);
+  }
+}
 // helper: part[nchunk][2N] -> (out0 | out1); `tmp` must hold 16*2N floats when nchunk > 16
 static inline void reduce_params(const float* part, float* tmp, float* out0, float* out1, int nchunk, int N,
                                  int accumulate, hipStream_t s, float* out2 = nullptr) {
@@ -582,11 +593,14 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_blk_kernel(
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 constexpr int BLK_GRID = 512;   // workgroups of the block-per-row kernels (2 per CU); rows are grid-strided
 
+// row chunks of the column-reduction kernels: enough workgroups (up to 2048) to cover HBM latency on
+// the tall-skinny conv activations (M ~ 10^6 rows x 48..384 channels); partials are then reduced in
+// two levels (reduce_chunksA -> final)
 inline int chunks_for(int M) {
   int rc = 64;  // rows per chunk
   int n = cdiv(M, rc);
-  if (n > 256) {
-    rc = cdiv(M, 256);
+  if (n > 2048) {
+    rc = cdiv(M, 2048);
     n = cdiv(M, rc);
   }
   return n;
@@ -663,14 +677,13 @@ int genrl_ln_act_bwd(const float* dy, long lddy, const float* x, long ldx, const
     const int nchunk = chunks_for(M);
     const int rpc = cdiv(M, nchunk);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), nchunk), dim3(256), 0, s, dx, lddx, ws, M, N, rpc);
-    hipLaunchKernelGGL(reduce_chunks_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, ws, dcolsum, nchunk, (long)N,
-                       accumulate_params);
+    reduce_cols(ws, ws + (long)nchunk * N, dcolsum, nchunk, N, accumulate_params, s);
   }
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }
 
-long genrl_colsum_ws_floats(int M, int N) { return (long)chunks_for(M) * N; }
+long genrl_colsum_ws_floats(int M, int N) { return (long)(chunks_for(M) + 16) * N; }
 
 int genrl_colsum(const float* x, long ldx, float* out, float* ws, int M, int N, int accumulate, void* stream) {
   GENRL_ENTER();
@@ -678,7 +691,7 @@ int genrl_colsum(const float* x, long ldx, float* out, float* ws, int M, int N, 
   const int nchunk = chunks_for(M);
   const int rpc = cdiv(M, nchunk);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), nchunk), dim3(256), 0, s, x, ldx, ws, M, N, rpc);
-  hipLaunchKernelGGL(reduce_chunks_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, ws, out, nchunk, (long)N, accumulate);
+  reduce_cols(ws, ws + (long)nchunk * N, out, nchunk, N, accumulate, s);
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }

@@ -51,15 +51,21 @@ def shard_rows(x, rank, world, dim):
 
 
 def grad_reduce(flat_grad):
-    """Sum-all-reduce one flat gradient buffer in place; returns the divisor (world size)."""
-    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    """Sum-all-reduce one flat gradient buffer in place; returns the divisor (world size).
+    Under hipGraph capture the collective is a cut between two graphs (genrl_amd/graph.py)."""
+    from . import graph
+    graph.cut(lambda: dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM))
     return dist.get_world_size()
 
 
 def all_gather_flat(x):
-    out = [torch.empty_like(x) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, x.contiguous())
-    return torch.cat(out)
+    """Concatenation of `x` over ranks.  The output buffer is allocated once per call site and is
+    static across graph replays."""
+    from . import graph
+    x = x.contiguous()
+    out = torch.empty(dist.get_world_size() * x.numel(), dtype=x.dtype, device=x.device)
+    graph.cut(lambda: dist.all_gather_into_tensor(out, x))
+    return out
 
 
 def install(optimizer_cls, reward_ema_cls):

@@ -1,48 +1,93 @@
 """hipGraph capture of one whole training iteration.
 
 The hot path launches ~5 k kernels per iteration, many of them a few microseconds long (the
-sequential RSSM / imagination chains).  Eager Python cannot feed those fast enough, so the GPU
-idles between launches.  `GraphedStep` captures the iteration once into a hipGraph
+sequential RSSM / imagination chains).  Eager Python cannot always feed those fast enough — above
+all when the replay batch is sharded over 8 GPUs and each rank's kernels shrink while the host work
+per iteration stays the same.  `GraphedStep` captures the iteration once into hipGraphs
 (`torch.cuda.CUDAGraph`: our ctypes launches go to torch's current stream, which is the capturing
-stream) and replays it: one host call per iteration, kernels back-to-back.
+stream) and replays them: a handful of host calls per iteration, kernels back-to-back.
 
 What makes the iteration capturable: no host synchronisation anywhere on the path (metrics stay
 device tensors), sampling noise from the device generator, Adam's step count on the device
-(`FlatGroup.step_dev`), workspaces from torch's graph-private pool.  The only host-side decision
-of the reference's iteration — the slow-critic hard copy every `slow_target_update` updates
-(agent/dreamer.py:455-462) — is deferred to `after_replay`."""
+(`FlatGroup.step_dev`), workspaces from torch's graph-private pool.
+
+Collectives are NOT captured: data-parallel all-reduces / all-gathers are "cuts" — the capture is
+split into consecutive graphs sharing one memory pool, and the collective runs eagerly between two
+replays on buffers that are static across replays (flat gradient buffers; a preallocated gather
+output).  `cut()` is called by genrl_amd/dp.py's hooks.
+
+The only host-side decision of the reference's iteration — the slow-critic hard copy every
+`slow_target_update` updates (agent/dreamer.py:455-462) — is deferred to after the replay."""
 import torch
+
+_active = None      # the GraphedStep currently capturing (None otherwise)
+
+
+def cut(eager_fn):
+    """Run `eager_fn` outside graph capture.  Inside a capture: close the current graph, run the
+    function eagerly (and remember it for every replay), open the next graph."""
+    if _active is None:
+        return eager_fn()
+    return _active._cut(eager_fn)
 
 
 class GraphedStep:
     def __init__(self, agent, batch, step_fn, warmup=3):
-        """batch: dict of device tensors whose storage becomes the graph's static input."""
+        """batch: dict of device tensors whose storage becomes the graphs' static input."""
+        global _active
         self.agent = agent
         self.static_batch = {k: v.clone() for k, v in batch.items()}
         self.step_fn = step_fn
-        self.graph = None
+        self.items = []          # ('graph', CUDAGraph) | ('eager', fn)
         self.metrics = None
         ac = agent._imag_behavior
         ac._defer_slow_target = True
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
+        self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
             for _ in range(warmup):
                 step_fn(agent, self.static_batch)
                 ac.update_slow_target()
-        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.metrics = step_fn(agent, self.static_batch)
-        # host-side bookkeeping the capture executed once
-        ac.update_slow_target()
+        self.pool = torch.cuda.graph_pool_handle()
+        _active = self
+        try:
+            with torch.cuda.stream(self.stream):
+                self._begin()
+                self.metrics = step_fn(agent, self.static_batch)
+                self._end()
+        finally:
+            _active = None
+        torch.cuda.current_stream().wait_stream(self.stream)
+        torch.cuda.synchronize()
+        ac.update_slow_target()          # host-side bookkeeping the capture executed once
+
+    def _begin(self):
+        self._g = torch.cuda.CUDAGraph()
+        self._g.capture_begin(pool=self.pool)
+
+    def _end(self):
+        self._g.capture_end()
+        self.items.append(('graph', self._g))
+        self._g = None
+
+    def _cut(self, eager_fn):
+        self._end()
+        out = eager_fn()
+        self.items.append(('eager', eager_fn))
+        self._begin()
+        return out
 
     def __call__(self, batch=None):
         if batch is not None:
             for k, v in batch.items():
                 self.static_batch[k].copy_(v, non_blocking=True)
-        self.graph.replay()
+        for kind, it in self.items:
+            if kind == 'graph':
+                it.replay()
+            else:
+                it()
         for g in self._groups():
             g.step += 1
         self.agent._imag_behavior.update_slow_target()

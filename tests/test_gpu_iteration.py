@@ -33,7 +33,7 @@ def sites_from(noise):
             'imag.target_init_q': noise['imag']['target_init_q']}
 
 
-def run_product(name, lr_zero, cfg_over, ocfg_over):
+def run_product(name, lr_zero, cfg_over, ocfg_over, overlap=False):
     if not torch.cuda.is_available():
         pytest.skip('needs MI355X')
     from genrl_amd import config, noise as gnoise
@@ -44,7 +44,7 @@ def run_product(name, lr_zero, cfg_over, ocfg_over):
     if lr_zero:
         for k in ('model_opt', 'actor_opt', 'critic_opt'):
             over[k] = dict(lr=0.0, wd=0.0)
-    cfg = config.default_cfg(B, T, device='cuda', **over)
+    cfg = config.default_cfg(B, T, device='cuda', overlap_detached=overlap, **over)
     ag = config.make_agent(cfg, act_dim=A)
     ocfg = O.make_cfg(stoch=S, discrete=K, act_dim=A, horizon=H, **ocfg_over)
     p = detgen.det_state_dict(agent_param_shapes(ocfg), seed)
@@ -139,8 +139,9 @@ def test_tiny_optimizer_step_vs_reference():
             assert torch.equal(sd[k], sd[k.replace('_target_critic', 'critic')])
 
 
-def test_c1_full_dims_vs_reference():
-    g, ocfg, p, batch, noise, ag, outputs, mets_wm, mets, grads = run_product('c1_full.npz', True, {}, {})
+@pytest.mark.parametrize('overlap', [False, True])
+def test_c1_full_dims_vs_reference(overlap):
+    g, ocfg, p, batch, noise, ag, outputs, mets_wm, mets, grads = run_product('c1_full.npz', True, {}, {}, overlap=overlap)
     mism = (outputs['post']['stoch'].argmax(-1).cpu().numpy() != g['post_idx']).mean()
     assert mism < 2e-3, mism
     check_vs_golden(g, mets_wm, mets, 1e-3)
