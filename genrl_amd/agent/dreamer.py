@@ -240,10 +240,15 @@ class WorldModel(Module):  # ref :120-321
         rssm = self.rssm
         seq = {k: [v] for k, v in start.items()}
         seq['action'] = [torch.zeros(N, A, device=dev)]
+        # the two heads of DistLayer('normal') (mean, std) as ONE product: weights stacked once per rollout
+        head_w = torch.cat([policy._out._out.weight, policy._out._std.weight], 0)
+        head_b = torch.cat([policy._out._out.bias, policy._out._std.bias], 0)
+        raws = []
         for h in range(horizon):
             stoch, deter = seq['stoch'][-1], seq['deter'][-1]
             s_flat = stoch.reshape(N, -1)
-            raw = policy._out.raw(policy.trunk(stop_gradient(s_flat), stop_gradient(deter)))
+            raw = ops.linear(policy.trunk(stop_gradient(s_flat), stop_gradient(deter)), head_w, head_b)
+            raws.append(raw.detach())
             if eval_policy:
                 action = ops.actor_mean_std(raw, policy._out._min_std, policy._out._max_std)[0]
             else:
@@ -255,6 +260,9 @@ class WorldModel(Module):  # ref :120-321
             for key, value in dict(stoch=stoch, deter=deter, logit=logit, action=action).items():
                 seq[key].append(value)
         seq = {k: torch.stack(v, 0) for k, v in seq.items()}
+        # policy outputs at states 0..H-1 — exactly what ActorCritic.actor_loss re-evaluates for its
+        # entropy metric (agent/dreamer.py:397: actor(sg(feat[:-2]))): kept to avoid a second forward
+        self._last_actor_raw = torch.stack(raws, 0)
         seq['feat'] = rssm.get_feat(seq)
         disc = torch.ones(list(seq['deter'].shape[:-1]) + [1], device=dev)       # no discount head
         seq['discount'] = disc * self.cfg.discount
@@ -316,18 +324,34 @@ class ActorCritic(Module):  # ref :323-462
         metrics = {}
         hor = self.cfg.imag_horizon
         self._target_critic.requires_grad_(False)
+        overlap = getattr(self.cfg, 'overlap_detached', False) and common.Optimizer.grad_reduce is None
         with common.RequiresGrad(self.actor):
             seq = world_model.imagine(self.actor, start, is_terminal, hor)
+            self._rollout_actor_raw = getattr(world_model, '_last_actor_raw', None)
             reward = reward_fn(seq)
             seq['reward'], mets1 = self.rewnorm(reward)
             mets1 = {f'reward_{k}': v for k, v in mets1.items()}
             target, mets2, baseline = self.target(seq)
             actor_loss, mets3 = self.actor_loss(seq, target, baseline)
+            seq_d = {k: stop_gradient(v) for k, v in seq.items()}
+            target_d = stop_gradient(target)
+
+            def critic_step():
+                with common.RequiresGrad(self.critic):
+                    critic_loss, mets4_ = self.critic_loss(seq_d, target_d)
+                    return self.critic_opt(critic_loss, self.critic.parameters()), mets4_
+            if overlap:
+                # the critic regression only needs the (detached) rollout and targets: run it on a side
+                # stream concurrently with the actor's BPTT — two GEMM streams fill each CU with two
+                # independent workgroups.  Joined below, before the slow-target copy.
+                with streams.fork('critic'):
+                    cm, mets4 = critic_step()
             metrics.update(self.actor_opt(actor_loss, self.actor.parameters()))
-        with common.RequiresGrad(self.critic):
-            seq = {k: stop_gradient(v) for k, v in seq.items()}
-            critic_loss, mets4 = self.critic_loss(seq, target)
-            metrics.update(self.critic_opt(critic_loss, self.critic.parameters()))
+        if overlap:
+            streams.join('critic')
+        else:
+            cm, mets4 = critic_step()
+        metrics.update(cm)
         metrics.update(**mets1, **mets2, **mets3, **mets4)
         if not getattr(self, '_defer_slow_target', False):     # hipGraph mode: the driver calls it per replay
             self.update_slow_target()
@@ -346,8 +370,14 @@ class ActorCritic(Module):  # ref :323-462
         if ent_scale != 0:
             raise NotImplementedError('actor_ent != 0 is off the GenRL path (agent/genrl.yaml:9)')
         with torch.no_grad():       # entropy is a metric only when its scale is 0 (no wasted backward)
-            s, d = seq['stoch'][:-2], seq['deter'][:-2]
-            ent = self.actor(s.reshape(list(s.shape[:-2]) + [-1]), d).entropy()[:, :, None]
+            raw = getattr(self, '_rollout_actor_raw', None)
+            if raw is not None and raw.shape[0] >= seq['stoch'].shape[0] - 2:
+                # same weights, same inputs as the rollout's own policy evaluations: reuse them
+                dist = common.NormalDist(raw[:seq['stoch'].shape[0] - 2], self.actor._out._min_std, self.actor._out._max_std)
+            else:
+                s, d = seq['stoch'][:-2], seq['deter'][:-2]
+                dist = self.actor(s.reshape(list(s.shape[:-2]) + [-1]), d)
+            ent = dist.entropy()[:, :, None]
         metrics['actor_ent'] = ent.mean()
         metrics['actor_ent_scale'] = ent_scale
         weight = stop_gradient(seq['weight'])

@@ -292,7 +292,11 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(
       for (int r = 0; r < 16; ++r) {
         if (KG > 1 && (r / RPG) != kg) continue;
         const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+#ifdef GENRL_DBG_NO_STORE
+        if (row < M && acc[i][j][r] == 12345.678f) {
+#else
         if (row < M) {
+#endif
           float* c = C + (long)row * ldc + col;
           float v = acc[i][j][r] + bv;
           if (accumulate) v += *c;

@@ -32,9 +32,9 @@ def fork(name):
         yield s
 
 
-def join():
+def join(name=None):
     cur = torch.cuda.current_stream()
     for key in list(_dirty):
-        if key[1] == torch.cuda.current_device():
+        if key[1] == torch.cuda.current_device() and (name is None or key[0] == name):
             cur.wait_stream(_side[key])
             _dirty.discard(key)
