@@ -351,35 +351,78 @@ __global__ __launch_bounds__(256) void maxcos_bwd_kernel(const float* __restrict
 // Reward alignment (video_text_reward, align_sequence; tools/genrl_utils.py:344-366) given the
 // per-step conv_in projections: score[t][n] = mean_{j<nf} maxcos(ct[j][n], ca[t+j][n]); best t*
 // per column (first max); ts_idx[tau][n] = max(tau - t*, 0) and the flattened target row index.
+// One workgroup per imagination row n: the nf target rows and T agent rows are read ONCE; every
+// thread owns an E/256 slice and accumulates all nf*(T-nf) dot products and the nf+T squared
+// norms, which are then block-reduced.  (Each row of E floats is ~6 KB: the whole problem is one
+// pass over ct[:nf] and ca, HBM/L2-bound.)
+constexpr int AL_MAX_T = 32, AL_MAX_NF = 8, AL_MAX_D = AL_MAX_NF * (AL_MAX_T - AL_MAX_NF);
 __global__ __launch_bounds__(256) void align_index_kernel(const float* __restrict__ ct, const float* __restrict__ ca,
                                                           long* __restrict__ urow, int T, long N, int E, int nf) {
+  constexpr int AL_SLOTS = AL_MAX_D + AL_MAX_T + AL_MAX_NF;
+  __shared__ float swave[4][AL_SLOTS];   // per-wave partials, summed in a fixed order (deterministic)
+  __shared__ float sdot[AL_SLOTS];
+  __shared__ int sbest;
+  const long n = blockIdx.x;
+  const int W = T - nf;                       // number of windows
+  const int nd = nf * W, ntot = nd + T + nf;
+  const int wv = threadIdx.x >> 6;
+  // per-thread partial sums over its slice of E, one value at a time to bound registers:
+  // loop over agent rows tau; for each, the nf target rows it pairs with
   const int lane = threadIdx.x & 63;
-  const long n = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
-  float best = -INFINITY;
-  int bt = 0;
-  for (int t = 0; t < T - nf; ++t) {
-    float sc = 0.f;
-    for (int j = 0; j < nf; ++j) {
-      const float* ur = ct + ((long)j * N + n) * E;
-      const float* vr = ca + ((long)(t + j) * N + n) * E;
-      float su = 0.f, sv = 0.f;
-      for (int i = lane; i < E; i += 64) {
-        su += ur[i] * ur[i];
-        sv += vr[i] * vr[i];
-      }
-      const float mn = fmaxf(sqrtf(wave_sum(su)), sqrtf(wave_sum(sv)));
-      float d = 0.f;
-      for (int i = lane; i < E; i += 64) d += (ur[i] / mn) * (vr[i] / mn);
-      sc += wave_sum(d);
+  for (int tau = 0; tau < T; ++tau) {
+    const float* vr = ca + ((long)tau * N + n) * E;
+    float vv = 0.f;
+    float d[AL_MAX_NF];
+#pragma unroll
+    for (int j = 0; j < AL_MAX_NF; ++j) d[j] = 0.f;
+    for (int e = threadIdx.x; e < E; e += 256) {
+      const float v = vr[e];
+      vv += v * v;
+#pragma unroll
+      for (int j = 0; j < AL_MAX_NF; ++j)
+        if (j < nf) d[j] += v * ct[((long)j * N + n) * E + e];
     }
-    sc /= nf;
-    if (sc > best) {
-      best = sc;
-      bt = t;
+    vv = wave_sum(vv);
+    if (lane == 0) swave[wv][nd + tau] = vv;
+#pragma unroll
+    for (int j = 0; j < AL_MAX_NF; ++j) {
+      if (j < nf) {
+        const int t = tau - j;               // window index this (tau, j) pair belongs to
+        const float s = wave_sum(d[j]);
+        if (lane == 0 && t >= 0 && t < W) swave[wv][t * nf + j] = s;
+      }
     }
   }
-  for (int tau = lane; tau < T; tau += 64) urow[(long)tau * N + n] = (long)max(tau - bt, 0) * N + n;
+  for (int j = 0; j < nf; ++j) {
+    const float* ur = ct + ((long)j * N + n) * E;
+    float uu = 0.f;
+    for (int e = threadIdx.x; e < E; e += 256) uu += ur[e] * ur[e];
+    uu = wave_sum(uu);
+    if (lane == 0) swave[wv][nd + T + j] = uu;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ntot; i += 256) sdot[i] = (swave[0][i] + swave[1][i]) + (swave[2][i] + swave[3][i]);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float best = -INFINITY;
+    int bt = 0;
+    for (int t = 0; t < W; ++t) {
+      float sc = 0.f;
+      for (int j = 0; j < nf; ++j) {
+        const float mn = fmaxf(sqrtf(sdot[nd + T + j]), sqrtf(sdot[nd + t + j]));
+        sc += sdot[t * nf + j] / (mn * mn);
+      }
+      sc /= nf;
+      if (sc > best) {
+        best = sc;
+        bt = t;
+      }
+    }
+    sbest = bt;
+  }
+  __syncthreads();
+  const int bt = sbest;
+  for (int tau = threadIdx.x; tau < T; tau += 256) urow[(long)tau * N + n] = (long)max(tau - bt, 0) * N + n;
 }
 
 template <typename F>
@@ -529,8 +572,8 @@ int genrl_maxcos_bwd(const float* u, const float* v, const long* urow, const flo
 int genrl_align_index(const float* ct, const float* ca, long* urow, int T, long N, int E, int nf, void* stream) {
   GENRL_ENTER();
   if (N <= 0) return GENRL_OK;
-  hipLaunchKernelGGL(align_index_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, ct, ca, urow, T, N, E,
-                     nf);
+  if (T > AL_MAX_T || nf > AL_MAX_NF || nf >= T) return GENRL_EINVAL;
+  hipLaunchKernelGGL(align_index_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, ct, ca, urow, T, N, E, nf);
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }

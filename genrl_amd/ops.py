@@ -835,13 +835,12 @@ class _DenseLNAct(Function):
         K2 = c.shape[1] if ctx.has2 else 0
         N, K = W.shape
         dev = dy.device
-        dpre = dy.reshape(M, N).contiguous()
-        if dpre.data_ptr() == dy.data_ptr():
-            dpre = dpre.clone()               # the LN backward below writes in place
+        dy2 = dy.reshape(M, N).contiguous()
+        dpre = torch.empty_like(pre)          # gradient w.r.t. the pre-LayerNorm projection
         need_p = ctx.needs_input_grad[2] or ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         gb = torch.empty(3, N, device=dev) if need_p else None
         ws = _ws(lib().genrl_ln_ws_floats(M, N), dev) if need_p else None
-        check(lib().genrl_ln_act_bwd(_p(dpre), N, _p(pre), N, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dpre), N,
+        check(lib().genrl_ln_act_bwd(_p(dy2), N, _p(pre), N, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dpre), N,
                                      _p(gb[0]) if need_p else None, _p(gb[1]) if need_p else None,
                                      _p(gb[2]) if need_p else None, _p(ws), M, N, 1, 0, _stream()), 'ln_act_bwd')
         d1 = d2 = dW = None
