@@ -615,6 +615,7 @@ class Optimizer:
         group = self._group_for(live)
         group.rebind()
         loss.backward()
+        ops.wgrad_stream.join()
         if Optimizer.grad_hook is not None:
             Optimizer.grad_hook(self._name, live)
         gscale = 1.0

@@ -212,19 +212,21 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(
   //   step kt: issue global loads of tile kt+2 | MFMA on LDS[kt&1] | registers(tile kt+1) -> LDS[(kt+1)&1]
   // so a global load has a whole step plus an MFMA phase to land before it is consumed.
   if (PD == 2) {
-    fetch(0, 0);
+    fetch(0, 0);                  // both leading tiles are requested back-to-back: one exposed
+    if (nk > 1) fetch(1, 1);      // memory latency in the prologue instead of two
     stage(0, 0);
-    if (nk > 1) fetch(0, 1);
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
-      if (kt + 2 < nk) fetch(1, kt + 2);
+      // LDS[0] holds tile kt, register stage 1 holds tile kt+1
+      if (kt + 2 < nk) fetch(0, kt + 2);
       compute(0);
-      if (kt + 1 < nk) stage(0, 1);
+      if (kt + 1 < nk) stage(1, 1);
       __syncthreads();
       if (kt + 1 >= nk) break;
-      if (kt + 3 < nk) fetch(0, kt + 3);
+      // LDS[1] holds tile kt+1, register stage 0 holds tile kt+2
+      if (kt + 3 < nk) fetch(1, kt + 3);
       compute(1);
-      if (kt + 2 < nk) stage(1, 0);
+      if (kt + 2 < nk) stage(0, 0);
       __syncthreads();
     }
   } else {   // one tile ahead (fewer registers: keeps the 128x128 shape at 3 waves/SIMD)
