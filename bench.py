@@ -171,8 +171,10 @@ def main():
     # ---- kernel roofline: HIP events around every launch of the fp32-MFMA GEMM kernel in one extra step
     if rank == 0 and not args.no_kernel_profile:
         ops.gemm_profile = []
+        ov, ag.cfg.overlap_detached = ag.cfg.overlap_detached, False   # single stream: clean per-launch durations
         one_step(ag, batch)
         torch.cuda.synchronize()
+        ag.cfg.overlap_detached = ov
         prof, ops.gemm_profile = ops.gemm_profile, None
         tot_ms = sum(p_[3].elapsed_time(p_[4]) for p_ in prof)
         tot_fl = sum(2.0 * p_[0] * p_[1] * p_[2] for p_ in prof)
