@@ -248,7 +248,7 @@ class WorldModel(Module):  # ref :120-321
             stoch, deter = seq['stoch'][-1], seq['deter'][-1]
             s_flat = stoch.reshape(N, -1)
             raw = ops.linear(policy.trunk(stop_gradient(s_flat), stop_gradient(deter)), head_w, head_b)
-            raws.append(raw.detach())
+            raws.append(raw)
             if eval_policy:
                 action = ops.actor_mean_std(raw, policy._out._min_std, policy._out._max_std)[0]
             else:
@@ -262,7 +262,7 @@ class WorldModel(Module):  # ref :120-321
         seq = {k: torch.stack(v, 0) for k, v in seq.items()}
         # policy outputs at states 0..H-1 — exactly what ActorCritic.actor_loss re-evaluates for its
         # entropy metric (agent/dreamer.py:397: actor(sg(feat[:-2]))): kept to avoid a second forward
-        self._last_actor_raw = torch.stack(raws, 0)
+        self._last_actor_raw = torch.stack(raws, 0)          # (H, N, 2A), attached to the actor's graph
         seq['feat'] = rssm.get_feat(seq)
         disc = torch.ones(list(seq['deter'].shape[:-1]) + [1], device=dev)       # no discount head
         seq['discount'] = disc * self.cfg.discount
@@ -367,18 +367,24 @@ class ActorCritic(Module):  # ref :323-462
         metrics['reward_ema_095'] = self.ema_vals[1].clone()
         objective = normed_target[1:]
         ent_scale = self.cfg.actor_ent
+        n_pol = seq['stoch'].shape[0] - 2
+        raw = getattr(self, '_rollout_actor_raw', None)
+        if raw is None or raw.shape[0] < n_pol:       # rollout not produced by WorldModel.imagine: re-evaluate
+            s, d = stop_gradient(seq['stoch'][:-2]), stop_gradient(seq['deter'][:-2])
+            raw = self.actor._out.raw(self.actor.trunk(s.reshape(list(s.shape[:-2]) + [-1]), d))
+        # same weights, same inputs as the rollout's own policy evaluations (the reference re-runs the
+        # actor on sg(feat[:-2]), ref :397): their outputs - and graph - are reused
+        raw = raw[:n_pol]
+        A = raw.shape[-1] // 2
+        mn, mx = self.actor._out._min_std, self.actor._out._max_std
         if ent_scale != 0:
-            raise NotImplementedError('actor_ent != 0 is off the GenRL path (agent/genrl.yaml:9)')
-        with torch.no_grad():       # entropy is a metric only when its scale is 0 (no wasted backward)
-            raw = getattr(self, '_rollout_actor_raw', None)
-            if raw is not None and raw.shape[0] >= seq['stoch'].shape[0] - 2:
-                # same weights, same inputs as the rollout's own policy evaluations: reuse them
-                dist = common.NormalDist(raw[:seq['stoch'].shape[0] - 2], self.actor._out._min_std, self.actor._out._max_std)
-            else:
-                s, d = seq['stoch'][:-2], seq['deter'][:-2]
-                dist = self.actor(s.reshape(list(s.shape[:-2]) + [-1]), d)
-            ent = dist.entropy()[:, :, None]
-        metrics['actor_ent'] = ent.mean()
+            std = (mx - mn) * torch.sigmoid(raw[..., A:] + 2.0) + mn
+            ent = (0.5 + 0.5 * np.log(2 * np.pi) + torch.log(std)).sum(-1)[:, :, None]
+            objective = objective + ent_scale * ent
+        else:
+            with torch.no_grad():       # a metric only: no backward through it (its scale is 0)
+                ent = common.NormalDist(raw.detach(), mn, mx).entropy()[:, :, None]
+        metrics['actor_ent'] = ent.detach().mean()
         metrics['actor_ent_scale'] = ent_scale
         weight = stop_gradient(seq['weight'])
         actor_loss = -(weight[:-2] * objective).mean()

@@ -86,3 +86,37 @@ def tiny_overrides():
     r = dict(hidden=32, deter=32, stoch=4, discrete=4)
     return dict(rssm=r, connector_rssm=r, reward_head=dict(units=32), actor=dict(units=32), critic=dict(units=32),
                 encoder=dict(cnn_depth=4), decoder=dict(cnn_depth=4))
+
+
+def dreamer_cfg(batch_size=64, batch_length=50, device='cuda', task='walker_walk', **over):
+    """conf/defaults/dreamer_v3.yaml + conf/env/dmc_pixels.yaml + agent/dreamer.yaml (BASELINE
+    configs[2]: DreamerAgent, walker A=6)."""
+    rssm = dict(ensemble=1, hidden=512, deter=512, stoch=32, discrete=32, norm='layer', std_act='softplus', min_std=0.1,
+                single_obs_posterior=False)
+    cfg = default_cfg(batch_size, batch_length, device, task)
+    for k in ('connector', 'connector_rssm', 'connector_kl', 'imag_reward_fn', 'imag_reward_norm', 'imag_reward_args',
+              'clip_add_noise', 'clip_lafite_noise', 'viclip_encode', 'imag_actor_grad'):
+        cfg.pop(k, None)
+    cfg.update(_ad(dict(rssm=rssm, reward_head=dict(layers=4, units=512, norm='layer', dist='twohot'),
+                        decoder_inputs='feat', actor=dict(layers=4, units=512, norm='layer', dist='normal', min_std=0.1),
+                        critic=dict(layers=4, units=512, norm='layer', dist='twohot'), imag_horizon=15,
+                        grad_heads=['decoder', 'reward'], actor_ent=3e-4)))
+    for k, v in over.items():
+        if isinstance(v, dict) and isinstance(cfg.get(k), dict):
+            cfg[k].update(v)
+        else:
+            cfg[k] = _ad(v)
+    return cfg
+
+
+def make_dreamer_agent(cfg, act_dim=6, img=64):
+    from .agent.dreamer import DreamerAgent
+    obs = dict(observation=Spec((3, img, img), np.uint8), is_first=Spec((), bool), is_last=Spec((), bool),
+               is_terminal=Spec((), bool))
+    return DreamerAgent(name='dreamer', cfg=cfg, obs_space=obs, act_spec=Spec((act_dim,), np.float32))
+
+
+def dreamer_tiny_overrides():
+    r = dict(hidden=32, deter=32, stoch=4, discrete=4)
+    return dict(rssm=r, reward_head=dict(units=32), actor=dict(units=32), critic=dict(units=32),
+                encoder=dict(cnn_depth=4), decoder=dict(cnn_depth=4))

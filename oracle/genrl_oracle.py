@@ -35,6 +35,8 @@ def make_cfg(**over):
         conn_kl_free=0.0, conn_kl_forward=True, conn_kl_balance=0.8, conn_loss_scale=1.0,
         lafite_noise=0.5, discount=0.99, lam=0.95, horizon=16, actor_ent=0.0,
         min_std=0.1, max_std=1.0, unimix=0.99, ema_alpha=0.01,
+        single_obs_posterior=True, decoder_inputs='stoch', reward_grad=False,     # GenRL defaults
+
         model_opt=dict(lr=1e-4, eps=1e-8, clip=1000.0, wd=1e-6),
         actor_opt=dict(lr=3e-5, eps=1e-5, clip=100.0, wd=1e-6),
         critic_opt=dict(lr=3e-5, eps=1e-5, clip=100.0, wd=1e-6),
@@ -258,8 +260,11 @@ def img_step(p, cfg, prefix, stoch, deter, action, q=None):
     return dict(stoch=new_stoch, deter=deter, logit=logit)
 
 
-def post_logits(p, cfg, embed, prefix='wm.rssm.'):
-    """get_post_stoch with single_obs_posterior (agent/dreamer_utils.py:442-457)."""
+def post_logits(p, cfg, embed, prefix='wm.rssm.', deter=None):
+    """get_post_stoch (agent/dreamer_utils.py:442-457); without single_obs_posterior the input is
+    cat([deter, embed])."""
+    if not cfg.single_obs_posterior:
+        embed = torch.cat([deter, embed], -1)
     x = dense_ln_silu(embed, p[f'{prefix}_obs_out.0.weight'], p[f'{prefix}_obs_out.0.bias'],
                       p[f'{prefix}_obs_out.1._layer.weight'], p[f'{prefix}_obs_out.1._layer.bias'])
     lg = F.linear(x, p[f'{prefix}_obs_dist.weight'], p[f'{prefix}_obs_dist.bias'])
@@ -283,7 +288,7 @@ def observe(p, cfg, embed, action, is_first, noise, prefix='wm.rssm.'):
             deter = torch.einsum('b,b...->b...', m, deter)
             a = torch.einsum('b,b...->b...', m, a)
         prior = img_step(p, cfg, prefix, stoch, deter, a, noise['prior_q'][t])
-        plog = post_logits(p, cfg, embed[:, t], prefix)
+        plog = post_logits(p, cfg, embed[:, t], prefix, prior['deter'])
         pst = onehot_sample(plog, noise['post_q'][t], cfg.unimix)
         post = dict(stoch=pst, deter=prior['deter'], logit=plog)
         posts.append(post); priors.append(prior)
@@ -308,10 +313,10 @@ def wm_loss(p, cfg, batch, noise):
     post, prior = observe(p, cfg, embed, batch['action'], batch['is_first'], noise)
     kl, kl_value = kl_loss(post['logit'], prior['logit'], cfg.kl_forward, cfg.kl_balance, cfg.kl_free)
     feat = get_feat(post)
-    stoch_flat = post['stoch'].reshape(B * T, -1)
-    recon = decoder(p, cfg, stoch_flat).reshape(obs.shape)
+    dec_in = post['stoch'].reshape(B * T, -1) if cfg.decoder_inputs == 'stoch' else feat.reshape(B * T, -1)
+    recon = decoder(p, cfg, dec_in).reshape(obs.shape)
     like_obs = -((recon - obs) ** 2).sum([2, 3, 4])               # MSEDist.log_prob, agg sum
-    rew_logits = mlp_head(p, 'wm.heads.reward.', feat.detach(), cfg.mlp_layers)
+    rew_logits = mlp_head(p, 'wm.heads.reward.', feat if cfg.reward_grad else feat.detach(), cfg.mlp_layers)
     like_rew = twohot_logprob(rew_logits, batch['reward'])
     losses = dict(kl=kl, observation=-like_obs.mean(), reward=-like_rew.mean())
     model_loss = cfg.kl_scale * losses['kl'] + losses['observation'] + losses['reward']
@@ -539,3 +544,8 @@ def optimizer_step(params, grads, state, lr, eps, clip, wd, decay_only=()):
         params[n] = params[n] - (lr / bc1) * (m / denom)
         state[n] = (step, m, v)
     return norm
+
+
+def env_reward(p, cfg, seq):
+    """env_reward (agent/dreamer.py:16-17): the reward head's mean on imagined features."""
+    return twohot_mean(mlp_head(p, 'wm.heads.reward.', seq['feat'], cfg.mlp_layers))

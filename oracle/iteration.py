@@ -91,3 +91,35 @@ def run_iteration(p, cfg, batch, noise, text_feat, opt_state=None, apply_updates
                lambda_target=lam_t.detach(), target_cache=target_cache, ts_idx=ts_idx,
                p=p, opt_state=opt_state)
     return res
+
+
+def run_dreamer_iteration(p, cfg, batch, noise, apply_updates=False):
+    """DreamerAgent.update (agent/dreamer.py:94-97): world-model step, then the acting behaviour
+    trained in imagination on the reward head's predictions (acting_reward_fn = env_reward)."""
+    p = dict(p)
+    wm = [n for n in p if n.startswith('wm.')]
+    actor = [n for n in p if n.startswith('_acting_behavior.actor.')]
+    critic = [n for n in p if n.startswith('_acting_behavior.critic.')]
+    res = dict(grads={}, metrics={})
+    q = _leafs(p, wm)
+    loss, outs, mets = O.wm_loss(q, cfg, batch, noise['wm'])
+    res['grads']['wm'] = _grads(loss, q, wm)
+    res['metrics'].update({k: v.detach() for k, v in mets.items()})
+    res['metrics']['model_loss'] = loss.detach()
+    res['metrics']['model_grad_norm'] = O.global_grad_norm(list(res['grads']['wm'].values()))
+    res['outs'] = outs
+    assert not apply_updates
+    post = {k: v.detach() for k, v in outs['post'].items()}
+    q = _leafs(p, actor + critic)
+    seq = O.imagine(q, cfg, post, noise['imag'], actor_prefix='_acting_behavior.actor.')
+    reward = O.env_reward(q, cfg, seq)
+    ema = p.get('_acting_behavior.ema_vals', torch.zeros(2))
+    al, cl, lam_t, mets, new_ema = O.actor_critic_losses(q, cfg, seq, reward, ema, prefix='_acting_behavior.')
+    ga, gc = _grads(al, q, actor), _grads(cl, q, critic)
+    res['grads']['actor'], res['grads']['critic'] = ga, gc
+    im = dict(actor_loss=al.detach(), actor_grad_norm=O.global_grad_norm(list(ga.values())), critic_loss=cl.detach(),
+              critic_grad_norm=O.global_grad_norm(list(gc.values())), **O.stream_norm_metrics(reward.detach()),
+              **{k: (v.detach() if torch.is_tensor(v) else v) for k, v in mets.items()})
+    res['metrics'].update(im)
+    res.update(seq={k: v.detach() for k, v in seq.items()}, reward=reward.detach(), lambda_target=lam_t.detach())
+    return res

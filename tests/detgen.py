@@ -88,3 +88,25 @@ def tiny_overrides():
     r = dict(hidden=32, deter=32, stoch=4, discrete=4)
     return dict(rssm=r, connector_rssm=r, reward_head=dict(units=32), actor=dict(units=32),
                 critic=dict(units=32), encoder=dict(cnn_depth=4), decoder=dict(cnn_depth=4))
+
+
+def det_batch(B, T, A=10, img=64, seed=0):
+    """Deterministic synthetic replay batch (numpy PCG64), regenerated on both sides of a fixture."""
+    g = np.random.Generator(np.random.PCG64([seed, B, T, A, img]))
+    obs = g.integers(0, 256, size=(B, T, 3, img, img), dtype=np.uint8)
+    act = g.uniform(-1, 1, size=(B, T, A)).astype(np.float32)
+    rew = g.uniform(0, 2, size=(B, T, 1)).astype(np.float32)
+    is_first = np.zeros((B, T), bool); is_first[:, 0] = True
+    if B > 1:
+        is_first[1, T // 2] = True                    # an episode boundary inside a window
+    e = g.standard_normal(size=(B, T // 8, 512)).astype(np.float32)
+    e /= np.linalg.norm(e, axis=-1, keepdims=True)
+    return dict(observation=obs, action=act, reward=rew, discount=np.ones((B, T, 1), np.float32),
+                is_first=is_first, is_last=np.zeros((B, T), bool), is_terminal=np.zeros((B, T), bool),
+                clip_video=np.repeat(e, 8, axis=1))
+
+
+def dreamer_tiny_overrides():
+    r = dict(hidden=32, deter=32, stoch=4, discrete=4)
+    return dict(rssm=r, reward_head=dict(units=32), actor=dict(units=32), critic=dict(units=32),
+                encoder=dict(cnn_depth=4), decoder=dict(cnn_depth=4))

@@ -63,14 +63,14 @@ def kat():
     print('kat.npz', len(out))
 
 
-def run_iteration(B, T, A, over, seed, lr_zero, full_tensors, batch):
+def run_iteration(B, T, A, over, seed, lr_zero, full_tensors, batch, img=64, store_batch=True):
     """One train.py iteration (train.py:273-340) on the reference with injected noise."""
     m = rh.ref_modules()
     over = dict(over)
     if lr_zero:
         for k in ('model_opt', 'actor_opt', 'critic_opt'):
             over[k] = dict(lr=0.0, wd=0.0)
-    ag = rh.make_ref_agent(B, T, A=A, imag_reward_fn='capture_reward', **over)
+    ag = rh.make_ref_agent(B, T, A=A, img=img, imag_reward_fn='capture_reward', **over)
     ag.wm.viclip_model = rh.FakeClip()
     sd = ag.state_dict()
     det = detgen.det_state_dict({k: v.shape for k, v in sd.items()}, seed)
@@ -162,7 +162,66 @@ def run_iteration(B, T, A, over, seed, lr_zero, full_tensors, batch):
             out[f'psum.{n}'] = summarize(pten - det[n], 4)
     out['meta'] = np.array([B, T, A, S, K, H, seed, int(lr_zero)])
     out['torch_version'] = np.array(torch.__version__)
-    flat('batch.', batch, out)
+    if store_batch:
+        flat('batch.', batch, out)
+    out['img'] = np.array(img)
+    return out
+
+
+def run_dreamer(B, T, A, over, seed):
+    """DreamerAgent.update (update_wm + update_acting_behavior with env_reward), lr = 0."""
+    over = dict(over)
+    for k in ('model_opt', 'actor_opt', 'critic_opt'):
+        over[k] = dict(lr=0.0, wd=0.0)
+    ag = rh.make_ref_dreamer(B, T, A=A, **over)
+    for d_ in ag._acting_behavior._target_critic.parameters():
+        d_.data = d_.data.clone()
+    det = detgen.det_state_dict({k: v.shape for k, v in ag.state_dict().items()}, seed)
+    ag.load_state_dict(det)
+    S, K, H = ag.cfg.rssm.stoch, ag.cfg.rssm.discrete, ag.cfg.imag_horizon
+    noise = detgen.iteration_noise(B, T, S, K, A, H, seed=seed)
+    tape = []
+    for t in range(T):
+        tape.append(('exp', noise['wm']['prior_q'][t])); tape.append(('exp', noise['wm']['post_q'][t]))
+    tape.append(('normal', noise['imag']['act_eps0']))
+    for h in range(H):
+        tape.append(('normal', noise['imag']['act_eps'][h])); tape.append(('exp', noise['imag']['step_q'][h]))
+    tape = rh.NoiseTape('replay', tape)
+    names = {id(p): n for n, p in ag.named_parameters()}
+    grads, phase = {}, ['wm']
+    orig_clip = torch.nn.utils.clip_grad_norm_
+
+    def clip_capture(params, clip, *a, **k):
+        params = list(params)
+        grads[phase[0]] = {names[id(p)]: p.grad.detach().clone() for p in params if p.grad is not None}
+        return orig_clip(params, clip, *a, **k)
+    batch = detgen.det_batch(B, T, A=A, seed=seed)
+    tb = {k: v for k, v in rh.to_torch(batch).items() if k != 'clip_video'}
+    torch.nn.utils.clip_grad_norm_ = clip_capture
+    out = {}
+    try:
+        with rh.inject_noise(tape):
+            state, outputs, mets = ag.update_wm(tb, 0)
+            mets_wm = {k: torch.as_tensor(v).clone() for k, v in mets.items()}
+            phase[0] = 'actor'
+            orig_cl = ag._acting_behavior.critic_loss
+
+            def critic_hook(*a, **k):
+                phase[0] = 'critic'
+                return orig_cl(*a, **k)
+            ag._acting_behavior.critic_loss = critic_hook
+            _, mets = ag.update_acting_behavior(state, outputs, {}, tb)
+    finally:
+        torch.nn.utils.clip_grad_norm_ = orig_clip
+    assert tape.pos == len(tape.tape), (tape.pos, len(tape.tape))
+    flat('metrics_wm.', mets_wm, out); flat('metrics_act.', {k: torch.as_tensor(v) for k, v in mets.items()}, out)
+    out['post_idx'] = outputs['post']['stoch'].detach().argmax(-1).to(torch.int16).numpy()
+    for ph, gd in grads.items():
+        for n, gten in gd.items():
+            out[f'gsum.{ph}.{n}'] = summarize(gten, 4)
+    out['meta'] = np.array([B, T, A, S, K, H, seed, 1])
+    out['torch_version'] = np.array(torch.__version__)
+    out['img'] = np.array(64)
     return out
 
 
@@ -177,6 +236,15 @@ def main():
     b = rh.stickman_batch(4, 16, seed=0)
     o = run_iteration(4, 16, 10, {}, seed=0, lr_zero=True, full_tensors=False, batch=b)
     np.savez_compressed(f'{HERE}/c1_full.npz', **o); print('c1_full.npz', len(o))
+    # c4-like: 128x128 frames need the 5-layer conv stacks; kitchen A=9; tiny widths;
+    # the batch (incl. an is_first inside a window) is regenerated from its seed, not stored
+    c4 = dict(tiny); c4['encoder'] = dict(cnn_depth=4, cnn_kernels=[4, 4, 4, 4, 4]); c4['decoder'] = dict(cnn_depth=4, cnn_kernels=[5, 5, 5, 6, 6])
+    b = detgen.det_batch(2, 16, A=9, img=128, seed=4)
+    o = run_iteration(2, 16, 9, c4, seed=4, lr_zero=True, full_tensors=False, batch=b, img=128, store_batch=False)
+    np.savez_compressed(f'{HERE}/c4_tiny.npz', **o); print('c4_tiny.npz', len(o))
+    # c3-like: DreamerAgent + dreamer_v3.yaml (walker A=6, T=50 is not a multiple of 8), tiny widths
+    o = run_dreamer(2, 18, 6, detgen.dreamer_tiny_overrides(), seed=3)
+    np.savez_compressed(f'{HERE}/c3_dreamer_tiny.npz', **o); print('c3_dreamer_tiny.npz', len(o))
 
 
 if __name__ == '__main__':

@@ -209,3 +209,26 @@ def synth_batch(B, T, A=10, img=64, seed=0):
 
 def to_torch(batch):
     return {k: torch.as_tensor(v) for k, v in batch.items()}
+
+
+def make_ref_dreamer(B, T, img=64, A=6, seed=0, **over):
+    """DreamerAgent with conf/defaults/dreamer_v3.yaml (BASELINE configs[2])."""
+    m = ref_modules()
+    cfg = AD()
+    cfg.update(_load(f'{REF}/conf/defaults/dreamer_v3.yaml'))
+    cfg.update(_load(f'{REF}/conf/env/dmc_pixels.yaml'))
+    a = _load(f'{REF}/agent/dreamer.yaml')
+    for k in ('_target_', 'cfg', 'obs_space', 'act_spec'):
+        a.pop(k)
+    name = a.pop('name')
+    cfg.update(a)
+    cfg.update(device='cpu', precision=32, batch_size=B, batch_length=T, task='walker_walk')
+    for k, v in over.items():
+        if isinstance(v, dict) and isinstance(cfg.get(k), dict):
+            cfg[k].update(_conv(v))
+        else:
+            cfg[k] = _conv(v)
+    obs = dict(observation=Spec((3, img, img), np.uint8), is_first=Spec((), bool), is_last=Spec((), bool),
+               is_terminal=Spec((), bool))
+    torch.manual_seed(seed)
+    return m.dreamer.DreamerAgent(name=name, cfg=cfg, obs_space=obs, act_spec=Spec((A,), np.float32))

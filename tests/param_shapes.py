@@ -16,7 +16,7 @@ def _mlp(pre, inp, units, layers, out):
     return d
 
 
-def _rssm(pre, c, action_dim, embed_dim=None):
+def _rssm(pre, c, action_dim, embed_dim=None, single=True):
     S = c.stoch * c.discrete
     d = {f'{pre}_cell._layer.weight': (3 * c.deter, c.hidden + c.deter),
          f'{pre}_cell._norm.weight': (3 * c.deter,), f'{pre}_cell._norm.bias': (3 * c.deter,),
@@ -28,7 +28,7 @@ def _rssm(pre, c, action_dim, embed_dim=None):
               f'{pre}_ensemble_img_out.0.0.weight': (c.hidden, c.deter), f'{pre}_ensemble_img_out.0.0.bias': (c.hidden,),
               f'{pre}_ensemble_img_out.0.1._layer.weight': (c.hidden,), f'{pre}_ensemble_img_out.0.1._layer.bias': (c.hidden,)})
     if embed_dim is not None:
-        d.update({f'{pre}_obs_out.0.weight': (c.hidden, embed_dim), f'{pre}_obs_out.0.bias': (c.hidden,),
+        d.update({f'{pre}_obs_out.0.weight': (c.hidden, embed_dim if single else embed_dim + c.deter), f'{pre}_obs_out.0.bias': (c.hidden,),
                   f'{pre}_obs_out.1._layer.weight': (c.hidden,), f'{pre}_obs_out.1._layer.bias': (c.hidden,)})
     return d
 
@@ -46,7 +46,8 @@ def embed_dim(c):
     return (2 ** (len(c.enc_kernels) - 1)) * c.cnn_depth * sizes[-1] ** 2
 
 
-def agent_param_shapes(c):
+def agent_param_shapes(c, dreamer=False):
+    """dreamer=True: DreamerAgent (no connector / _imag_behavior; decoder may take feat)."""
     d = {}
     n = len(c.enc_kernels)
     for i, k in enumerate(c.enc_kernels):
@@ -59,8 +60,8 @@ def agent_param_shapes(c):
     E = embed_dim(c)
     S = c.stoch * c.discrete
     F = S + c.deter
-    d.update(_rssm('wm.rssm.', c, c.act_dim, E))
-    d['wm.heads.decoder._conv_in.0.weight'] = (32 * c.cnn_depth, S)
+    d.update(_rssm('wm.rssm.', c, c.act_dim, E, getattr(c, 'single_obs_posterior', True)))
+    d['wm.heads.decoder._conv_in.0.weight'] = (32 * c.cnn_depth, S if getattr(c, 'decoder_inputs', 'stoch') == 'stoch' else F)
     d['wm.heads.decoder._conv_in.0.bias'] = (32 * c.cnn_depth,)
     n = len(c.dec_kernels)
     for i, k in enumerate(c.dec_kernels):
@@ -72,6 +73,8 @@ def agent_param_shapes(c):
             d[f'wm.heads.decoder._conv_model.{3*i+1}.norm.weight'] = (co,)
             d[f'wm.heads.decoder._conv_model.{3*i+1}.norm.bias'] = (co,)
     d.update(_mlp('wm.heads.reward.', F, c.units, c.mlp_layers, [('_out', 255)]))
+    if dreamer:
+        return _behaviors(d, c, F, ('_acting_behavior.',))
     ca = c.clip_dim + c.n_frames
     d.update(_rssm('wm.connector.', c, ca, None))
     al, D, M = 'wm.connector.aligner.', c.clip_dim, c.clip_dim // 2
@@ -90,7 +93,11 @@ def agent_param_shapes(c):
               f'{ip}3.weight': (c.hidden, c.hidden), f'{ip}3.bias': (c.hidden,),
               f'{ip}4._layer.weight': (c.hidden,), f'{ip}4._layer.bias': (c.hidden,),
               f'{ip}6.weight': (c.deter, c.hidden), f'{ip}6.bias': (c.deter,)})
-    for b in ('_acting_behavior.', '_imag_behavior.'):
+    return _behaviors(d, c, F, ('_acting_behavior.', '_imag_behavior.'))
+
+
+def _behaviors(d, c, F, names):
+    for b in names:
         d[f'{b}ema_vals'] = (2,)
         d.update(_mlp(f'{b}actor.', F, c.units, c.mlp_layers, [('_out', c.act_dim), ('_std', c.act_dim)]))
         d.update(_mlp(f'{b}critic.', F, c.units, c.mlp_layers, [('_out', 255)]))

@@ -52,3 +52,12 @@ def test_agent_is_picklable():
     buf = io.BytesIO(); torch.save(ag, buf); buf.seek(0)
     ag2 = torch.load(buf, weights_only=False)
     assert set(ag2.state_dict()) == set(ag.state_dict())
+
+
+def test_dreamer_agent_weight_contract():
+    from genrl_amd import config
+    cfg = config.dreamer_cfg(2, 18, device='cpu', **config.dreamer_tiny_overrides())
+    ag = config.make_dreamer_agent(cfg)
+    ocfg = O.make_cfg(stoch=4, discrete=4, act_dim=6, deter=32, hidden=32, units=32, cnn_depth=4,
+                      single_obs_posterior=False, decoder_inputs='feat')
+    assert {k: tuple(v.shape) for k, v in ag.state_dict().items()} == param_shapes.agent_param_shapes(ocfg, dreamer=True)

@@ -45,12 +45,14 @@ def run_product(name, lr_zero, cfg_over, ocfg_over, overlap=False):
         for k in ('model_opt', 'actor_opt', 'critic_opt'):
             over[k] = dict(lr=0.0, wd=0.0)
     cfg = config.default_cfg(B, T, device='cuda', overlap_detached=overlap, **over)
-    ag = config.make_agent(cfg, act_dim=A)
+    ag = config.make_agent(cfg, act_dim=A, img=int(g['img']) if 'img' in g else 64)
     ocfg = O.make_cfg(stoch=S, discrete=K, act_dim=A, horizon=H, **ocfg_over)
     p = detgen.det_state_dict(agent_param_shapes(ocfg), seed)
     ag.load_state_dict({k: v.cuda() for k, v in p.items()})
     ag.wm.viclip_model = FakeClip()
     batch_cpu = {k[len('batch.'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('batch.')}
+    if not batch_cpu:
+        batch_cpu = {k: torch.from_numpy(v) for k, v in detgen.det_batch(B, T, A=A, img=int(g['img']), seed=seed).items()}
     batch = {k: v.cuda() for k, v in batch_cpu.items()}
     noise = detgen.iteration_noise(B, T, S, K, A, H, seed=seed)
     grads, phase = {}, []
@@ -150,3 +152,70 @@ def test_c1_full_dims_vs_reference(overlap):
             _, ph, name = key.split('.', 2)
             l2 = grads[ph][name].double().norm().item()
             np.testing.assert_allclose(l2, val[2], rtol=5e-3, atol=1e-6, err_msg=key)
+
+
+def test_c4_128px_five_layer_convs_vs_reference():
+    """configs[3]-like: 128x128 frames, 5-layer encoder/decoder, kitchen A=9."""
+    from genrl_amd import config
+    over = config.tiny_overrides()
+    over['encoder'] = dict(cnn_depth=4, cnn_kernels=[4, 4, 4, 4, 4]); over['decoder'] = dict(cnn_depth=4, cnn_kernels=[5, 5, 5, 6, 6])
+    oc = dict(deter=32, hidden=32, units=32, cnn_depth=4, img=128, enc_kernels=(4, 4, 4, 4, 4), dec_kernels=(5, 5, 5, 6, 6))
+    g, ocfg, p, batch, noise, ag, outputs, mets_wm, mets, grads = run_product('c4_tiny.npz', True, over, oc)
+    assert outputs['embed'].shape[-1] == 256                 # 64 ch x 2 x 2
+    assert (outputs['post']['stoch'].argmax(-1).cpu().numpy() == g['post_idx']).all()
+    check_vs_golden(g, mets_wm, mets, 3e-4)
+    for key, val in g.items():
+        if key.startswith('gsum.'):
+            _, ph, name = key.split('.', 2)
+            np.testing.assert_allclose(grads[ph][name].double().norm().item(), val[2], rtol=2e-3, atol=1e-6, err_msg=key)
+
+
+def test_c3_dreamer_agent_vs_reference_and_oracle():
+    """configs[2]-like: DreamerAgent.update = update_wm + update_acting_behavior(env_reward) with
+    dreamer_v3.yaml semantics (posterior from [deter, embed], decoder on feat, reward head trained,
+    actor entropy bonus, T=18)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs MI355X')
+    from genrl_amd import config, noise as gnoise
+    from genrl_amd.agent import dreamer_utils as common
+    from oracle.iteration import run_dreamer_iteration
+    g = dict(np.load(os.path.join(G, 'c3_dreamer_tiny.npz')))
+    B, T, A, S, K, H, seed, _ = [int(x) for x in g['meta']]
+    zero = dict(lr=0.0, wd=0.0)
+    cfg = config.dreamer_cfg(B, T, device='cuda', model_opt=zero, actor_opt=zero, critic_opt=zero,
+                             **config.dreamer_tiny_overrides())
+    ag = config.make_dreamer_agent(cfg, act_dim=A)
+    ocfg = O.make_cfg(stoch=S, discrete=K, act_dim=A, horizon=H, deter=32, hidden=32, units=32, cnn_depth=4,
+                      single_obs_posterior=False, decoder_inputs='feat', reward_grad=True, actor_ent=3e-4)
+    p = detgen.det_state_dict(agent_param_shapes(ocfg, dreamer=True), seed)
+    assert {k: tuple(v.shape) for k, v in ag.state_dict().items()} == {k: tuple(v.shape) for k, v in p.items()}
+    ag.load_state_dict({k: v.cuda() for k, v in p.items()})
+    bc = {k: torch.from_numpy(v) for k, v in detgen.det_batch(B, T, A=A, seed=seed).items() if k != 'clip_video'}
+    batch = {k: v.cuda() for k, v in bc.items()}
+    noise = detgen.iteration_noise(B, T, S, K, A, H, seed=seed)
+    sites = {'rssm.prior': [noise['wm']['prior_q'][t] for t in range(T)],
+             'rssm.post': [noise['wm']['post_q'][t] for t in range(T)],
+             'imag.act_eps': noise['imag']['act_eps'], 'imag.step_q': noise['imag']['step_q']}
+    grads = {}
+    names = {id(q): n for n, q in ag.named_parameters()}
+    common.Optimizer.grad_hook = lambda opt, params: grads.__setitem__(
+        {'model': 'wm', 'actor': 'actor', 'critic': 'critic'}[opt], {names[id(q)]: q.grad.detach().clone().cpu() for q in params})
+    try:
+        with gnoise.inject(sites):
+            state, outputs, mets = ag.update_wm(batch, 0)
+            mets_wm = {k: float(v) for k, v in mets.items()}
+            _, mets = ag.update_acting_behavior(state, outputs, {}, batch)
+    finally:
+        common.Optimizer.grad_hook = None
+    mets = {k: float(v) for k, v in mets.items()}
+    assert (outputs['post']['stoch'].argmax(-1).cpu().numpy() == g['post_idx']).all()
+    for key, val in g.items():
+        for pre, src in (('metrics_wm.', mets_wm), ('metrics_act.', mets)):
+            if key.startswith(pre):
+                np.testing.assert_allclose(src[key[len(pre):]], float(val), rtol=3e-4, atol=2e-6, err_msg=key)
+    res = run_dreamer_iteration(p, ocfg, bc, noise)
+    for ph in ('wm', 'actor', 'critic'):
+        assert set(grads[ph]) == set(res['grads'][ph]), (ph, set(grads[ph]) ^ set(res['grads'][ph]))
+        for name, gref in res['grads'][ph].items():
+            a, b = grads[ph][name].numpy(), gref.numpy()
+            np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-5 * max(1.0, np.abs(b).max()), err_msg=f'{ph}.{name}')

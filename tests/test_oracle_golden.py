@@ -63,6 +63,8 @@ def setup_case(name, **cfg_over):
     cfg = O.make_cfg(stoch=S, discrete=K, act_dim=A, horizon=H, **cfg_over)
     p = detgen.det_state_dict(agent_shapes(cfg), seed)
     batch = {k[len('batch.'):]: T_(v) for k, v in g.items() if k.startswith('batch.')}
+    if not batch:       # regenerated from its seed (tests/detgen.py)
+        batch = {k: T_(v) for k, v in detgen.det_batch(B, T, A=A, img=int(g['img']), seed=seed).items()}
     noise = detgen.iteration_noise(B, T, S, K, A, H, seed=seed)
     gtxt = torch.Generator().manual_seed(123)
     text = torch.nn.functional.normalize(torch.randn(1, 512, generator=gtxt), dim=-1)
@@ -138,3 +140,42 @@ def test_c1_full_dims_vs_reference():
         if key.startswith('gsum.'):
             _, ph, name = key.split('.', 2)
             np.testing.assert_allclose(summarize(res['grads'][ph][name], 4)[2], val[2], rtol=2e-3, atol=1e-6, err_msg=key)
+
+
+C4 = dict(deter=32, hidden=32, units=32, cnn_depth=4, img=128, enc_kernels=(4, 4, 4, 4, 4), dec_kernels=(5, 5, 5, 6, 6))
+
+
+def test_c4_128px_five_layer_convs_vs_reference():
+    """configs[3]-like: 128x128 frames, 5-layer conv stacks, A=9, an is_first inside a window."""
+    g, cfg, p, batch, noise, text = setup_case('c4_tiny.npz', **C4)
+    res = run_iteration(p, cfg, batch, noise, text, apply_updates=False)
+    assert (res['outs']['post']['stoch'].argmax(-1).numpy() == g['post_idx']).all()
+    assert (res['seq']['stoch'].argmax(-1).numpy() == g['imag_idx']).all()
+    check_metrics(res, g, 5e-5)
+    for key, val in g.items():
+        if key.startswith('gsum.'):
+            _, ph, name = key.split('.', 2)
+            np.testing.assert_allclose(summarize(res['grads'][ph][name], 4)[1:3], val[1:3], rtol=5e-4, atol=1e-5, err_msg=key)
+
+
+def test_c3_dreamer_agent_vs_reference():
+    """configs[2]-like: DreamerAgent + dreamer_v3.yaml (posterior from [deter, embed], decoder on feat,
+    reward head trained end-to-end, env_reward, actor entropy 3e-4, T not a multiple of 8)."""
+    from oracle.iteration import run_dreamer_iteration
+    g = load('c3_dreamer_tiny.npz')
+    B, T, A, S, K, H, seed, _ = [int(x) for x in g['meta']]
+    cfg = O.make_cfg(stoch=S, discrete=K, act_dim=A, horizon=H, deter=32, hidden=32, units=32, cnn_depth=4,
+                     single_obs_posterior=False, decoder_inputs='feat', reward_grad=True, actor_ent=3e-4)
+    from param_shapes import agent_param_shapes
+    p = detgen.det_state_dict(agent_param_shapes(cfg, dreamer=True), seed)
+    batch = {k: T_(v) for k, v in detgen.det_batch(B, T, A=A, seed=seed).items()}
+    noise = detgen.iteration_noise(B, T, S, K, A, H, seed=seed)
+    res = run_dreamer_iteration(p, cfg, batch, noise)
+    assert (res['outs']['post']['stoch'].argmax(-1).numpy() == g['post_idx']).all()
+    for key, val in g.items():
+        for pre in ('metrics_wm.', 'metrics_act.'):
+            if key.startswith(pre):
+                np.testing.assert_allclose(float(res['metrics'][key[len(pre):]]), float(val), rtol=5e-5, atol=1e-6, err_msg=key)
+        if key.startswith('gsum.'):
+            _, ph, name = key.split('.', 2)
+            np.testing.assert_allclose(summarize(res['grads'][ph][name], 4)[1:3], val[1:3], rtol=5e-4, atol=1e-5, err_msg=key)
