@@ -197,19 +197,26 @@ class WorldModel(Module):  # ref :120-321
     def loss(self, data, state=None):  # ref :219-252
         data = self.preprocess(data)
         embed = self.encoder(data)
+        # cfg.overlap_detached: the prior branch (GRU scan -> prior head -> KL) runs on a side stream
+        # beside the decoder / reward-head branch (genrl_amd/streams.py); only possible when the heads
+        # do not read `deter` with a gradient path that the KL shares, i.e. the GenRL configuration
+        fork = (getattr(self.cfg, 'overlap_detached', False) and self.rssm.single_obs_posterior
+                and self.cfg.decoder_inputs == 'stoch' and self.grad_heads == ['decoder'])
+        self.rssm.fork_prior = fork
         post, prior = self.rssm.observe(embed, data['action'], data['is_first'], state)
-        kl_loss, kl_value = self.rssm.kl_loss(post, prior, **self.cfg.kl)
-        assert len(kl_loss.shape) == 0 or (len(kl_loss.shape) == 1 and kl_loss.shape[0] == 1), kl_loss.shape
+        self.rssm.fork_prior = False
         likes = {}
-        losses = {'kl': kl_loss}
-        feat = self.rssm.get_feat(post)
+        losses = {'kl': None}
+        joined = not fork
         for name, head in self.heads.items():
             grad_head = (name in self.grad_heads)
             if name == 'decoder':
-                inp = self.decoder_input_fn(post)
+                inp = self.decoder_input_fn(post)            # posterior stoch: produced on the main stream
                 inp = inp if grad_head else stop_gradient(inp)
                 out = head(inp)
             else:       # MLP heads consume feat = [stoch, deter] without the concatenation
+                if not joined:                               # deter comes from the side-stream scan
+                    streams.join('scan'); joined = True
                 s, d = self.rssm.get_stoch(post), post['deter']
                 if not grad_head:
                     s, d = stop_gradient(s), stop_gradient(d)
@@ -219,6 +226,12 @@ class WorldModel(Module):  # ref :120-321
                 like = dist.log_prob(data[key])
                 likes[key] = like
                 losses[key] = -like.mean()
+        if not joined:
+            streams.join('scan')
+        kl_loss, kl_value = self.rssm.kl_loss(post, prior, **self.cfg.kl)
+        assert len(kl_loss.shape) == 0 or (len(kl_loss.shape) == 1 and kl_loss.shape[0] == 1), kl_loss.shape
+        losses['kl'] = kl_loss
+        feat = self.rssm.get_feat(post)
         model_loss = sum(self.cfg.loss_scales.get(k, 1.0) * v for k, v in losses.items())
         outs = dict(embed=embed, feat=feat, post=post, prior=prior, likes=likes, kl=kl_value)
         metrics = {f'{name}_loss': value for name, value in losses.items()}

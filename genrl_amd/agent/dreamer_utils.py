@@ -9,13 +9,14 @@ are used only as *parameter holders*: their torch forward is never called on the
 Only what the GenRL path configures is implemented (norm 'layer'/'none', act SiLU, discrete
 latents, GRU cell, dists mse / twohot / normal / onehot); other reference options raise.
 """
+import contextlib
 import re
 
 import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import noise, ops
+from .. import noise, ops, streams
 
 Module = nn.Module
 
@@ -479,14 +480,21 @@ class EnsembleRSSM(Module):  # ref :302-555
         plog = self._post_logits(emb.reshape(T * B, -1)).reshape(T, B, S, K)
         pst = ops.onehot_sample(plog, noise.draw('exp', 'wm.post_q', (T, B * S, K), dev))
         st0 = state if state is not None else self.initial(B)
-        prev = torch.cat([st0['stoch'].reshape(1, B, S * K), pst.reshape(T, B, S * K)[:-1]], 0)
-        mrow = mask.reshape(T * B, 1)
-        x = _dense_ln_silu((prev.reshape(T * B, S * K) * mrow), self._img_in[0], self._img_in[1],
-                           act.reshape(T * B, -1) * mrow)
-        deter = ops.gru_seq(x.reshape(T, B, -1), mask, st0['deter'], self._cell._layer.weight,
-                            self._cell._norm.weight, self._cell._norm.bias)
-        qlog = self._prior_logits(deter.reshape(T * B, -1)).reshape(T, B, S, K)
-        qst = ops.onehot_sample(qlog, noise.draw('exp', 'wm.prior_q', (T, B * S, K), dev))
+        q_prior = noise.draw('exp', 'wm.prior_q', (T, B * S, K), dev)
+        # Everything below only feeds the KL term (with `decoder_inputs: stoch` the decoder and the
+        # reward head need the posterior alone): when `fork_prior` is set it is enqueued on a side
+        # stream, so this latency-bound T-step chain runs beside the conv-heavy decoder work; autograd
+        # replays each branch's backward on its own stream.  The caller joins before using `prior`.
+        ctx = streams.fork('scan') if getattr(self, 'fork_prior', False) else contextlib.nullcontext()
+        with ctx:
+            prev = torch.cat([st0['stoch'].reshape(1, B, S * K), pst.reshape(T, B, S * K)[:-1]], 0)
+            mrow = mask.reshape(T * B, 1)
+            x = _dense_ln_silu((prev.reshape(T * B, S * K) * mrow), self._img_in[0], self._img_in[1],
+                               act.reshape(T * B, -1) * mrow)
+            deter = ops.gru_seq(x.reshape(T, B, -1), mask, st0['deter'], self._cell._layer.weight,
+                                self._cell._norm.weight, self._cell._norm.bias)
+            qlog = self._prior_logits(deter.reshape(T * B, -1)).reshape(T, B, S, K)
+            qst = ops.onehot_sample(qlog, q_prior)
         bm = lambda x: x.transpose(0, 1)
         post = {'stoch': bm(pst), 'deter': bm(deter), 'logit': bm(plog)}
         prior = {'stoch': bm(qst), 'deter': bm(deter), 'logit': bm(qlog)}

@@ -345,7 +345,9 @@ inline SplitPlan plan_split(int M, int N, int K) {
   SplitPlan p{1, K};
   if (tiles >= 192 || K < 1024) return p;
   long s = cdiv(512, tiles);
-  const long smax = K / 512;          // at least 512 k (8 BK-steps) per split
+  // at least 512 k (8 BK-steps) per split; very tile-starved launches (the M=32 steps of the RSSM
+  // scans, N=10/20 heads) are latency-bound weight streams: more, shorter splits (>= 128 k)
+  const long smax = tiles <= 64 ? K / 128 : K / 512;
   if (s > smax) s = smax;
   if (s <= 1) return p;
   int kps = cdiv(cdiv(K, s), SMALL_BK) * SMALL_BK;
