@@ -42,7 +42,8 @@ template <int BM, int BN, int BK, int KG, int PD, bool FAST, bool A_KC, bool B_K
 __global__ __launch_bounds__(256 * KG) void sgemm_kernel(
     const float* __restrict__ A, long a_ld, const float* __restrict__ B, long b_ld,
     float* __restrict__ C, long ldc, const float* __restrict__ bias, int M, int N, int Ktot,
-    int accumulate, int a_vec, int b_vec, int tiles_n, int ntiles, int k_per_split, float* __restrict__ ws) {
+    int accumulate, int a_vec, int b_vec, int tiles_n, int ntiles, int k_per_split, float* __restrict__ ws,
+    int tiles_m, int xcd_m) {
   constexpr int NT = 256 * KG;
   // k-contiguous operands are written to LDS with scalar (transposing) stores: an odd leading
   // dimension keeps those at <= 2-way bank conflicts; row-contiguous operands use 16-B stores.
@@ -58,13 +59,28 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(
   float* As = lds;                 // [2][A_SZ]
   float* Bs = lds + 2 * A_SZ;      // [2][B_SZ]
 
-  // XCD-aware bijective remap (guide T1): XCD x gets tiles [start_x, start_x + cnt_x)
+  // XCD-aware tile order.  The dispatcher places workgroup b on XCD b % 8 and each XCD has a private
+  // 4 MB L2: give every XCD a compact 2-D sub-block of the tile grid (xm x xn XCDs over the
+  // tiles_m x tiles_n grid, chosen by the launcher so that the sub-block's A row-panels + B column-
+  // panels fit the L2), instead of whole tile rows (which make every XCD stream ALL of B).
+  // Falls back to a bijective linear split when the grid does not divide.
   int bid = blockIdx.x;
+  int tile_m, tile_n;
   {
-    const int q = ntiles / 8, r = ntiles % 8, x = bid % 8, i = bid / 8;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    const int x = bid % 8, i = bid / 8;
+    if (xcd_m > 0) {
+      const int sub_m = tiles_m / xcd_m, sub_n = tiles_n / (8 / xcd_m);
+      const int xm = x / (8 / xcd_m), xn = x % (8 / xcd_m);
+      tile_m = xm * sub_m + i / sub_n;
+      tile_n = xn * sub_n + i % sub_n;
+    } else {
+      const int q = ntiles / 8, r = ntiles % 8;
+      bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+      tile_m = bid / tiles_n;
+      tile_n = bid % tiles_n;
+    }
   }
-  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
   // split-K: blockIdx.y owns k in [kbeg, K) and writes a partial tile to ws[blockIdx.y][M][N]
   const int kbeg = blockIdx.y * k_per_split;
   const int K = min(Ktot, kbeg + k_per_split);
@@ -366,12 +382,27 @@ int launch_cfg(const float* A, long a_rs, long a_ks, const float* B, long b_rs, 
   const int b_vec = ((b_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
   const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN), ntiles = tiles_m * tiles_n;
   dim3 grid(ntiles, splits), block(256 * KG);
+  // XCD sub-block shape: xcd_m x (8/xcd_m) XCDs over the tile grid, minimising the per-XCD operand
+  // footprint  sub_m*BM*K (A panels) + sub_n*BN*K (B panels)
+  int xcd_m = 0;
+  {
+    double best = 1e30;
+    for (int xm = 1; xm <= 8; xm *= 2) {
+      const int xn = 8 / xm;
+      if (tiles_m % xm || tiles_n % xn) continue;
+      const double fp = (double)(tiles_m / xm) * BM + (double)(tiles_n / xn) * BN;
+      if (fp < best) {
+        best = fp;
+        xcd_m = xm;
+      }
+    }
+  }
   // branch-free loader preconditions (see load_fast)
   const bool fast = a_vec && b_vec && (K % 4 == 0) && K >= 4 && (a_kc || (M % 4 == 0 && M >= 4)) &&
                     (b_kc || (N % 4 == 0 && N >= 4));
 #define GO(F, AK, BKC)                                                                                   \
   hipLaunchKernelGGL((sgemm_kernel<BM, BN, BK, KG, PD, F, AK, BKC>), grid, block, 0, s, A, a_ld, B, b_ld, C, \
-                     ldc, bias, M, N, K, accumulate, a_vec, b_vec, tiles_n, ntiles, kps, ws)
+                     ldc, bias, M, N, K, accumulate, a_vec, b_vec, tiles_n, ntiles, kps, ws, tiles_m, xcd_m)
   if (fast) {
     if (a_kc && b_kc) GO(true, true, true);
     else if (a_kc && !b_kc) GO(true, true, false);
