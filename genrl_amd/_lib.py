@@ -19,7 +19,7 @@ def parse_header(path=HEADER):
     for m in re.finditer(r'\b(int|long)\s+(genrl_\w+)\s*\(([^)]*)\)\s*;', src):
         ret, name, args = m.group(1), m.group(2), m.group(3)
         al = []
-        for a in [x.strip() for x in args.split(',') if x.strip()]:
+        for a in [x.strip() for x in args.split(',') if x.strip() and x.strip() != 'void']:
             if '*' in a:
                 al.append((ctypes.c_void_p, a.split('*')[-1].strip()))
             else:
