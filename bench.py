@@ -96,6 +96,9 @@ def main():
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--dump-gemm', default='')
     ap.add_argument('--no-overlap', action='store_true', help='keep the connector updates on the main stream')
+    ap.add_argument('--input', default='replay', choices=['replay', 'fixed'],
+                    help="replay: every step draws a fresh batch from the device-resident replay store "
+                         "(genrl_amd/replay.py, on-GPU window gather); fixed: one batch reused")
     ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
                     help='replay the iteration as captured hipGraphs (collectives stay eager between graphs)')
     args = ap.parse_args()
@@ -121,6 +124,16 @@ def main():
     full = synth_batch(B, T)
     batch = {k: v.to(dev) for k, v in dp.shard_batch({k: torch.from_numpy(v) for k, v in full.items()}, rank, world).items()}
     torch.manual_seed(1234 + rank)               # per-rank sampling noise
+    replay = None
+    if args.input == 'replay':
+        # device-resident store of synthetic episodes; each rank draws its own B/world windows per step
+        from genrl_amd.replay import DeviceReplay
+        specs = {k: (v.shape[2:], v.dtype) for k, v in full.items()}
+        replay = DeviceReplay(specs, T, 16 * 8 * T, device=dev, batch_size=B // world)
+        for i in range(16):
+            ep = synth_batch(1, 8 * T, seed=100 + i)
+            replay.store_episode({k: v[0] for k, v in ep.items()})
+        np.random.seed(4321 + rank)
 
     graphed = None
     if args.graph != 'off':
@@ -134,7 +147,14 @@ def main():
             graphed = None
             ag._imag_behavior._defer_slow_target = False
             torch.cuda.synchronize()
-    run_step = (lambda: graphed()) if graphed is not None else (lambda: one_step(ag, batch))
+    if replay is None:
+        run_step = (lambda: graphed()) if graphed is not None else (lambda: one_step(ag, batch))
+    elif graphed is not None:
+        def run_step():
+            replay.sample(out=graphed.static_batch)          # windows gathered straight into the graphs' inputs
+            return graphed()
+    else:
+        run_step = lambda: one_step(ag, replay.sample())
     for _ in range(args.warmup):
         mets = run_step()
     torch.cuda.synchronize()
@@ -159,7 +179,9 @@ def main():
         out = {'metric': 'world-model+imag update steps/sec (B32xL32x64x64x3)', 'value': sps, 'unit': 'steps/s',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * dt / args.steps,
                'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
-               'data': 'synthetic (seeded uint8 64x64 RGB replay, random-init weights, stub text embedding)',
+               'data': 'synthetic (seeded uint8 64x64 RGB replay, random-init weights, stub text embedding); '
+                       + ('fresh batch per step gathered on-GPU from a device-resident replay store' if replay is not None
+                          else 'one fixed batch'),
                'config': {'workload': 'configs[1]: full WM + 2x connector + imag-behaviour update, video_text_reward, '
                                       f'batch {B} x seq {T}, 64x64x3, horizon 16, A=10',
                           'global_batch': B, 'seq_len': T, 'parallelism': f'dp{world}',

@@ -181,3 +181,38 @@ int genrl_transpose_last2(const float* in, float* out, long B, int P, int C, voi
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Replay window gather (tools/replay.py:223-236): dst[b, t, :] = src[(start[b] + t) % ring_rows, :]
+// for rows of `row_bytes` bytes (the store is a ring of `ring_rows` steps; episodes may wrap).  One workgroup per (b, t) row; 16-byte lanes when the row size
+// and both bases allow, bytes otherwise.  Pure HBM copy (a B32xT32 batch of 64x64x3 frames is
+// 12.6 MB).
+namespace {
+__global__ __launch_bounds__(256) void gather_windows_kernel(const uint8_t* __restrict__ src, long row_bytes,
+                                                             const long* __restrict__ start, int T,
+                                                             long ring_rows, uint8_t* __restrict__ dst, int vec_ok) {
+  const long b = blockIdx.x / T, t = blockIdx.x % T;
+  const uint8_t* s = src + ((start[b] + t) % ring_rows) * row_bytes;
+  uint8_t* d = dst + (long)blockIdx.x * row_bytes;
+  if (vec_ok) {
+    const long nv = row_bytes >> 4;
+    for (long i = threadIdx.x; i < nv; i += 256)
+      reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+  } else {
+    for (long i = threadIdx.x; i < row_bytes; i += 256) d[i] = s[i];
+  }
+}
+}  // namespace
+
+extern "C" int genrl_gather_windows(const void* src, long row_bytes, long ring_rows, const long* start, int B, int T,
+                                    void* dst, void* stream) {
+  GENRL_ENTER();
+  if (B <= 0 || T <= 0 || row_bytes <= 0) return GENRL_OK;
+  if (ring_rows <= 0) return GENRL_EINVAL;
+  const int vec_ok = (row_bytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+  hipLaunchKernelGGL(gather_windows_kernel, dim3((unsigned)B * T), dim3(256), 0, (hipStream_t)stream,
+                     (const uint8_t*)src, row_bytes, start, T, ring_rows, (uint8_t*)dst, vec_ok);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}

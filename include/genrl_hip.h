@@ -105,6 +105,12 @@ int genrl_col2im_s2(const float* cols, const float* bias, float* out, int Nimg, 
                     int Ho_override, int Wo_override, int out_nchw, void* stream);
 int genrl_transpose_last2(const float* in, float* out, long B, int P, int C, void* stream);
 
+/* ---- replay window gather: ReplayBuffer.__iter__'s np.stack of (episode, t0..t0+T) slices + host-to-device
+ * copy (tools/replay.py:223-236) on a device-resident ring of ring_rows steps:
+ * dst[b,t,:] = src[(start[b]+t) % ring_rows,:] */
+int genrl_gather_windows(const void* src, long row_bytes, long ring_rows, const long* start, int B, int T, void* dst,
+                         void* stream);
+
 /* ---- Optimizer.__call__ (agent/dreamer_utils.py:892-932) on flat buffers */
 long genrl_sqnorm_ws_floats(long n);
 int genrl_grad_norm(const float* g, long n, float* norm_out, float* ws, float scale, void* stream);

@@ -110,3 +110,31 @@ def dreamer_tiny_overrides():
     r = dict(hidden=32, deter=32, stoch=4, discrete=4)
     return dict(rssm=r, reward_head=dict(units=32), actor=dict(units=32), critic=dict(units=32),
                 encoder=dict(cnn_depth=4), decoder=dict(cnn_depth=4))
+
+
+REPLAY_SPECS = {'observation': ((3, 16, 16), np.uint8), 'action': ((5,), np.float32), 'reward': ((1,), np.float32),
+                'discount': ((1,), np.float32), 'is_first': ((), bool), 'is_last': ((), bool),
+                'is_terminal': ((), bool), 'clip_video': ((24,), np.float32)}
+REPLAY_LENS = [23, 17, 40, 12, 31, 19, 27]
+
+
+def det_episode(i, length, specs=REPLAY_SPECS, seed=0):
+    """Synthetic episode i in the on-disk layout of tools/replay.py:save_episode (reward 1-D as envs emit it,
+    no 'discount' key, one extra key the loader must ignore)."""
+    g = _rng(f'episode{i}', seed)
+    ep = {}
+    for k, (shape, dt) in specs.items():
+        if k == 'discount':
+            continue
+        if dt == np.uint8:
+            ep[k] = g.integers(0, 256, (length,) + shape, dtype=np.uint8)
+        elif dt == bool:
+            ep[k] = np.zeros((length,), bool)
+        else:
+            ep[k] = g.standard_normal((length,) + shape).astype(np.float32)
+    ep['reward'] = ep['reward'].reshape(-1)
+    ep['is_first'][0] = True
+    ep['is_last'][-1] = True
+    ep['is_terminal'][-1] = bool(i % 2)
+    ep['extra_unused'] = g.standard_normal((length, 2)).astype(np.float32)
+    return ep
