@@ -5,6 +5,7 @@ import contextlib
 from collections import OrderedDict
 
 import numpy as np
+import os
 import torch
 import torch.nn as nn
 
@@ -257,10 +258,21 @@ class WorldModel(Module):  # ref :120-321
         head_w = torch.cat([policy._out._out.weight, policy._out._std.weight], 0)
         head_b = torch.cat([policy._out._out.bias, policy._out._std.bias], 0)
         raws = []
+        # training rollouts: the policy's H backward passes are batched into one over all H*N rows
+        tape = None
+        if (torch.is_grad_enabled() and head_w.requires_grad and horizon > 1 and policy._norm != 'none'
+                and not os.environ.get('GENRL_NO_ACTOR_TAPE')):
+            layers = [(getattr(policy, f'dense{i}').weight, getattr(policy, f'dense{i}').bias,
+                       getattr(policy, f'norm{i}')._layer.weight, getattr(policy, f'norm{i}')._layer.bias,
+                       getattr(policy, f'norm{i}')._layer.eps) for i in range(policy._layers)]
+            tape = ops.ActorTape(horizon, N, layers, head_w, head_b, dev)
         for h in range(horizon):
             stoch, deter = seq['stoch'][-1], seq['deter'][-1]
             s_flat = stoch.reshape(N, -1)
-            raw = ops.linear(policy.trunk(stop_gradient(s_flat), stop_gradient(deter)), head_w, head_b)
+            if tape is not None:
+                raw = tape.step(h, stop_gradient(s_flat), stop_gradient(deter))
+            else:
+                raw = ops.linear(policy.trunk(stop_gradient(s_flat), stop_gradient(deter)), head_w, head_b)
             raws.append(raw)
             if eval_policy:
                 action = ops.actor_mean_std(raw, policy._out._min_std, policy._out._max_std)[0]
@@ -273,6 +285,8 @@ class WorldModel(Module):  # ref :120-321
             for key, value in dict(stoch=stoch, deter=deter, logit=logit, action=action).items():
                 seq[key].append(value)
         seq = {k: torch.stack(v, 0) for k, v in seq.items()}
+        if tape is not None:     # layer-0 inputs of all steps = the stacked rollout states (no copies)
+            tape.inputs = (seq['stoch'].detach().reshape(horizon + 1, N, -1), seq['deter'].detach())
         # policy outputs at states 0..H-1 — exactly what ActorCritic.actor_loss re-evaluates for its
         # entropy metric (agent/dreamer.py:397: actor(sg(feat[:-2]))): kept to avoid a second forward
         self._last_actor_raw = torch.stack(raws, 0)          # (H, N, 2A), attached to the actor's graph

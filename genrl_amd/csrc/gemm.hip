@@ -36,6 +36,13 @@
 // row-panel in that XCD's private L2).
 #include "common.h"
 
+#ifdef GENRL_DBG_TIMING
+// per-wave phase cycle counts of the most recent launch: [slot = (block*16 + wave) % 65536][6]
+__device__ unsigned long long genrl_dbg_cycles[65536 * 6];
+extern "C" void genrl_dbg_read(unsigned long long* out, int nslots) {
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(genrl_dbg_cycles), sizeof(unsigned long long) * 6 * nslots);
+}
+#endif
 namespace {
 
 template <int BM, int BN, int BK, int KG, int PD, bool FAST, bool A_KC, bool B_KC>
@@ -227,23 +234,57 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(
   // Software pipeline (register stages alternate, LDS double-buffered, one barrier per BK):
   //   step kt: issue global loads of tile kt+2 | MFMA on LDS[kt&1] | registers(tile kt+1) -> LDS[(kt+1)&1]
   // so a global load has a whole step plus an MFMA phase to land before it is consumed.
+#ifdef GENRL_DBG_TIMING
+  long long tacc[6] = {0, 0, 0, 0, 0, 0};
+  long long tlast = __builtin_readcyclecounter();
+#define TICK(i)                                        \
+  {                                                    \
+    const long long now__ = __builtin_readcyclecounter(); \
+    tacc[i] += now__ - tlast;                          \
+    tlast = now__;                                     \
+  }
+#else
+#define TICK(i)
+#endif
   if (PD == 2) {
     fetch(0, 0);                  // both leading tiles are requested back-to-back: one exposed
     if (nk > 1) fetch(1, 1);      // memory latency in the prologue instead of two
     stage(0, 0);
     __syncthreads();
+    TICK(4);
     for (int kt = 0; kt < nk; kt += 2) {
-      // LDS[0] holds tile kt, register stage 1 holds tile kt+1
+      // LDS[0] holds tile kt, register stage 1 holds tile kt+1.  The next global loads are issued
+      // AFTER this step's MFMAs are queued: right after the barrier every wave of the workgroup
+      // would hit the CU's single address unit at once (32 KB per step = 512 issue cycles) with the
+      // MFMA pipe idle; behind the MFMAs the waves arrive staggered and the issue is hidden.
+#ifdef GENRL_FETCH_EARLY
       if (kt + 2 < nk) fetch(0, kt + 2);
+#endif
+      TICK(0);
       compute(0);
+      TICK(1);
+#ifndef GENRL_FETCH_EARLY
+      if (kt + 2 < nk) fetch(0, kt + 2);
+#endif
       if (kt + 1 < nk) stage(1, 1);
+      TICK(2);
       __syncthreads();
+      TICK(3);
       if (kt + 1 >= nk) break;
       // LDS[1] holds tile kt+1, register stage 0 holds tile kt+2
+#ifdef GENRL_FETCH_EARLY
       if (kt + 3 < nk) fetch(1, kt + 3);
+#endif
+      TICK(0);
       compute(1);
+      TICK(1);
+#ifndef GENRL_FETCH_EARLY
+      if (kt + 3 < nk) fetch(1, kt + 3);
+#endif
       if (kt + 2 < nk) stage(0, 0);
+      TICK(2);
       __syncthreads();
+      TICK(3);
     }
   } else {   // one tile ahead (fewer registers: keeps the 128x128 shape at 3 waves/SIMD)
     fetch(0, 0);
@@ -322,6 +363,13 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(
         }
       }
     }
+#ifdef GENRL_DBG_TIMING
+  TICK(5);
+  if (lane == 0) {
+    const int slot = ((blockIdx.y * gridDim.x + blockIdx.x) * (int)(blockDim.x >> 6) + wave) & 65535;
+    for (int i = 0; i < 6; ++i) genrl_dbg_cycles[slot * 6 + i] = (unsigned long long)tacc[i];
+  }
+#endif
 }
 
 // C[m,n] = sum_s ws[s][m][n] (+bias[n]) (+C[m,n])
@@ -336,6 +384,106 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __rest
   if (bias) s += bias[n];
   float* c = C + (long)m * ldc + n;
   *c = accumulate ? *c + s : s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Skinny-M GEMM (M <= 32, A k-contiguous): the recurrent h W_h^T / dpre W_h products of the RSSM
+// scans (M = sequences per GPU) and the other few-row products.  These are weight streams, not
+// MFMA work: a 64-row tile would be >= 50 % padding and needs split-K + a reduce launch to fill the
+// chip.  Here a workgroup owns 16 output columns, its 16 waves split K, every lane feeds
+// v_mfma_f32_16x16x4_f32 straight from global memory (16-byte loads along k, no LDS staging) and
+// the 16 partial 16x16 blocks are summed through LDS in a fixed order (deterministic).
+// MFMA 16x16x4 operand layout: A[i = lane%16][k = lane/16], B[k = lane/16][j = lane%16],
+// D[i = 4*(lane/16) + v][j = lane%16].  A lane loads 4 consecutive k at kbase + 4*(lane/16); the e-th
+// MFMA then multiplies k = {kbase + 4q + e} on both operands, so any k pairing is consistent.
+template <int MB, bool B_KC>
+__global__ __launch_bounds__(1024) void skinny_kernel(const float* __restrict__ A, long a_ld,
+                                                      const float* __restrict__ B, long b_ld,
+                                                      float* __restrict__ C, long ldc,
+                                                      const float* __restrict__ bias, int M, int N, int K,
+                                                      int accumulate, int vec) {
+  constexpr int NW = 16;
+  __shared__ float red[NW][MB][4][64];
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, q = l >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int col = min(n0 + li, N - 1);
+  f32x4 acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* arow[MB];
+  bool rok[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int r = li + 16 * mb;
+    rok[mb] = r < M;
+    arow[mb] = A + (long)min(r, M - 1) * a_ld;
+  }
+  const int kchunks = (K + 15) >> 4;
+  const int cpw = (kchunks + NW - 1) / NW;
+  const int c0 = w * cpw, c1 = min(c0 + cpw, kchunks);
+  const int kfull = K >> 4;   // chunks entirely inside K
+  auto body = [&](int c, bool guarded) {
+    const int k = (c << 4) + 4 * q;
+    float4 a[MB], b;
+    if (!guarded && vec) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) a[mb] = *reinterpret_cast<const float4*>(arow[mb] + k);
+      if (B_KC) {
+        b = *reinterpret_cast<const float4*>(B + (long)col * b_ld + k);
+      } else {
+        const float* bp = B + (long)k * b_ld + col;
+        b.x = bp[0]; b.y = bp[b_ld]; b.z = bp[2 * b_ld]; b.w = bp[3 * b_ld];
+      }
+    } else {
+      float av[MB][4], bv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = k + e < K;
+        const int kk = ok ? k + e : 0;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) av[mb][e] = ok ? arow[mb][kk] : 0.f;
+        bv[e] = ok ? (B_KC ? B[(long)col * b_ld + kk] : B[(long)kk * b_ld + col]) : 0.f;
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) a[mb] = make_float4(av[mb][0], av[mb][1], av[mb][2], av[mb][3]);
+      b = make_float4(bv[0], bv[1], bv[2], bv[3]);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+      if (!rok[mb]) a[mb] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].x, b.x, acc[mb], 0, 0, 0);
+      acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].y, b.y, acc[mb], 0, 0, 0);
+      acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].z, b.z, acc[mb], 0, 0, 0);
+      acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].w, b.w, acc[mb], 0, 0, 0);
+    }
+  };
+  const int cfast = min(c1, kfull);
+  int c = c0;
+#pragma unroll 4
+  for (; c < cfast; ++c) body(c, false);
+  for (; c < c1; ++c) body(c, true);
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) red[w][mb][v][l] = acc[mb][v];
+  __syncthreads();
+  // thread t -> output (row r = t/16, column n0 + t%16): 64-byte row segments
+  const int t = threadIdx.x;
+  if (t < MB * 256) {
+    const int r = t >> 4, cj = t & 15, mb = r >> 4, rr = r & 15;
+    const int lane = (rr >> 2) * 16 + cj, v = rr & 3;
+    float sum = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) sum += red[ww][mb][v][lane];
+    const int oc = n0 + cj;
+    if (r < M && oc < N) {
+      if (bias) sum += bias[oc];
+      float* cp = C + (long)r * ldc + oc;
+      *cp = accumulate ? *cp + sum : sum;
+    }
+  }
 }
 
 #ifndef GENRL_SMALL_PD
@@ -427,6 +575,7 @@ extern "C" void genrl_set_last_error(int code) { g_last_error = code; }
 extern "C" const char* genrl_last_error(void) { return hipGetErrorString((hipError_t)g_last_error); }
 
 extern "C" long genrl_sgemm_ws_floats(int M, int N, int K) {
+  // (the skinny path (M <= 32, A k-contiguous) needs none; the stride-agnostic answer stays an upper bound)
   if ((long)cdiv(M, 128) * cdiv(N, 128) >= 512) return 0;
   const SplitPlan p = plan_split(M, N, K);
   return p.splits > 1 ? (long)p.splits * M * N : 0;
@@ -439,6 +588,22 @@ extern "C" int genrl_sgemm(const float* A, long a_rs, long a_ks, const float* B,
   if (M <= 0 || N <= 0) return GENRL_OK;
   if (K <= 0 || (a_rs != 1 && a_ks != 1) || (b_rs != 1 && b_ks != 1)) return GENRL_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
+#ifndef GENRL_NO_SKINNY
+  if (M <= 32 && a_ks == 1) {
+    const bool b_kc = (b_ks == 1);
+    const long b_ld = b_kc ? b_rs : b_ks;
+    const int vec = ((a_rs & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                    (!b_kc || (((b_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0)));
+    dim3 grid(cdiv(N, 16)), block(1024);
+#define GO(MB, BKC) \
+  hipLaunchKernelGGL((skinny_kernel<MB, BKC>), grid, block, 0, s, A, a_rs, B, b_ld, C, ldc, bias, M, N, K, accumulate, vec)
+    if (M <= 16) { if (b_kc) GO(1, true); else GO(1, false); }
+    else { if (b_kc) GO(2, true); else GO(2, false); }
+#undef GO
+    GENRL_CHECK_LAUNCH();
+    return GENRL_OK;
+  }
+#endif
   const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
   if (t128 >= 512)
     return launch_cfg<128, 128, GENRL_BIG_BK, GENRL_BIG_KG, 1>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, 1, K,

@@ -1,0 +1,25 @@
+#!/bin/bash
+# kernel-trace summary of bench.py at a given per-GPU batch: top kernels by time, launch count, busy vs wall
+# usage: scripts/prof_batch.sh <batch> [extra bench args]
+B=$1; shift
+cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -o b -- python bench.py --batch $B --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-profile "$@" > gpurun_out/prof_b${B}.log 2>&1
+tail -1 gpurun_out/prof_b${B}.log | cut -c1-200
+python - $B <<'PY'
+import csv, sys, collections
+rows = list(csv.DictReader(open("/tmp/kt/b_kernel_trace.csv")))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# keep the last 10 steps' worth: take the last 60% of launches as the steady state
+n = len(rows); rows = rows[int(n * 0.5):]
+t0 = int(rows[0]["Start_Timestamp"]); t1 = int(rows[-1]["End_Timestamp"])
+agg = collections.defaultdict(lambda: [0, 0.0])
+busy = 0.0
+for r in rows:
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:90]
+    agg[name][0] += 1; agg[name][1] += d; busy += d
+print(f"launches {len(rows)}  wall {1e-6*(t1-t0):.1f} ms  sum-of-kernels {busy/1e3:.1f} ms  ({100*busy/1e3/(1e-6*(t1-t0)):.0f}% incl. overlap)")
+for name, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
+    print(f"{d/1e3:8.2f} ms {c:6d} x {d/c:7.1f} us  {name}")
+PY

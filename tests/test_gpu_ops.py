@@ -66,6 +66,28 @@ def test_sgemm_exact_layout(ops):
     assert torch.equal(C.cpu(), 2 * (A @ B.T))
 
 
+@pytest.mark.parametrize('M', [1, 4, 16, 17, 32])
+@pytest.mark.parametrize('N,K', [(10, 8), (16, 520), (1000, 1034), (3072, 1024), (1024, 3073), (33, 5)])
+def test_sgemm_skinny(ops, M, N, K):
+    """M <= 32 with k-contiguous A takes the MFMA-16x16x4 weight-stream kernel: both B layouts,
+    bias + accumulate, ragged K/N, exact on small integers and close on random data."""
+    A = (torch.arange(M * K, dtype=torch.float32).reshape(M, K) % 7 - 3)
+    B = ((torch.arange(N * K, dtype=torch.float32).reshape(N, K) * 3) % 5 - 2)
+    bias = torch.arange(N, dtype=torch.float32) % 3
+    C = torch.full((M, N), 2.0, device='cuda')
+    ops.sgemm(A.cuda(), K, 1, B.cuda(), K, 1, C, N, bias.cuda(), M, N, K, accumulate=True)      # B k-contiguous
+    want = A.double() @ B.double().T + bias.double() + 2.0
+    assert torch.equal(C.cpu().double(), want)
+    Bt = B.T.contiguous().cuda()                                                                 # B row-contiguous
+    C2 = torch.empty(M, N, device='cuda')
+    ops.sgemm(A.cuda(), K, 1, Bt, 1, N, C2, N, None, M, N, K)
+    assert torch.equal(C2.cpu().double(), A.double() @ B.double().T)
+    Ar = torch.randn(M, K, generator=g(1)); Br = torch.randn(N, K, generator=g(2))
+    C3 = torch.empty(M, N, device='cuda')
+    ops.sgemm(Ar.cuda(), K, 1, Br.cuda(), K, 1, C3, N, None, M, N, K)
+    np.testing.assert_allclose(C3.cpu().numpy(), (Ar.double() @ Br.double().T).numpy(), rtol=1e-4, atol=1e-4 * K ** 0.5)
+
+
 @pytest.mark.parametrize('M,N,act', [(5, 32, 1), (300, 1024, 1), (64, 3072, 0), (33, 48, 1)])
 def test_ln_act(ops, M, N, act):
     x = torch.randn(M, N, generator=g(1)) * 2 + 0.3
