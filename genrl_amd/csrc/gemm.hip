@@ -499,24 +499,68 @@ __global__ __launch_bounds__(1024) void skinny_kernel(const float* __restrict__ 
 #endif
 constexpr int SMALL_BK = GENRL_SMALL_BK, SMALL_KG = GENRL_SMALL_KG;
 
-// Split-K plan for the 64x64 configuration: only outputs with too few tiles to give every CU a
-// workgroup split the reduction over blockIdx.y.
+// Launch plan: tile configuration + split-K count, from a small cost model.  All workgroups of a
+// launch do equal work, so they run in ceil(WGs / slots) rounds: a WG count just above a multiple of
+// the slot count wastes most of a round, and tile padding (M = 96 -> 2 x 64 or 1 x 128 rows) wastes
+// MFMA work.  The conv weight-gradient products (2-54 small tiles, K ~ 1e5-1e6) lost up to 50 % to
+// this with a "enough workgroups" rule.  Costs in us; constants from the K sweeps in profiles/.
+//   small: 64x64 tile, 1024 threads, one WG per CU (256 slots), 17.8 ns per k per WG
+//   big  : 128x128 tile, 256 threads, up to 3 WGs per CU (768 slots) sharing the CU's MFMA rate
 struct SplitPlan {
-  int splits, k_per_split;
+  int big, splits, k_per_split;
 };
+inline double reduce_cost(long sp, long M, long N) { return sp > 1 ? 5.0 + (double)sp * M * N * 4.0 / 3.0e6 : 0.0; }
 inline SplitPlan plan_split(int M, int N, int K) {
+  static const char* force = getenv("GENRL_GEMM_FORCE");   // calibration only: "s,<splits>" / "b,<splits>"
   const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
-  SplitPlan p{1, K};
-  if (tiles >= 192 || K < 1024) return p;
-  long s = cdiv(512, tiles);
-  // at least 512 k (8 BK-steps) per split; very tile-starved launches (the M=32 steps of the RSSM
-  // scans, N=10/20 heads) are latency-bound weight streams: more, shorter splits (>= 128 k)
-  const long smax = tiles <= 64 ? K / 128 : K / 512;
-  if (s > smax) s = smax;
-  if (s <= 1) return p;
-  int kps = cdiv(cdiv(K, s), SMALL_BK) * SMALL_BK;
-  p.k_per_split = kps;
-  p.splits = cdiv(K, kps);
+  const long tiles_b = (long)cdiv(M, 128) * cdiv(N, 128);
+  SplitPlan p{tiles_b >= 512, 1, K};
+  if (force) {
+    p.big = force[0] == 'b';
+    const long s = atol(force + 2);
+    const int bk = p.big ? GENRL_BIG_BK : SMALL_BK;
+    p.k_per_split = cdiv(cdiv(K, s > 0 ? s : 1), bk) * bk;
+    p.splits = cdiv(K, p.k_per_split);
+    return p;
+  }
+  if (p.big || K < 1024) return p;
+  double best = 1e30;
+  // ---- small configuration
+  {
+    const double t_fixed = 5.0, t_k = 0.0178;
+    const long smax = tiles >= 192 ? 1 : (tiles <= 64 ? K / 128 : K / 512);
+    for (long s = 1; s <= smax && s <= 512; ++s) {
+      const long kps = (long)cdiv(cdiv(K, s), SMALL_BK) * SMALL_BK;
+      const long sp = cdiv(K, kps);
+      const long rounds = cdiv(tiles * sp, 256);
+      const double t = rounds * (t_fixed + kps * t_k) + reduce_cost(sp, M, N);
+      if (t < best - 1e-9) {
+        best = t;
+        p = SplitPlan{0, (int)sp, (int)kps};
+      }
+    }
+    if (smax < 1) best = cdiv(tiles, 256) * (t_fixed + K * t_k), p = SplitPlan{0, 1, K};
+  }
+#ifndef GENRL_NO_BIG_SPLIT
+  // ---- big configuration with split-K (few output tiles, long K)
+  if (K >= 2048) {
+    const double t_fixed = 6.0, t_k = 0.067;
+    for (long s = 1; s <= K / 512 && s <= 1024; ++s) {
+      const long kps = (long)cdiv(cdiv(K, s), 64) * 64;
+      const long sp = cdiv(K, kps);
+      const long wgs = tiles_b * sp;
+      const long rounds = cdiv(wgs, 768);
+      const long per_cu = wgs >= 768 ? 3 : cdiv(wgs, 256);          // co-resident WGs share the MFMA pipes
+      const double lat = per_cu == 1 ? 1.4 : (per_cu == 2 ? 1.1 : 1.0);   // fewer waves hide less latency
+      const double t = rounds * (t_fixed + kps * t_k * per_cu * lat) + reduce_cost(sp, M, N);
+      if (t < best - 1e-9) {
+        best = t;
+        p = SplitPlan{1, (int)sp, (int)kps};
+      }
+    }
+  }
+#endif
+  if (p.splits <= 1) p.splits = 1, p.k_per_split = K;
   return p;
 }
 
@@ -576,7 +620,6 @@ extern "C" const char* genrl_last_error(void) { return hipGetErrorString((hipErr
 
 extern "C" long genrl_sgemm_ws_floats(int M, int N, int K) {
   // (the skinny path (M <= 32, A k-contiguous) needs none; the stride-agnostic answer stays an upper bound)
-  if ((long)cdiv(M, 128) * cdiv(N, 128) >= 512) return 0;
   const SplitPlan p = plan_split(M, N, K);
   return p.splits > 1 ? (long)p.splits * M * N : 0;
 }
@@ -604,21 +647,20 @@ extern "C" int genrl_sgemm(const float* A, long a_rs, long a_ks, const float* B,
     return GENRL_OK;
   }
 #endif
-  const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
-  if (t128 >= 512)
-    return launch_cfg<128, 128, GENRL_BIG_BK, GENRL_BIG_KG, 1>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, 1, K,
-                                       nullptr, s);
-  const SplitPlan p = plan_split(M, N, K);
-  if (p.splits > 1 && ws && ws_floats >= (long)p.splits * M * N) {
-    int rc = launch_cfg<64, 64, SMALL_BK, SMALL_KG, GENRL_SMALL_PD>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate,
-                                                    p.splits, p.k_per_split, ws, s);
-    if (rc) return rc;
-    const long MN = (long)M * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(MN, 256)), dim3(256), 0, s, ws, C, ldc, bias, M, N, p.splits,
-                       accumulate);
-    GENRL_CHECK_LAUNCH();
-    return GENRL_OK;
-  }
-  return launch_cfg<64, 64, SMALL_BK, SMALL_KG, GENRL_SMALL_PD>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, 1, K,
-                                                nullptr, s);
+  SplitPlan p = plan_split(M, N, K);
+  const bool split = p.splits > 1 && ws && ws_floats >= (long)p.splits * M * N;
+  if (!split) p.splits = 1, p.k_per_split = K;
+  float* wsp = split ? ws : nullptr;
+  int rc;
+  if (p.big)
+    rc = launch_cfg<128, 128, GENRL_BIG_BK, GENRL_BIG_KG, 1>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate,
+                                                            p.splits, p.k_per_split, wsp, s);
+  else
+    rc = launch_cfg<64, 64, SMALL_BK, SMALL_KG, GENRL_SMALL_PD>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K,
+                                                               accumulate, p.splits, p.k_per_split, wsp, s);
+  if (rc || !split) return rc;
+  const long MN = (long)M * N;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(MN, 256)), dim3(256), 0, s, ws, C, ldc, bias, M, N, p.splits, accumulate);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
 }
