@@ -45,12 +45,31 @@ extern "C" void genrl_dbg_read(unsigned long long* out, int nslots) {
 #endif
 namespace {
 
-template <int BM, int BN, int BK, int KG, int PD, bool FAST, bool A_KC, bool B_KC>
+// Implicit stride-2 convolution operand (no materialised patch matrix): the logical row of pixel
+// m = (n, oy, ox) is the k x k x C patch of an NHWC image, i.e. k segments of seg_len = k*C
+// contiguous floats, seg_stride = W*C apart, starting at n*sn + oy*sy + ox*sx.  Element (m, kk) lives
+// at base(m) + (kk / seg_len) * seg_stride + kk % seg_len.  G = 1: the A operand (k-contiguous, rows
+// = pixels) is such a patch matrix; G = 2: the B operand of an 'rr' product (k index = pixel,
+// n index = kk) is.  Divisions use a float reciprocal + one correction step (operands < 2^24).
+struct Gather {
+  int seg_len, seg_stride, ow, ohw, sn, sy, sx;
+  float inv_seg, inv_ow, inv_ohw;
+};
+__device__ __forceinline__ int fdiv(int x, int d, float inv) {
+  int q = (int)((float)x * inv);
+  const int r = x - q * d;
+  q += (r >= d) ? 1 : 0;
+  q -= (r < 0) ? 1 : 0;
+  return q;
+}
+
+template <int BM, int BN, int BK, int KG, int PD, bool FAST, bool A_KC, bool B_KC, int G = 0>
 __global__ __launch_bounds__(256 * KG) void sgemm_kernel(
     const float* __restrict__ A, long a_ld, const float* __restrict__ B, long b_ld,
     float* __restrict__ C, long ldc, const float* __restrict__ bias, int M, int N, int Ktot,
     int accumulate, int a_vec, int b_vec, int tiles_n, int ntiles, int k_per_split, float* __restrict__ ws,
-    int tiles_m, int xcd_m) {
+    int tiles_m, int xcd_m, Gather g) {
+  static_assert(G == 0 || (FAST && ((G == 1 && A_KC && B_KC) || (G == 2 && !A_KC && !B_KC))), "gather variants");
   constexpr int NT = 256 * KG;
   // k-contiguous operands are written to LDS with scalar (transposing) stores: an odd leading
   // dimension keeps those at <= 2-way bank conflicts; row-contiguous operands use 16-B stores.
@@ -152,21 +171,32 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(
   // outside the matrix (K % 4 == 0; row counts of row-contiguous operands % 4 == 0).  The load is then
   // unconditional from a clamped (always valid) address and zeroed by a select: no divergent branch,
   // so hipcc keeps the prefetched tiles in flight with counted vmcnt waits instead of vmcnt(0).
+  auto gbase = [&](int m) -> long {
+    const int n = fdiv(m, g.ohw, g.inv_ohw), r = m - n * g.ohw;
+    const int oy = fdiv(r, g.ow, g.inv_ow), ox = r - oy * g.ow;
+    return (long)n * g.sn + (long)oy * g.sy + (long)ox * g.sx;
+  };
+  auto gseg = [&](int kk) -> long {
+    const int sgi = fdiv(kk, g.seg_len, g.inv_seg);
+    return (long)sgi * g.seg_stride + (kk - sgi * g.seg_len);
+  };
   auto load_fast = [&](const float* __restrict__ P, long ld, int rows_total, int r0, int k0, bool kc, int bdim,
-                       float4& out, int v) -> bool {
+                       float4& out, int v, bool gath) -> bool {
     float4 o;
     bool inb;
     if (kc) {
       const int row = r0 + v / (BK / 4), k = k0 + ((v % (BK / 4)) << 2);
       inb = k < K;                                         // rows beyond M/N only feed unstored outputs
       const int rc = min(row, rows_total - 1), kc_ = min(k, Ktot - 4);
-      o = *reinterpret_cast<const float4*>(P + (long)rc * ld + kc_);
+      if (gath) o = *reinterpret_cast<const float4*>(P + gbase(rc) + gseg(kc_));
+      else o = *reinterpret_cast<const float4*>(P + (long)rc * ld + kc_);
     } else {
       const int per = bdim >> 2;
       const int k = k0 + v / per, row = r0 + ((v % per) << 2);
       inb = (k < K) && (row < rows_total);
       const int kc_ = min(k, Ktot - 1), rc = min(row, rows_total - 4);
-      o = *reinterpret_cast<const float4*>(P + (long)kc_ * ld + rc);
+      if (gath) o = *reinterpret_cast<const float4*>(P + gbase(kc_) + gseg(rc));
+      else o = *reinterpret_cast<const float4*>(P + (long)kc_ * ld + rc);
     }
     out = o;          // raw; zeroing by `inb` happens when the registers are staged into LDS, so
     return inb;       // that nothing consumes the load result while it is in flight
@@ -190,12 +220,12 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(
   auto fetch = [&](int s, int kt) {      // global -> register stage s
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
-      if (FAST) ia[s][i] = load_fast(A, a_ld, M, m0, kbeg + kt * BK, A_KC, BM, ra[s][i], tid + i * NT);
+      if (FAST) ia[s][i] = load_fast(A, a_ld, M, m0, kbeg + kt * BK, A_KC, BM, ra[s][i], tid + i * NT, G == 1);
       else load_tile(A, a_ld, a_vec, M, m0, kbeg + kt * BK, A_KC, BM, ra[s][i], tid + i * NT);
     }
 #pragma unroll
     for (int i = 0; i < BV; ++i) {
-      if (FAST) ib[s][i] = load_fast(B, b_ld, N, n0, kbeg + kt * BK, B_KC, BN, rb[s][i], tid + i * NT);
+      if (FAST) ib[s][i] = load_fast(B, b_ld, N, n0, kbeg + kt * BK, B_KC, BN, rb[s][i], tid + i * NT, G == 2);
       else load_tile(B, b_ld, b_vec, N, n0, kbeg + kt * BK, B_KC, BN, rb[s][i], tid + i * NT);
     }
   };
@@ -544,7 +574,7 @@ inline SplitPlan plan_split(int M, int N, int K) {
 #ifndef GENRL_NO_BIG_SPLIT
   // ---- big configuration with split-K (few output tiles, long K)
   if (K >= 2048) {
-    const double t_fixed = 6.0, t_k = 0.067;
+    const double t_fixed = 6.0, t_k = 0.060;   // (sustained long-K rate is a little better than the 64x64 tile)
     for (long s = 1; s <= K / 512 && s <= 1024; ++s) {
       const long kps = (long)cdiv(cdiv(K, s), 64) * 64;
       const long sp = cdiv(K, kps);
@@ -567,11 +597,18 @@ inline SplitPlan plan_split(int M, int N, int K) {
 template <int BM, int BN, int BK, int KG, int PD>
 int launch_cfg(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks, float* C,
                long ldc, const float* bias, int M, int N, int K, int accumulate, int splits, int kps, float* ws,
-               hipStream_t s) {
+               hipStream_t s, int G = 0, const Gather* gp = nullptr) {
   const bool a_kc = (a_ks == 1), b_kc = (b_ks == 1);
   const long a_ld = a_kc ? a_rs : a_ks, b_ld = b_kc ? b_rs : b_ks;
-  const int a_vec = ((a_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-  const int b_vec = ((b_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  int a_vec = ((a_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  int b_vec = ((b_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  Gather g{};
+  if (G) {
+    g = *gp;
+    const int ok = ((g.seg_len | g.seg_stride | g.sn | g.sy | g.sx) & 3) == 0;
+    if (G == 1) a_vec = ok && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    else b_vec = ok && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  }
   const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN), ntiles = tiles_m * tiles_n;
   dim3 grid(ntiles, splits), block(256 * KG);
   // XCD sub-block shape: xcd_m x (8/xcd_m) XCDs over the tile grid, minimising the per-XCD operand
@@ -590,12 +627,21 @@ int launch_cfg(const float* A, long a_rs, long a_ks, const float* B, long b_rs, 
     }
   }
   // branch-free loader preconditions (see load_fast)
-  const bool fast = a_vec && b_vec && (K % 4 == 0) && K >= 4 && (a_kc || (M % 4 == 0 && M >= 4)) &&
+  const bool k4 = (K % 4 == 0) && K >= 4;     // only k-contiguous operands vectorise along k
+  const bool fast = a_vec && b_vec && ((!a_kc && !b_kc) || k4) && (a_kc || (M % 4 == 0 && M >= 4)) &&
                     (b_kc || (N % 4 == 0 && N >= 4));
 #define GO(F, AK, BKC)                                                                                   \
   hipLaunchKernelGGL((sgemm_kernel<BM, BN, BK, KG, PD, F, AK, BKC>), grid, block, 0, s, A, a_ld, B, b_ld, C, \
-                     ldc, bias, M, N, K, accumulate, a_vec, b_vec, tiles_n, ntiles, kps, ws, tiles_m, xcd_m)
-  if (fast) {
+                     ldc, bias, M, N, K, accumulate, a_vec, b_vec, tiles_n, ntiles, kps, ws, tiles_m, xcd_m, g)
+  if (G) {     // implicit-conv operands exist only for the branch-free loaders
+    if (!fast || (G == 1 && !(a_kc && b_kc)) || (G == 2 && (a_kc || b_kc))) return GENRL_EINVAL;
+    if (G == 1)
+      hipLaunchKernelGGL((sgemm_kernel<BM, BN, BK, KG, PD, true, true, true, 1>), grid, block, 0, s, A, a_ld, B, b_ld,
+                         C, ldc, bias, M, N, K, accumulate, a_vec, b_vec, tiles_n, ntiles, kps, ws, tiles_m, xcd_m, g);
+    else
+      hipLaunchKernelGGL((sgemm_kernel<BM, BN, BK, KG, PD, true, false, false, 2>), grid, block, 0, s, A, a_ld, B, b_ld,
+                         C, ldc, bias, M, N, K, accumulate, a_vec, b_vec, tiles_n, ntiles, kps, ws, tiles_m, xcd_m, g);
+  } else if (fast) {
     if (a_kc && b_kc) GO(true, true, true);
     else if (a_kc && !b_kc) GO(true, true, false);
     else if (!a_kc && b_kc) GO(true, false, true);
@@ -624,15 +670,15 @@ extern "C" long genrl_sgemm_ws_floats(int M, int N, int K) {
   return p.splits > 1 ? (long)p.splits * M * N : 0;
 }
 
-extern "C" int genrl_sgemm(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks,
-                           float* C, long ldc, const float* bias, int M, int N, int K,
-                           int accumulate, float* ws, long ws_floats, void* stream) {
+static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks,
+                      float* C, long ldc, const float* bias, int M, int N, int K,
+                      int accumulate, float* ws, long ws_floats, void* stream, int G, const Gather* gp) {
   GENRL_ENTER();
   if (M <= 0 || N <= 0) return GENRL_OK;
   if (K <= 0 || (a_rs != 1 && a_ks != 1) || (b_rs != 1 && b_ks != 1)) return GENRL_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
 #ifndef GENRL_NO_SKINNY
-  if (M <= 32 && a_ks == 1) {
+  if (M <= 32 && a_ks == 1 && G == 0) {
     const bool b_kc = (b_ks == 1);
     const long b_ld = b_kc ? b_rs : b_ks;
     const int vec = ((a_rs & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
@@ -654,13 +700,42 @@ extern "C" int genrl_sgemm(const float* A, long a_rs, long a_ks, const float* B,
   int rc;
   if (p.big)
     rc = launch_cfg<128, 128, GENRL_BIG_BK, GENRL_BIG_KG, 1>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate,
-                                                            p.splits, p.k_per_split, wsp, s);
+                                                            p.splits, p.k_per_split, wsp, s, G, gp);
   else
     rc = launch_cfg<64, 64, SMALL_BK, SMALL_KG, GENRL_SMALL_PD>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K,
-                                                               accumulate, p.splits, p.k_per_split, wsp, s);
+                                                               accumulate, p.splits, p.k_per_split, wsp, s, G, gp);
   if (rc || !split) return rc;
   const long MN = (long)M * N;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(MN, 256)), dim3(256), 0, s, ws, C, ldc, bias, M, N, p.splits, accumulate);
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
+}
+
+extern "C" int genrl_sgemm(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks,
+                           float* C, long ldc, const float* bias, int M, int N, int K,
+                           int accumulate, float* ws, long ws_floats, void* stream) {
+  return sgemm_impl(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, ws, ws_floats, stream, 0, nullptr);
+}
+
+extern "C" int genrl_sgemm_conv(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks,
+                                float* C, long ldc, const float* bias, int M, int N, int K, int accumulate,
+                                float* ws, long ws_floats, int which, int img_h, int img_w, int img_c, int ksize,
+                                void* stream) {
+  if ((which != 1 && which != 2) || ksize <= 0 || img_h < ksize || img_w < ksize) return GENRL_EINVAL;
+  const int oh = (img_h - ksize) / 2 + 1, ow = (img_w - ksize) / 2 + 1;
+  Gather g;
+  g.seg_len = ksize * img_c;
+  g.seg_stride = img_w * img_c;
+  g.ow = ow;
+  g.ohw = oh * ow;
+  g.sn = img_h * img_w * img_c;
+  g.sy = 2 * img_w * img_c;
+  g.sx = 2 * img_c;
+  g.inv_seg = 1.0f / (float)g.seg_len;
+  g.inv_ow = 1.0f / (float)g.ow;
+  g.inv_ohw = 1.0f / (float)g.ohw;
+  // the patch-matrix side must have the logical shape (pixels x k*k*C)
+  const long pixels = which == 1 ? M : K, kk = which == 1 ? K : N;
+  if (kk != (long)ksize * ksize * img_c || pixels % g.ohw != 0) return GENRL_EINVAL;
+  return sgemm_impl(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, ws, ws_floats, stream, which, &g);
 }

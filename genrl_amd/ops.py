@@ -1,6 +1,7 @@
 """torch.autograd bindings of the HIP kernels (libgenrl_hip.so).  PyTorch owns device memory,
 streams and the autograd graph; every flop of the hot path runs in the hand-written kernels.
 No CPU fallback: calling an op with a non-CUDA tensor raises."""
+import os
 import torch
 from torch.autograd import Function
 
@@ -93,6 +94,21 @@ def sgemm(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate=False,
     if gemm_profile is not None:
         e1 = torch.cuda.Event(enable_timing=True); e1.record()
         gemm_profile.append((M, N, K, e0, e1, ('k' if a_ks == 1 else 'r') + ('k' if b_ks == 1 else 'r')))
+
+
+def sgemm_conv(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, which, img, accumulate=False):
+    """sgemm with operand `which` (1 = A, 2 = B) read as the implicit stride-2 patch matrix of the NHWC
+    image img = (H, W, C, k) (include/genrl_hip.h: genrl_sgemm_conv) — no materialised im2col."""
+    if gemm_profile is not None:
+        e0 = torch.cuda.Event(enable_timing=True); e0.record()
+    nws = lib().genrl_sgemm_ws_floats(M, N, K)
+    ws = torch.empty(nws, dtype=torch.float32, device=C.device) if nws > 0 else None
+    H, W, Cc, k = img
+    check(lib().genrl_sgemm_conv(A.data_ptr(), a_rs, a_ks, B.data_ptr(), b_rs, b_ks, C.data_ptr(), ldc, _p(bias),
+                                 M, N, K, int(accumulate), _p(ws), nws, which, H, W, Cc, k, _stream()), 'sgemm_conv')
+    if gemm_profile is not None:
+        e1 = torch.cuda.Event(enable_timing=True); e1.record()
+        gemm_profile.append((M, N, K, e0, e1, ('k' if a_ks == 1 else 'r') + ('k' if b_ks == 1 else 'r') + f'/conv{which}'))
 
 
 def colsum(x2d, out=None, accumulate=False):
@@ -638,6 +654,11 @@ def _col2im(cols, bias, Nimg, Ha, Wa, C, k, Ho=0, Wo=0, nchw=False):
     return out
 
 
+def _implicit_conv(img, C):
+    """The GEMM can gather stride-2 patches itself when every patch segment is 16-byte addressable."""
+    return img.dtype == torch.float32 and C % 4 == 0 and img.data_ptr() % 16 == 0 and not os.environ.get('GENRL_EXPLICIT_IM2COL')
+
+
 class _Conv2dS2(Function):
     """nn.Conv2d(k, stride 2) as patch-gather + GEMM.  x: f32 NHWC (N,H,W,C) or u8 NCHW (N,C,H,W)
     [preprocess fused]; Wp (Co, k*k*Ci) = weight permuted to (co, kh, kw, ci); returns NHWC."""
@@ -650,13 +671,16 @@ class _Conv2dS2(Function):
         else:
             Nimg, Hi, Wi, C = x.shape
         Co = Wp.shape[0]
-        cols = _im2col(x, Nimg, Hi, Wi, C, k, 2 if u8 else 0)
-        M, K = cols.shape
+        Ho, Wo = (Hi - k) // 2 + 1, (Wi - k) // 2 + 1
+        M, K = Nimg * Ho * Wo, C * k * k
         y = torch.empty(M, Co, device=x.device)
-        sgemm(cols, K, 1, Wp, K, 1, y, Co, b, M, Co, K)
+        if _implicit_conv(x, C):       # patches gathered by the GEMM's A loader straight from the image
+            sgemm_conv(x, K, 1, Wp, K, 1, y, Co, b, M, Co, K, 1, (Hi, Wi, C, k))
+        else:
+            cols = _im2col(x, Nimg, Hi, Wi, C, k, 2 if u8 else 0)
+            sgemm(cols, K, 1, Wp, K, 1, y, Co, b, M, Co, K)
         ctx.save_for_backward(x, Wp)
         ctx.dims = (Nimg, Hi, Wi, C, k, u8)
-        Ho, Wo = (Hi - k) // 2 + 1, (Wi - k) // 2 + 1
         return y.reshape(Nimg, Ho, Wo, Co)
 
     @staticmethod
@@ -670,10 +694,13 @@ class _Conv2dS2(Function):
         dy2 = dy.reshape(M, Co).contiguous()
         dx = dW = db = None
         if ctx.needs_input_grad[1]:
-            cols = _im2col(x, Nimg, Hi, Wi, C, k, 2 if u8 else 0)     # recomputed, not stored
             dW = torch.empty(Co, K, device=dy.device)
-            sgemm(dy2, 1, Co, cols, 1, K, dW, K, None, Co, K, M)
-            del cols
+            if _implicit_conv(x, C) and Co % 4 == 0:
+                sgemm_conv(dy2, 1, Co, x, 1, K, dW, K, None, Co, K, M, 2, (Hi, Wi, C, k))
+            else:
+                cols = _im2col(x, Nimg, Hi, Wi, C, k, 2 if u8 else 0)     # recomputed, not stored
+                sgemm(dy2, 1, Co, cols, 1, K, dW, K, None, Co, K, M)
+                del cols
         if ctx.needs_input_grad[2]:
             db = colsum(dy2)
         if (not u8) and ctx.needs_input_grad[0]:
@@ -715,15 +742,22 @@ class _ConvT2dS2(Function):
         Ho, Wo = 2 * (Hi - 1) + k, 2 * (Wi - 1) + k
         M, Nw = Nimg * Hi * Wi, Co * k * k
         dy = dy.contiguous()
-        dcols = _im2col(dy, Nimg, Ho, Wo, Co, k, 0)                   # (M, Nw)
+        implicit = _implicit_conv(dy, Co) and Ci % 4 == 0
+        dcols = None if implicit else _im2col(dy, Nimg, Ho, Wo, Co, k, 0)       # (M, Nw) patch matrix of dy
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, Ci, device=dy.device)
-            sgemm(dcols, Nw, 1, Wp, Nw, 1, dx, Ci, None, M, Ci, Nw)   # dx = dcols W^T
+            if implicit:
+                sgemm_conv(dy, Nw, 1, Wp, Nw, 1, dx, Ci, None, M, Ci, Nw, 1, (Ho, Wo, Co, k))
+            else:
+                sgemm(dcols, Nw, 1, Wp, Nw, 1, dx, Ci, None, M, Ci, Nw)   # dx = dcols W^T
             dx = dx.reshape(Nimg, Hi, Wi, Ci)
         if ctx.needs_input_grad[1]:
             dW = torch.empty(Ci, Nw, device=dy.device)
-            sgemm(x, 1, Ci, dcols, 1, Nw, dW, Nw, None, Ci, Nw, M)    # dW = x^T dcols
+            if implicit:
+                sgemm_conv(x, 1, Ci, dy, 1, Nw, dW, Nw, None, Ci, Nw, M, 2, (Ho, Wo, Co, k))
+            else:
+                sgemm(x, 1, Ci, dcols, 1, Nw, dW, Nw, None, Ci, Nw, M)    # dW = x^T dcols
         if ctx.needs_input_grad[2]:
             db = colsum(dy.reshape(-1, Co))
         return dx, dW, db, None

@@ -28,6 +28,17 @@ long genrl_sgemm_ws_floats(int M, int N, int K);
 int genrl_sgemm(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks, float* C, long ldc,
                 const float* bias, int M, int N, int K, int accumulate, float* ws, long ws_floats, void* stream);
 
+/* The same product with ONE operand read as the implicit patch matrix of a stride-2 k x k convolution
+ * over an NHWC image (N, img_h, img_w, img_c) -- replaces F.unfold-style patch materialisation for
+ * nn.Conv2d forward / weight gradient (agent/dreamer_utils.py:604-621) and the nn.ConvTranspose2d
+ * input / weight gradients (:686-706).  which = 1: A (k-contiguous, a_ks = 1) is the (pixels x k*k*C)
+ * patch matrix of the image at `A`, B k-contiguous;  which = 2: A and B row-contiguous, B is the patch
+ * matrix (K = pixels, N = k*k*C) of the image at `B`.  Patch column order (kh, kw, c).  Requires
+ * img_c % 4 == 0 and 16-byte aligned operands (returns 1 otherwise). */
+int genrl_sgemm_conv(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks, float* C, long ldc,
+                     const float* bias, int M, int N, int K, int accumulate, float* ws, long ws_floats, int which,
+                     int img_h, int img_w, int img_c, int ksize, void* stream);
+
 /* ---- LayerNorm(+SiLU): NormLayer + act (agent/dreamer_utils.py:844-859,462-463,745) and, on NHWC
  * activations, ImgChLayerNorm (:1031-1040).  act: 0 none, 1 SiLU. */
 int genrl_ln_act_fwd(const float* x, long ldx, const float* gamma, const float* beta, float* y, long ldy, float* mean,
