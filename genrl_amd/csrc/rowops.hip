@@ -4,6 +4,13 @@
 // All are HBM/L2-bound: one 64-lane wave owns one row, lanes stride the row so every global
 // access is a coalesced 256-B segment, reductions are wavefront shuffles (no LDS).
 #include "common.h"
+#include <algorithm>
+
+#ifdef GENRL_NO_NARROW_LN
+#define NARROW_LN false
+#else
+#define NARROW_LN true
+#endif
 
 namespace {
 
@@ -102,6 +109,118 @@ __global__ __launch_bounds__(256) void ln_act_bwd_params_kernel(
     const int l = threadIdx.x;
     part[((long)blockIdx.y * 2 + 0) * N + c] = sg[0][l] + sg[1][l] + sg[2][l] + sg[3][l];
     part[((long)blockIdx.y * 2 + 1) * N + c] = sb[0][l] + sb[1][l] + sb[2][l] + sb[3][l];
+  }
+}
+
+// ------------------------------------------------------------------ narrow rows (N <= 256): channel LayerNorm
+// The image channel-LayerNorm (ImgChLayerNorm, agent/dreamer_utils.py:1031-1040) runs over rows of
+// 48..192 floats with up to ~10^6 rows: a whole wave per 192-byte row leaves most lanes idle and makes
+// every access a partial line.  Here a row is owned by GL = 16/32/64 lanes holding one float4 each, a
+// wave covers 64/GL consecutive rows per iteration (one contiguous span), reductions stay inside
+// the lane group, and the backward produces dx and the per-column partial sums (dgamma, dbeta and
+// optionally the column sums of dx) in ONE pass over dy and x.
+__device__ __forceinline__ float4 ld4z(const float* p, bool ok) {
+  return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+template <int GL>
+__global__ __launch_bounds__(256) void ln_act_fwd_grp_kernel(const float* __restrict__ x, long ldx,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ y,
+                                                             long ldy, float* __restrict__ mean_out,
+                                                             float* __restrict__ rstd_out, int M, int N, float eps,
+                                                             int act) {
+  constexpr int RPW = 64 / GL;
+  const int lane = threadIdx.x & 63, gl = lane % GL, gi = lane / GL;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  const int c = gl * 4;
+  const bool cok = c < N;
+  const float4 g4 = ld4z(gamma + c, cok), b4 = ld4z(beta + c, cok);
+  const float invn = 1.0f / N;
+  for (long r = wave * RPW + gi; r < M; r += nwaves * RPW) {
+    const float4 v = ld4z(x + r * ldx + c, cok);
+    const float mean = group_sum<GL>(v.x + v.y + v.z + v.w) * invn;
+    float4 d = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+    if (!cok) d = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float var = group_sum<GL>(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * invn;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    float4 z = make_float4(d.x * rstd * g4.x + b4.x, d.y * rstd * g4.y + b4.y, d.z * rstd * g4.z + b4.z,
+                           d.w * rstd * g4.w + b4.w);
+    if (act) z = make_float4(siluf_(z.x), siluf_(z.y), siluf_(z.z), siluf_(z.w));
+    if (cok) *reinterpret_cast<float4*>(y + r * ldy + c) = z;
+    if (gl == 0) {
+      mean_out[r] = mean;
+      rstd_out[r] = rstd;
+    }
+  }
+}
+
+// part layout [gridDim.x][np][N] (np = 2: dgamma, dbeta; 3: + column sums of dx), or NULL
+template <int GL>
+__global__ __launch_bounds__(256) void ln_act_bwd_grp_kernel(const float* __restrict__ dy, long lddy,
+                                                             const float* __restrict__ x, long ldx,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ mean_in,
+                                                             const float* __restrict__ rstd_in, float* __restrict__ dx,
+                                                             long lddx, float* __restrict__ part, int M, int N, int act,
+                                                             int np) {
+  constexpr int RPW = 64 / GL;
+  __shared__ float4 sm[3][4][GL];
+  const int lane = threadIdx.x & 63, gl = lane % GL, gi = lane / GL, w = threadIdx.x >> 6;
+  const long wave = (long)blockIdx.x * 4 + w, nwaves = (long)gridDim.x * 4;
+  const int c = gl * 4;
+  const bool cok = c < N;
+  const float4 g4 = ld4z(gamma + c, cok), b4 = ld4z(beta + c, cok);
+  const float invn = 1.0f / N;
+  float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag, ac = ag;
+  for (long r = wave * RPW + gi; r < M; r += nwaves * RPW) {
+    const float4 xv = ld4z(x + r * ldx + c, cok), dv = ld4z(dy + r * lddy + c, cok);
+    const float mean = mean_in[r], rstd = rstd_in[r];
+    float4 xh = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+    if (!cok) xh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 dz = dv;
+    if (act) {
+      dz.x *= dsiluf_(xh.x * g4.x + b4.x);
+      dz.y *= dsiluf_(xh.y * g4.y + b4.y);
+      dz.z *= dsiluf_(xh.z * g4.z + b4.z);
+      dz.w *= dsiluf_(xh.w * g4.w + b4.w);
+    }
+    const float4 dxh = make_float4(dz.x * g4.x, dz.y * g4.y, dz.z * g4.z, dz.w * g4.w);
+    const float s1 = group_sum<GL>(dxh.x + dxh.y + dxh.z + dxh.w) * invn;
+    const float s2 = group_sum<GL>(dxh.x * xh.x + dxh.y * xh.y + dxh.z * xh.z + dxh.w * xh.w) * invn;
+    const float4 o = make_float4(rstd * (dxh.x - s1 - xh.x * s2), rstd * (dxh.y - s1 - xh.y * s2),
+                                 rstd * (dxh.z - s1 - xh.z * s2), rstd * (dxh.w - s1 - xh.w * s2));
+    if (cok && dx) *reinterpret_cast<float4*>(dx + r * lddx + c) = o;
+    ag.x += dz.x * xh.x; ag.y += dz.y * xh.y; ag.z += dz.z * xh.z; ag.w += dz.w * xh.w;
+    ab.x += dz.x; ab.y += dz.y; ab.z += dz.z; ab.w += dz.w;
+    if (cok) { ac.x += o.x; ac.y += o.y; ac.z += o.z; ac.w += o.w; }
+  }
+  if (!part) return;
+  // lanes with the same column (gl) across the RPW row groups of the wave, then the 4 waves through LDS
+  auto xsum = [&](float4& a) {
+#pragma unroll
+    for (int o = GL; o < 64; o <<= 1) {
+      a.x += __shfl_xor(a.x, o, 64);
+      a.y += __shfl_xor(a.y, o, 64);
+      a.z += __shfl_xor(a.z, o, 64);
+      a.w += __shfl_xor(a.w, o, 64);
+    }
+  };
+  xsum(ag); xsum(ab); xsum(ac);
+  if (gi == 0) {
+    sm[0][w][gl] = ag;
+    sm[1][w][gl] = ab;
+    sm[2][w][gl] = ac;
+  }
+  __syncthreads();
+  if (threadIdx.x < GL && cok) {
+    float* pp = part + (long)blockIdx.x * np * N + c;
+    for (int q = 0; q < np; ++q) {
+      const float4 a0 = sm[q][0][gl], a1 = sm[q][1][gl], a2 = sm[q][2][gl], a3 = sm[q][3][gl];
+      *reinterpret_cast<float4*>(pp + (long)q * N) =
+          make_float4(a0.x + a1.x + a2.x + a3.x, a0.y + a1.y + a2.y + a3.y, a0.z + a1.z + a2.z + a3.z,
+                      a0.w + a1.w + a2.w + a3.w);
+    }
   }
 }
 
@@ -617,7 +736,15 @@ int genrl_ln_act_fwd(const float* x, long ldx, const float* gamma, const float* 
   hipStream_t s = (hipStream_t)stream;
   const bool fast = N > 256 && N <= 4096 && (N & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && aligned16(x) &&
                     aligned16(y) && aligned16(gamma) && aligned16(beta);
-  if (fast) {
+  const bool narrow = N <= 256 && (N & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && aligned16(x) && aligned16(y) &&
+                      aligned16(gamma) && aligned16(beta) && M >= 64 && NARROW_LN;
+  if (narrow) {
+    const int gl = N <= 64 ? 16 : (N <= 128 ? 32 : 64);
+    const int grid = (int)std::min<long>(cdiv(M, 4 * (64 / gl)), 2048);
+#define GO(GLV) hipLaunchKernelGGL((ln_act_fwd_grp_kernel<GLV>), dim3(grid), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, mean, rstd, M, N, eps, act)
+    if (gl == 16) GO(16); else if (gl == 32) GO(32); else GO(64);
+#undef GO
+  } else if (fast) {
     const int grid = M < 4 * BLK_GRID ? M : 4 * BLK_GRID;
     const int nv = cdiv(N, 1024);
 #define GO(NV) hipLaunchKernelGGL((ln_act_fwd_blk_kernel<NV>), dim3(grid), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, mean, rstd, M, N, eps, act)
@@ -651,6 +778,21 @@ int genrl_ln_act_bwd(const float* dy, long lddy, const float* x, long ldx, const
   const bool fast = N > 256 && N <= 4096 && (N & 3) == 0 && (lddy & 3) == 0 && (ldx & 3) == 0 &&
                     (!dx || ((lddx & 3) == 0 && aligned16(dx))) && aligned16(dy) && aligned16(x) &&
                     aligned16(gamma) && aligned16(beta) && (!dgamma || aligned16(ws));
+  const bool narrow = N <= 256 && (N & 3) == 0 && (lddy & 3) == 0 && (ldx & 3) == 0 &&
+                      (!dx || ((lddx & 3) == 0 && aligned16(dx))) && aligned16(dy) && aligned16(x) && aligned16(gamma) &&
+                      aligned16(beta) && (!dgamma || aligned16(ws)) && M >= 64 && (dgamma || !dcolsum) && NARROW_LN;
+  if (narrow) {
+    const int gl = N <= 64 ? 16 : (N <= 128 ? 32 : 64);
+    const int grid = (int)std::min<long>(cdiv(M, 4 * (64 / gl)), blk_grid_for(M));
+    float* part = dgamma ? ws : nullptr;
+    const int np = dcolsum ? 3 : 2;
+#define GO(GLV) hipLaunchKernelGGL((ln_act_bwd_grp_kernel<GLV>), dim3(grid), dim3(256), 0, s, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, part, M, N, act, np)
+    if (gl == 16) GO(16); else if (gl == 32) GO(32); else GO(64);
+#undef GO
+    if (dgamma) reduce_params(ws, ws + (long)grid * np * N, dgamma, dbeta, grid, N, accumulate_params, s, dcolsum);
+    GENRL_CHECK_LAUNCH();
+    return GENRL_OK;
+  }
   if (fast) {
     const int grid = blk_grid_for(M);
     const int nv = cdiv(N, 1024);

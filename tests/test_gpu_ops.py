@@ -88,7 +88,8 @@ def test_sgemm_skinny(ops, M, N, K):
     np.testing.assert_allclose(C3.cpu().numpy(), (Ar.double() @ Br.double().T).numpy(), rtol=1e-4, atol=1e-4 * K ** 0.5)
 
 
-@pytest.mark.parametrize('M,N,act', [(5, 32, 1), (300, 1024, 1), (64, 3072, 0), (33, 48, 1)])
+@pytest.mark.parametrize('M,N,act', [(5, 32, 1), (300, 1024, 1), (64, 3072, 0), (33, 48, 1), (64, 48, 1), (1000, 96, 1),
+                                     (4099, 192, 1), (777, 100, 0), (2050, 256, 1), (5000, 12, 1)])
 def test_ln_act(ops, M, N, act):
     x = torch.randn(M, N, generator=g(1)) * 2 + 0.3
     ga = 1 + 0.1 * torch.randn(N, generator=g(2)); be = 0.1 * torch.randn(N, generator=g(3))
