@@ -319,8 +319,7 @@ class Encoder(Module):  # ref :558-628
             x = x.permute(0, 2, 3, 1).contiguous()
         for i in range(len(self._cnn_kernels)):
             conv, ln = self._conv_model[3 * i], self._conv_model[3 * i + 1]
-            x = ops.conv2d_s2(x, conv.weight, conv.bias)
-            x = ops.ln_act(x, ln.norm.weight, ln.norm.bias, ln.norm.eps, act=True)
+            x = ops.conv2d_s2(x, conv.weight, conv.bias, ln=(ln.norm.weight, ln.norm.bias, ln.norm.eps))
         n, h, w, c = x.shape
         return ops.transpose_last2(x.reshape(n, h * w, c)).reshape(n, c * h * w)    # NCHW flatten, ref :621
 
@@ -360,10 +359,11 @@ class Decoder(Module):  # ref :631-715
         n = len(self._cnn_kernels)
         for i in range(n):
             conv = self._conv_model[3 * i]
-            x = ops.convT2d_s2(x, conv.weight, conv.bias)
             if i != n - 1:
                 ln = self._conv_model[3 * i + 1]
-                x = ops.ln_act(x, ln.norm.weight, ln.norm.bias, ln.norm.eps, act=True)
+                x = ops.convT2d_s2(x, conv.weight, conv.bias, ln=(ln.norm.weight, ln.norm.bias, ln.norm.eps))
+            else:
+                x = ops.convT2d_s2(x, conv.weight, conv.bias)
         N, H, W, C = x.shape
         x = ops.transpose_last2(x.reshape(N, H * W, C)).reshape(tuple(lead) + (C, H, W))   # -> NCHW
         return {key: MSEDist(x) for key in self.channels}

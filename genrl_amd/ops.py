@@ -654,6 +654,26 @@ def _col2im(cols, bias, Nimg, Ha, Wa, C, k, Ho=0, Wo=0, nchw=False):
     return out
 
 
+def _ln_fwd_rows(pre2d, gamma, beta, eps):
+    M, N = pre2d.shape
+    y = torch.empty_like(pre2d)
+    mean = torch.empty(M, device=pre2d.device); rstd = torch.empty(M, device=pre2d.device)
+    check(lib().genrl_ln_act_fwd(_p(pre2d), N, _p(gamma), _p(beta), _p(y), N, _p(mean), _p(rstd), M, N, eps, 1,
+                                 _stream()), 'ln_act_fwd')
+    return y, mean, rstd
+
+
+def _ln_bwd_rows(dy2d, pre2d, gamma, beta, mean, rstd):
+    """-> dpre, dgamma, dbeta, column sums of dpre (= the producing layer's bias gradient), one pass"""
+    M, N = pre2d.shape
+    dpre = torch.empty_like(pre2d)
+    gb = torch.empty(3, N, device=pre2d.device)
+    ws = _ws(lib().genrl_ln_ws_floats(M, N), pre2d.device)
+    check(lib().genrl_ln_act_bwd(_p(dy2d), N, _p(pre2d), N, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dpre), N,
+                                 _p(gb[0]), _p(gb[1]), _p(gb[2]), _p(ws), M, N, 1, 0, _stream()), 'ln_act_bwd')
+    return dpre, gb[0], gb[1], gb[2]
+
+
 def _implicit_conv(img, C):
     """The GEMM can gather stride-2 patches itself when every patch segment is 16-byte addressable."""
     return img.dtype == torch.float32 and C % 4 == 0 and img.data_ptr() % 16 == 0 and not os.environ.get('GENRL_EXPLICIT_IM2COL')
@@ -663,7 +683,7 @@ class _Conv2dS2(Function):
     """nn.Conv2d(k, stride 2) as patch-gather + GEMM.  x: f32 NHWC (N,H,W,C) or u8 NCHW (N,C,H,W)
     [preprocess fused]; Wp (Co, k*k*Ci) = weight permuted to (co, kh, kw, ci); returns NHWC."""
     @staticmethod
-    def forward(ctx, x, Wp, b, k):
+    def forward(ctx, x, Wp, b, k, gamma=None, beta=None, eps=0.0):
         u8 = x.dtype == torch.uint8
         x = x.contiguous()
         if u8:
@@ -679,20 +699,28 @@ class _Conv2dS2(Function):
         else:
             cols = _im2col(x, Nimg, Hi, Wi, C, k, 2 if u8 else 0)
             sgemm(cols, K, 1, Wp, K, 1, y, Co, b, M, Co, K)
-        ctx.save_for_backward(x, Wp)
         ctx.dims = (Nimg, Hi, Wi, C, k, u8)
+        ctx.fused_ln = gamma is not None
+        if ctx.fused_ln:           # channel-LayerNorm + SiLU of the layer (ImgChLayerNorm + act)
+            out, mean, rstd = _ln_fwd_rows(y, gamma, beta, eps)
+            ctx.save_for_backward(x, Wp, y, mean, rstd, gamma, beta)
+            return out.reshape(Nimg, Ho, Wo, Co)
+        ctx.save_for_backward(x, Wp)
         return y.reshape(Nimg, Ho, Wo, Co)
 
     @staticmethod
     def backward(ctx, dy):
-        x, Wp = ctx.saved_tensors
+        x, Wp = ctx.saved_tensors[:2]
         Nimg, Hi, Wi, C, k, u8 = ctx.dims
         Co = Wp.shape[0]
         K = C * k * k
         Ho, Wo = (Hi - k) // 2 + 1, (Wi - k) // 2 + 1
         M = Nimg * Ho * Wo
         dy2 = dy.reshape(M, Co).contiguous()
-        dx = dW = db = None
+        dx = dW = db = dg = dbe = None
+        if ctx.fused_ln:
+            pre, mean, rstd, gamma, beta = ctx.saved_tensors[2:]
+            dy2, dg, dbe, db_ln = _ln_bwd_rows(dy2, pre, gamma, beta, mean, rstd)
         if ctx.needs_input_grad[1]:
             dW = torch.empty(Co, K, device=dy.device)
             if _implicit_conv(x, C) and Co % 4 == 0:
@@ -702,27 +730,29 @@ class _Conv2dS2(Function):
                 sgemm(dy2, 1, Co, cols, 1, K, dW, K, None, Co, K, M)
                 del cols
         if ctx.needs_input_grad[2]:
-            db = colsum(dy2)
+            db = db_ln if ctx.fused_ln else colsum(dy2)
         if (not u8) and ctx.needs_input_grad[0]:
             dcols = torch.empty(M, K, device=dy.device)
             sgemm(dy2, Co, 1, Wp, 1, K, dcols, K, None, M, K, Co)     # dcols = dy W
             dx = _col2im(dcols, None, Nimg, Ho, Wo, C, k, Hi, Wi)
-        return dx, dW, db, None
+        return dx, dW, db, None, dg, dbe, None
 
 
-def conv2d_s2(x, W, b):
+def conv2d_s2(x, W, b, ln=None):
     """W (Co,Ci,k,k) in the reference layout; permuted per call to (Co, kh*kw*Ci) (gradient flows back
-    through the permute)."""
+    through the permute).  ln = (gamma, beta, eps): channel-LayerNorm + SiLU fused into the same node."""
     Co, Ci, k, _ = W.shape
     Wp = transpose_last2(W.reshape(Co, Ci, k * k)).reshape(Co, k * k * Ci)
-    return _Conv2dS2.apply(x, Wp, b, k)
+    if ln is None:
+        return _Conv2dS2.apply(x, Wp, b, k)
+    return _Conv2dS2.apply(x, Wp, b, k, ln[0], ln[1], float(ln[2]))
 
 
 class _ConvT2dS2(Function):
     """nn.ConvTranspose2d(k, stride 2) as GEMM + gather-form col2im.  x NHWC (N,Hi,Wi,Ci);
     Wp (Ci, k*k*Co) = weight permuted to (ci, kh, kw, co); returns NHWC."""
     @staticmethod
-    def forward(ctx, x, Wp, b, k):
+    def forward(ctx, x, Wp, b, k, gamma=None, beta=None, eps=0.0):
         x = _f32(x).contiguous()
         Nimg, Hi, Wi, Ci = x.shape
         Nw = Wp.shape[1]
@@ -731,17 +761,27 @@ class _ConvT2dS2(Function):
         cols = torch.empty(M, Nw, device=x.device)
         sgemm(x, Ci, 1, Wp, 1, Nw, cols, Nw, None, M, Nw, Ci)         # cols = x W
         y = _col2im(cols, b, Nimg, Hi, Wi, Co, k)
-        ctx.save_for_backward(x, Wp)
         ctx.dims = (Nimg, Hi, Wi, Ci, Co, k)
+        ctx.fused_ln = gamma is not None
+        if ctx.fused_ln:
+            out, mean, rstd = _ln_fwd_rows(y.reshape(-1, Co), gamma, beta, eps)
+            ctx.save_for_backward(x, Wp, y, mean, rstd, gamma, beta)
+            return out.reshape(y.shape)
+        ctx.save_for_backward(x, Wp)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, Wp = ctx.saved_tensors
+        x, Wp = ctx.saved_tensors[:2]
         Nimg, Hi, Wi, Ci, Co, k = ctx.dims
         Ho, Wo = 2 * (Hi - 1) + k, 2 * (Wi - 1) + k
         M, Nw = Nimg * Hi * Wi, Co * k * k
         dy = dy.contiguous()
+        dg = dbe = db_ln = None
+        if ctx.fused_ln:
+            pre, mean, rstd, gamma, beta = ctx.saved_tensors[2:]
+            dy, dg, dbe, db_ln = _ln_bwd_rows(dy.reshape(-1, Co), pre.reshape(-1, Co), gamma, beta, mean, rstd)
+            dy = dy.reshape(Nimg, Ho, Wo, Co)
         implicit = _implicit_conv(dy, Co) and Ci % 4 == 0
         dcols = None if implicit else _im2col(dy, Nimg, Ho, Wo, Co, k, 0)       # (M, Nw) patch matrix of dy
         dx = dW = db = None
@@ -759,15 +799,17 @@ class _ConvT2dS2(Function):
             else:
                 sgemm(x, 1, Ci, dcols, 1, Nw, dW, Nw, None, Ci, Nw, M)    # dW = x^T dcols
         if ctx.needs_input_grad[2]:
-            db = colsum(dy.reshape(-1, Co))
-        return dx, dW, db, None
+            db = db_ln if ctx.fused_ln else colsum(dy.reshape(-1, Co))
+        return dx, dW, db, None, dg, dbe, None
 
 
-def convT2d_s2(x, W, b):
+def convT2d_s2(x, W, b, ln=None):
     """W (Ci,Co,k,k) in the reference layout; permuted per call to (Ci, kh*kw*Co)."""
     Ci, Co, k, _ = W.shape
     Wp = transpose_last2(W.reshape(Ci, Co, k * k)).reshape(Ci, k * k * Co)
-    return _ConvT2dS2.apply(x, Wp, b, k)
+    if ln is None:
+        return _ConvT2dS2.apply(x, Wp, b, k)
+    return _ConvT2dS2.apply(x, Wp, b, k, ln[0], ln[1], float(ln[2]))
 
 
 class _TransposeLast2(Function):

@@ -201,6 +201,19 @@ def test_conv2d_s2(ops, N, Hi, C, Co, k):
     compare(lambda x, W, b: ops.conv2d_s2(x.permute(0, 2, 3, 1).contiguous(), W, b), ref, [x, W, b], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('N,Hi,C,Co,k', [(3, 31, 8, 16, 4), (8, 14, 48, 96, 4)])
+def test_conv_ln_act_fused(ops, N, Hi, C, Co, k):
+    x = torch.randn(N, C, Hi, Hi, generator=g(1)); W = torch.randn(Co, C, k, k, generator=g(2)) / (C * k * k) ** .5
+    b = torch.randn(Co, generator=g(3)); ga = 1 + 0.1 * torch.randn(Co, generator=g(4)); be = 0.1 * torch.randn(Co, generator=g(5))
+    ref = lambda x, W, b, ga, be: F.silu(F.layer_norm(F.conv2d(x, W, b, stride=2).permute(0, 2, 3, 1), (Co,), ga, be, 1e-3))
+    compare(lambda x, W, b, ga, be: ops.conv2d_s2(x.permute(0, 2, 3, 1).contiguous(), W, b, ln=(ga, be, 1e-3)), ref,
+            [x, W, b, ga, be], rtol=2e-4, atol=2e-4)
+    Wt = torch.randn(C, Co, k + 1, k + 1, generator=g(6)) / (C * k) ** .5
+    reft = lambda x, W, b, ga, be: F.silu(F.layer_norm(F.conv_transpose2d(x, W, b, stride=2).permute(0, 2, 3, 1), (Co,), ga, be, 1e-3))
+    compare(lambda x, W, b, ga, be: ops.convT2d_s2(x.permute(0, 2, 3, 1).contiguous(), W, b, ln=(ga, be, 1e-3)), reft,
+            [x[:, :, :7, :7].contiguous(), Wt, b, ga, be], rtol=2e-4, atol=2e-4)
+
+
 def test_conv2d_s2_u8(ops):
     o = torch.randint(0, 256, (2, 3, 64, 64), generator=g(1), dtype=torch.uint8)
     W = torch.randn(48, 3, 4, 4, generator=g(2)) / 7; b = torch.randn(48, generator=g(3))
