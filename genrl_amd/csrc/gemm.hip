@@ -431,7 +431,9 @@ __global__ __launch_bounds__(1024) void skinny_kernel(const float* __restrict__ 
                                                       const float* __restrict__ B, long b_ld,
                                                       float* __restrict__ C, long ldc,
                                                       const float* __restrict__ bias, int M, int N, int K,
-                                                      int accumulate, int vec) {
+                                                      int accumulate, int vec, long part_stride) {
+  // gridDim.y > 1: blockIdx.y owns a K range and writes its partial product to C + blockIdx.y * part_stride
+  // (no bias / accumulate); the consumer kernel sums the slabs in a fixed order.
   constexpr int NW = 16;
   __shared__ float red[NW][MB][4][64];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, q = l >> 4;
@@ -449,8 +451,15 @@ __global__ __launch_bounds__(1024) void skinny_kernel(const float* __restrict__ 
     arow[mb] = A + (long)min(r, M - 1) * a_ld;
   }
   const int kchunks = (K + 15) >> 4;
-  const int cpw = (kchunks + NW - 1) / NW;
-  const int c0 = w * cpw, c1 = min(c0 + cpw, kchunks);
+  const int cps = (kchunks + gridDim.y - 1) / gridDim.y;              // chunks per split
+  const int s0 = blockIdx.y * cps, s1 = min(s0 + cps, kchunks);
+  const int cpw = (max(s1 - s0, 0) + NW - 1) / NW;
+  const int c0 = s0 + w * cpw, c1 = min(c0 + cpw, s1);
+  if (gridDim.y > 1) {
+    C += (long)blockIdx.y * part_stride;
+    bias = nullptr;
+    accumulate = 0;
+  }
   const int kfull = K >> 4;   // chunks entirely inside K
   auto body = [&](int c, bool guarded) {
     const int k = (c << 4) + 4 * q;
@@ -685,7 +694,7 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
                     (!b_kc || (((b_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0)));
     dim3 grid(cdiv(N, 16)), block(1024);
 #define GO(MB, BKC) \
-  hipLaunchKernelGGL((skinny_kernel<MB, BKC>), grid, block, 0, s, A, a_rs, B, b_ld, C, ldc, bias, M, N, K, accumulate, vec)
+  hipLaunchKernelGGL((skinny_kernel<MB, BKC>), grid, block, 0, s, A, a_rs, B, b_ld, C, ldc, bias, M, N, K, accumulate, vec, 0L)
     if (M <= 16) { if (b_kc) GO(1, true); else GO(1, false); }
     else { if (b_kc) GO(2, true); else GO(2, false); }
 #undef GO
@@ -738,4 +747,28 @@ extern "C" int genrl_sgemm_conv(const float* A, long a_rs, long a_ks, const floa
   const long pixels = which == 1 ? M : K, kk = which == 1 ? K : N;
   if (kk != (long)ksize * ksize * img_c || pixels % g.ohw != 0) return GENRL_EINVAL;
   return sgemm_impl(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, ws, ws_floats, stream, which, &g);
+}
+
+// Skinny product (M <= 32, A k-contiguous) written as `nparts` K-split partial slabs P[s][M][ldp]
+// (s-th slab at P + s * part_stride) for a consumer that sums them (genrl_gru_gates_bwd's dhout2_parts):
+// the recurrent dgrad of a scan step has only N/16 = 64 column blocks, so the K split is what
+// spreads it over the chip, and summing in the consumer saves the reduce launch.
+extern "C" int genrl_sgemm_skinny_parts(const float* A, long a_rs, const float* B, long b_rs, long b_ks, float* P,
+                                        long ldp, long part_stride, int M, int N, int K, int nparts, void* stream) {
+  GENRL_ENTER();
+  if (M <= 0 || N <= 0) return GENRL_OK;
+  if (M > 32 || K <= 0 || nparts < 1 || nparts > 64 || (b_rs != 1 && b_ks != 1)) return GENRL_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool b_kc = (b_ks == 1);
+  const long b_ld = b_kc ? b_rs : b_ks;
+  const int vec = ((a_rs & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                  (!b_kc || (((b_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0)));
+  dim3 grid(cdiv(N, 16), nparts), block(1024);
+#define GO(MB, BKC) \
+  hipLaunchKernelGGL((skinny_kernel<MB, BKC>), grid, block, 0, s, A, a_rs, B, b_ld, P, ldp, nullptr, M, N, K, 0, vec, part_stride)
+  if (M <= 16) { if (b_kc) GO(1, true); else GO(1, false); }
+  else { if (b_kc) GO(2, true); else GO(2, false); }
+#undef GO
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
 }

@@ -600,7 +600,8 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_blk_kernel(
     const float* __restrict__ dhout, long lddo, const float* __restrict__ dhout2,
     const float* __restrict__ dhout2_scale, const float* __restrict__ pre, const float* __restrict__ h, long ldh, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in, float* __restrict__ dpre,
-    float* __restrict__ dh, long lddh, float* __restrict__ part, int R, int D) {
+    float* __restrict__ dh, long lddh, float* __restrict__ part, int R, int D,
+    const float* __restrict__ d2parts, int nparts, long part_stride) {
   __shared__ float red[8];
   const int dv = D >> 2, N = 3 * D;
   float4 ag[3][DV], ab[3][DV];
@@ -634,7 +635,11 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_blk_kernel(
         const float4 hv = hr[j];
         float4 go = gr_[j];
         if (dhout2) {
-          const float4 g2 = reinterpret_cast<const float4*>(dhout2 + (long)row * D)[j];
+          float4 g2 = reinterpret_cast<const float4*>(dhout2 + (long)row * D)[j];
+          for (int q = 0; q < nparts; ++q) {     // K-split partial slabs of the recurrent dgrad, fixed order
+            const float4 pq = reinterpret_cast<const float4*>(d2parts + q * part_stride + (long)row * D)[j];
+            g2.x += pq.x; g2.y += pq.y; g2.z += pq.z; g2.w += pq.w;
+          }
           const float sc = dhout2_scale ? dhout2_scale[row] : 1.0f;
           go.x += g2.x * sc; go.y += g2.y * sc; go.z += g2.z * sc; go.w += g2.w * sc;
         }
@@ -863,13 +868,18 @@ long genrl_gru_ws_floats(int R, int D) { return (long)(blk_grid_for(R) + 16) * 2
 // Backward of the gate block *including* its LayerNorm: dpre[R,3D] is the gradient w.r.t. the
 // pre-LayerNorm projection, dh[R,D] the direct path to the (masked) previous state.  The upstream
 // gradient is dhout + dhout2 * dhout2_scale[row] (dhout2 / its scale may be NULL): the recurrent
-// term of a sequence scan.  `h` is the masked state used in the forward (hm_out).
+// term of a sequence scan; dhout2_parts (optional): nparts more slabs [R,D], part_stride floats apart,
+// added to dhout2 before scaling (genrl_sgemm_skinny_parts output).  `h` is the masked state used in
+// the forward (hm_out).
 int genrl_gru_gates_bwd(const float* dhout, long lddo, const float* dhout2, const float* dhout2_scale,
                         const float* pre, const float* h, long ldh, const float* gamma, const float* beta,
                         const float* mean, const float* rstd, float* dpre, float* dh, long lddh, float* dgamma,
-                        float* dbeta, float* ws, int R, int D, int accumulate_params, void* stream) {
+                        float* dbeta, float* ws, int R, int D, int accumulate_params, const float* dhout2_parts,
+                        int nparts, long part_stride, void* stream) {
   GENRL_ENTER();
   if (R <= 0) return GENRL_OK;
+  if (!dhout2_parts) nparts = 0;
+  if (nparts > 0 && (!dhout2 || !aligned16(dhout2_parts) || (part_stride & 3))) return GENRL_EINVAL;
   if ((D & 3) || D > 4096 || (ldh & 3) || (lddo & 3) || (lddh & 3) || !aligned16(pre) || !aligned16(h) ||
       !aligned16(dhout) || !aligned16(dpre) || !aligned16(dh) || (dhout2 && !aligned16(dhout2)) ||
       (dgamma && !aligned16(ws)))
@@ -878,7 +888,7 @@ int genrl_gru_gates_bwd(const float* dhout, long lddo, const float* dhout2, cons
   const int grid = blk_grid_for(R);
   const int dvn = cdiv(D, 1024);
   float* part = dgamma ? ws : nullptr;
-#define GO(DV) hipLaunchKernelGGL((gru_gates_bwd_blk_kernel<DV>), dim3(grid), dim3(256), 0, s, dhout, lddo, dhout2, dhout2_scale, pre, h, ldh, gamma, beta, mean, rstd, dpre, dh, lddh, part, R, D)
+#define GO(DV) hipLaunchKernelGGL((gru_gates_bwd_blk_kernel<DV>), dim3(grid), dim3(256), 0, s, dhout, lddo, dhout2, dhout2_scale, pre, h, ldh, gamma, beta, mean, rstd, dpre, dh, lddh, part, R, D, dhout2_parts, nparts, part_stride)
   if (dvn == 1) GO(1); else if (dvn == 2) GO(2); else if (dvn == 3) GO(3); else GO(4);
 #undef GO
   if (dgamma) reduce_params(ws, ws + (long)grid * 6 * D, dgamma, dbeta, grid, 3 * D, accumulate_params, s);

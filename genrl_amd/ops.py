@@ -252,10 +252,10 @@ def _gru_fwd_raw(pre_ptr, h_ptr, gamma, beta, out_ptr, out2_ptr, scale2_ptr, mea
 
 
 def _gru_bwd_raw(dout_ptr, dout2_ptr, scale2_ptr, pre_ptr, h_ptr, gamma, beta, mean_ptr, rstd_ptr, dpre_ptr, dh_ptr,
-                 dg, db, ws, R, D, accumulate):
+                 dg, db, ws, R, D, accumulate, parts_ptr=None, nparts=0, part_stride=0):
     check(lib().genrl_gru_gates_bwd(dout_ptr, D, dout2_ptr, scale2_ptr, pre_ptr, h_ptr, D, _p(gamma), _p(beta),
                                     mean_ptr, rstd_ptr, dpre_ptr, dh_ptr, D, _p(dg), _p(db), _p(ws), R, D,
-                                    int(accumulate), _stream()), 'gru_gates_bwd')
+                                    int(accumulate), parts_ptr, nparts, part_stride, _stream()), 'gru_gates_bwd')
 
 
 class _GRUGates(Function):
@@ -1012,7 +1012,12 @@ class _GRUSeq(Function):
         gb = torch.zeros(2, 3 * D, device=dev)
         ws = _ws(lib().genrl_gru_ws_floats(B, D), dev)
         BD, B3D = B * D, B * 3 * D
-        cur, nxt = dha, None
+        # few sequences per GPU: the recurrent dgrad d(hm_t) += dpre_t W_h is a weight stream with only D/16
+        # column blocks -> K-split into slabs that the next step's gate backward sums (no reduce launch)
+        S = 4 if (B <= 32 and not os.environ.get('GENRL_NO_SCAN_PARTS')) else 0
+        pa = torch.empty(S, B, D, device=dev) if S else None
+        pb = torch.empty(S, B, D, device=dev) if S else None
+        cur, nxt, pcur, pnxt = dha, None, pa, None
         for t in range(T - 1, -1, -1):
             if ctx.has_mask:
                 hprev, hoff = hm, t * BD
@@ -1023,9 +1028,18 @@ class _GRUSeq(Function):
                          (mask.data_ptr() + 4 * (t + 1) * B) if (nxt is not None and ctx.has_mask) else None,
                          pre.data_ptr() + 4 * t * B3D, hprev.data_ptr() + 4 * hoff, gamma, beta,
                          mean.data_ptr() + 4 * t * B, rstd.data_ptr() + 4 * t * B, dpre.data_ptr() + 4 * t * B3D,
-                         cur.data_ptr(), gb[0], gb[1], ws, B, D, True)
-            sgemm(dpre, 3 * D, 1, W, 1, K, cur, D, None, B, D, 3 * D, accumulate=True, a_off=t * B3D, b_off=I)
+                         cur.data_ptr(), gb[0], gb[1], ws, B, D, True,
+                         pnxt.data_ptr() if (S and pnxt is not None) else None, S if pnxt is not None else 0, BD)
+            if S:
+                check(lib().genrl_sgemm_skinny_parts(dpre.data_ptr() + 4 * t * B3D, 3 * D, W.data_ptr() + 4 * I, 1, K,
+                                                     pcur.data_ptr(), D, BD, B, D, 3 * D, S, _stream()), 'sgemm_parts')
+            else:
+                sgemm(dpre, 3 * D, 1, W, 1, K, cur, D, None, B, D, 3 * D, accumulate=True, a_off=t * B3D, b_off=I)
             nxt, cur = cur, (dhb if cur is dha else dha)
+            if S:
+                pnxt, pcur = pcur, (pb if pcur is pa else pa)
+        if S:        # d(hm_0) = direct part + slabs
+            nxt = nxt + pnxt.sum(0)
         dx = dW = dh0 = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)

@@ -39,6 +39,12 @@ int genrl_sgemm_conv(const float* A, long a_rs, long a_ks, const float* B, long 
                      const float* bias, int M, int N, int K, int accumulate, float* ws, long ws_floats, int which,
                      int img_h, int img_w, int img_c, int ksize, void* stream);
 
+/* M <= 32 rows, A k-contiguous: the product as `nparts` K-split partial slabs (P + s*part_stride, leading dimension
+ * ldp) that the consumer sums -- the recurrent dgrad d h_{t-1} += dpre_t W_h of the RSSM scans' backward
+ * (GRUCell, agent/dreamer_utils.py:771-785), consumed by genrl_gru_gates_bwd(dhout2_parts). */
+int genrl_sgemm_skinny_parts(const float* A, long a_rs, const float* B, long b_rs, long b_ks, float* P, long ldp,
+                             long part_stride, int M, int N, int K, int nparts, void* stream);
+
 /* ---- LayerNorm(+SiLU): NormLayer + act (agent/dreamer_utils.py:844-859,462-463,745) and, on NHWC
  * activations, ImgChLayerNorm (:1031-1040).  act: 0 none, 1 SiLU. */
 int genrl_ln_act_fwd(const float* x, long ldx, const float* gamma, const float* beta, float* y, long ldy, float* mean,
@@ -61,7 +67,8 @@ long genrl_gru_ws_floats(int R, int D);
 int genrl_gru_gates_bwd(const float* dhout, long lddo, const float* dhout2, const float* dhout2_scale,
                         const float* pre, const float* h, long ldh, const float* gamma, const float* beta,
                         const float* mean, const float* rstd, float* dpre, float* dh, long lddh, float* dgamma,
-                        float* dbeta, float* ws, int R, int D, int accumulate_params, void* stream);
+                        float* dbeta, float* ws, int R, int D, int accumulate_params, const float* dhout2_parts,
+                        int nparts, long part_stride, void* stream);
 
 /* ---- actor Normal head: DistLayer 'normal' + rsample (agent/dreamer_utils.py:814-819) */
 int genrl_actor_head_fwd(const float* raw, const float* eps, float* action, float* mean, float* std, long R, int A,
