@@ -43,6 +43,10 @@ extern "C" void genrl_dbg_read(unsigned long long* out, int nslots) {
   hipMemcpyFromSymbol(out, HIP_SYMBOL(genrl_dbg_cycles), sizeof(unsigned long long) * 6 * nslots);
 }
 #endif
+#ifndef GENRL_MID_AT
+#define GENRL_MID_AT 3   /* staging after MFMA pair 3 of the 8 per step (KS/2 - 1 = last = old order) */
+#endif
+
 namespace {
 
 // Implicit stride-2 convolution operand (no materialised patch matrix): the logical row of pixel
@@ -243,21 +247,64 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(
       store_tile(Bs + buf * B_SZ, LDB, B_KC, BN, v, tid + i * NT);
     }
   };
-  auto compute = [&](int buf) {
+  // MFMAs of one BK step from LDS buffer `buf`; `mid()` runs after the first half has been issued.
+  // The register->LDS staging of the next tile goes there: queued MFMAs keep the matrix pipe busy while
+  // the wave does its LDS stores and walks into the barrier, instead of the whole workgroup draining the
+  // pipe first (staging after the last MFMA left it idle for the store + barrier + first-read latency
+  // of every step).
+  auto compute = [&](int buf, auto&& mid) {
     const float* as = As + buf * A_SZ + kg * KS * LDA;
     const float* bs = Bs + buf * B_SZ + kg * KS * LDB;
+    // all LDS operands of the step are requested up front (64x64 tile: 16 registers); the 128x128
+    // tile reads them pair by pair to stay at 3 waves/SIMD
+    constexpr bool PRELOAD = (BM == 64);
+    float av[PRELOAD ? KS / 2 : 1][TM], bv[PRELOAD ? KS / 2 : 1][TN];
+    if (PRELOAD) {
+#pragma unroll
+    for (int kk = 0; kk < KS / 2; ++kk) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[kk][i] = as[(2 * kk + lk) * LDA + wm0 + i * 32 + lrow];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[kk][j] = bs[(2 * kk + lk) * LDB + wn0 + j * 32 + lrow];
+    }
+    }
+    // 128x128 tile: operands of pair kk+1 are requested BEFORE the MFMAs of pair kk are issued (issuing
+    // TM*TN MFMAs takes >= 256 cycles, which covers the LDS latency), instead of read -> wait -> MFMA
+    float an[TM], bn[TN];
+    if (!PRELOAD) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) an[i] = as[lk * LDA + wm0 + i * 32 + lrow];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bn[j] = bs[lk * LDB + wn0 + j * 32 + lrow];
+    }
 #pragma unroll
     for (int kk = 0; kk < KS / 2; ++kk) {
       float a[TM], b[TN];
+      if (PRELOAD) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = as[(2 * kk + lk) * LDA + wm0 + i * 32 + lrow];
+        for (int i = 0; i < TM; ++i) a[i] = av[kk][i];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = bs[(2 * kk + lk) * LDB + wn0 + j * 32 + lrow];
+        for (int j = 0; j < TN; ++j) b[j] = bv[kk][j];
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = an[i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = bn[j];
+        if (kk + 1 < KS / 2) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) an[i] = as[(2 * (kk + 1) + lk) * LDA + wm0 + i * 32 + lrow];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bn[j] = bs[(2 * (kk + 1) + lk) * LDB + wn0 + j * 32 + lrow];
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs (hipcc sinks them otherwise)
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      if (!PRELOAD) __builtin_amdgcn_sched_barrier(0);
+      if (kk == GENRL_MID_AT) mid();
     }
   };
 
@@ -291,12 +338,13 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(
       if (kt + 2 < nk) fetch(0, kt + 2);
 #endif
       TICK(0);
-      compute(0);
-      TICK(1);
+      compute(0, [&]() {
 #ifndef GENRL_FETCH_EARLY
-      if (kt + 2 < nk) fetch(0, kt + 2);
+        if (kt + 2 < nk) fetch(0, kt + 2);
 #endif
-      if (kt + 1 < nk) stage(1, 1);
+        if (kt + 1 < nk) stage(1, 1);
+      });
+      TICK(1);
       TICK(2);
       __syncthreads();
       TICK(3);
@@ -306,12 +354,13 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(
       if (kt + 3 < nk) fetch(1, kt + 3);
 #endif
       TICK(0);
-      compute(1);
-      TICK(1);
+      compute(1, [&]() {
 #ifndef GENRL_FETCH_EARLY
-      if (kt + 3 < nk) fetch(1, kt + 3);
+        if (kt + 3 < nk) fetch(1, kt + 3);
 #endif
-      if (kt + 2 < nk) stage(0, 0);
+        if (kt + 2 < nk) stage(0, 0);
+      });
+      TICK(1);
       TICK(2);
       __syncthreads();
       TICK(3);
@@ -322,8 +371,7 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
       if (kt + 1 < nk) fetch(0, kt + 1);
-      compute(kt & 1);
-      if (kt + 1 < nk) stage(0, (kt + 1) & 1);
+      compute(kt & 1, [&]() { if (kt + 1 < nk) stage(0, (kt + 1) & 1); });
       __syncthreads();
     }
   }
@@ -532,6 +580,9 @@ __global__ __launch_bounds__(1024) void skinny_kernel(const float* __restrict__ 
 #define GENRL_SMALL_BK 64
 #define GENRL_SMALL_KG 4
 #endif
+#ifndef GENRL_BIG_PD
+#define GENRL_BIG_PD 1
+#endif
 #ifndef GENRL_BIG_BK
 #define GENRL_BIG_BK 16
 #define GENRL_BIG_KG 1
@@ -708,7 +759,7 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
   float* wsp = split ? ws : nullptr;
   int rc;
   if (p.big)
-    rc = launch_cfg<128, 128, GENRL_BIG_BK, GENRL_BIG_KG, 1>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate,
+    rc = launch_cfg<128, 128, GENRL_BIG_BK, GENRL_BIG_KG, GENRL_BIG_PD>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate,
                                                             p.splits, p.k_per_split, wsp, s, G, gp);
   else
     rc = launch_cfg<64, 64, SMALL_BK, SMALL_KG, GENRL_SMALL_PD>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K,
