@@ -194,15 +194,25 @@ def main():
     if rank == 0 and not args.no_kernel_profile:
         ops.gemm_profile = []
         ov, ag.cfg.overlap_detached = ag.cfg.overlap_detached, False   # single stream: clean per-launch durations
+        # park the stream behind a ~150 ms spin so that the host has enqueued the whole eager step before
+        # the GPU starts it: the events then bracket kernel execution, not host launch latency
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record(); torch.cuda._sleep(10_000_000); c1.record(); torch.cuda.synchronize()
+        torch.cuda._sleep(int(10_000_000 * 150.0 / max(c0.elapsed_time(c1), 1e-3)))
         one_step(ag, batch)
         torch.cuda.synchronize()
         ag.cfg.overlap_detached = ov
         prof, ops.gemm_profile = ops.gemm_profile, None
+        # M <= 32 products run the weight-streaming skinny_kernel (HBM/L2-bound by design), not sgemm_kernel
+        skinny = [p_ for p_ in prof if p_[5].endswith('/skinny')]
+        sk_ms = sum(p_[3].elapsed_time(p_[4]) for p_ in skinny)
+        sk_bytes = sum(4.0 * (p_[0] * p_[2] + p_[1] * p_[2] + p_[0] * p_[1]) for p_ in skinny)
+        prof_all, prof = prof, [p_ for p_ in prof if not p_[5].endswith('/skinny')]
         tot_ms = sum(p_[3].elapsed_time(p_[4]) for p_ in prof)
         tot_fl = sum(2.0 * p_[0] * p_[1] * p_[2] for p_ in prof)
         if args.dump_gemm:
             agg = {}
-            for (m, n, k, e0, e1, mode) in prof:
+            for (m, n, k, e0, e1, mode) in prof_all:
                 a = agg.setdefault((m, n, k, mode), [0, 0.0])
                 a[0] += 1; a[1] += e0.elapsed_time(e1)
             rows = sorted(([m, n, k, mode, c, ms] for (m, n, k, mode), (c, ms) in agg.items()), key=lambda r: -r[5])
@@ -213,7 +223,10 @@ def main():
                            'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
                            'kernel': 'sgemm_kernel<BM,BN,*> (gemm.hip, v_mfma_f32_32x32x2_f32), all instantiations',
                            'launches_per_step': len(prof), 'avg_launch_us': 1e3 * tot_ms / len(prof),
-                           'gemm_gflop_per_step': tot_fl / 1e9, 'gemm_ms_per_step': tot_ms}
+                           'gemm_gflop_per_step': tot_fl / 1e9, 'gemm_ms_per_step': tot_ms,
+                           'skinny_kernel': {'launches_per_step': len(skinny), 'ms_per_step': sk_ms,
+                                             'bound': 'hbm', 'achieved_GBps': sk_bytes / max(sk_ms, 1e-9) / 1e6,
+                                             'note': 'M<=32 scan-step products (weight streams), reported apart'}}
     elif rank == 0:
         out['roofline'] = None
     if rank == 0:

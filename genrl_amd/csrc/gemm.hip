@@ -595,10 +595,11 @@ constexpr int SMALL_BK = GENRL_SMALL_BK, SMALL_KG = GENRL_SMALL_KG;
 // MFMA work.  The conv weight-gradient products (2-54 small tiles, K ~ 1e5-1e6) lost up to 50 % to
 // this with a "enough workgroups" rule.  Costs in us; constants from the K sweeps in profiles/.
 //   small: 64x64 tile, 1024 threads, one WG per CU (256 slots), 17.8 ns per k per WG
-//   big  : 128x128 tile, 256 threads, up to 3 WGs per CU (768 slots) sharing the CU's MFMA rate
+//   big  : 128x128 tile, 256*KG threads, 3 (KG=1) or 2 (KG=2) WGs per CU sharing the CU's MFMA rate
 struct SplitPlan {
   int big, splits, k_per_split;
 };
+constexpr int BIG_WG_PER_CU = GENRL_BIG_KG == 1 ? 3 : 2;   // 256-thread WGs at 140 VGPRs: 3; 512-thread: 2
 inline double reduce_cost(long sp, long M, long N) { return sp > 1 ? 5.0 + (double)sp * M * N * 4.0 / 3.0e6 : 0.0; }
 inline SplitPlan plan_split(int M, int N, int K) {
   static const char* force = getenv("GENRL_GEMM_FORCE");   // calibration only: "s,<splits>" / "b,<splits>"
@@ -639,8 +640,8 @@ inline SplitPlan plan_split(int M, int N, int K) {
       const long kps = (long)cdiv(cdiv(K, s), 64) * 64;
       const long sp = cdiv(K, kps);
       const long wgs = tiles_b * sp;
-      const long rounds = cdiv(wgs, 768);
-      const long per_cu = wgs >= 768 ? 3 : cdiv(wgs, 256);          // co-resident WGs share the MFMA pipes
+      const long rounds = cdiv(wgs, 256 * BIG_WG_PER_CU);
+      const long per_cu = wgs >= 256 * BIG_WG_PER_CU ? BIG_WG_PER_CU : cdiv(wgs, 256);   // co-resident WGs share the MFMA pipes
       const double lat = per_cu == 1 ? 1.4 : (per_cu == 2 ? 1.1 : 1.0);   // fewer waves hide less latency
       const double t = rounds * (t_fixed + kps * t_k * per_cu * lat) + reduce_cost(sp, M, N);
       if (t < best - 1e-9) {

@@ -93,7 +93,8 @@ def sgemm(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate=False,
                             _stream()), 'sgemm')
     if gemm_profile is not None:
         e1 = torch.cuda.Event(enable_timing=True); e1.record()
-        gemm_profile.append((M, N, K, e0, e1, ('k' if a_ks == 1 else 'r') + ('k' if b_ks == 1 else 'r')))
+        gemm_profile.append((M, N, K, e0, e1, ('k' if a_ks == 1 else 'r') + ('k' if b_ks == 1 else 'r') +
+                             ('/skinny' if (M <= 32 and a_ks == 1) else '')))
 
 
 def sgemm_conv(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, which, img, accumulate=False):
