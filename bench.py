@@ -219,8 +219,20 @@ def main():
             os.makedirs(os.path.dirname(args.dump_gemm) or '.', exist_ok=True)
             json.dump(rows, open(args.dump_gemm, 'w'))
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        # HBM bytes per launch of the same kernel family from the committed PMC passes (rocprofv3 --pmc runs are
+        # separate processes by construction; scripts/pmc.sh, FETCH_SIZE doubled per MI355X_MICROARCH.md)
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')))
+            gk = [v for k_, v in pm.items() if k_.startswith('sgemm_kernel')]
+            nl = sum(v['launches'] for v in gk)
+            traffic = sum((v['hbm_read_bytes_per_launch'] + v['hbm_write_bytes_per_launch']) * v['launches'] for v in gk) / nl
+        except Exception:
+            pass
         out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                           'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                           'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
+                           'traffic_note': 'HBM bytes per launch (read+write) from profiles/r01_pmc.json; algorithmic '
+                                           f'operand bytes per launch {sum(4.0 * (p_[0] * p_[2] + p_[1] * p_[2] + p_[0] * p_[1]) for p_ in prof) / max(len(prof), 1):.3g}',
                            'kernel': 'sgemm_kernel<BM,BN,*> (gemm.hip, v_mfma_f32_32x32x2_f32), all instantiations',
                            'launches_per_step': len(prof), 'avg_launch_us': 1e3 * tot_ms / len(prof),
                            'gemm_gflop_per_step': tot_fl / 1e9, 'gemm_ms_per_step': tot_ms,

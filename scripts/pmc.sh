@@ -1,0 +1,42 @@
+#!/bin/bash
+# PMC passes over bench.py (separate runs; --kernel-trace only, as gpurun requires):
+#   pass 1: SQ counters (MFMA busy, wait breakdown)   pass 2: FETCH_SIZE   pass 3: WRITE_SIZE
+cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/pmc
+ARGS="bench.py --steps 2 --warmup 1 --graph off --no-overlap --no-cpu-baseline --no-kernel-profile --input fixed"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d /tmp/p1 -o p -- python $ARGS > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p2 -o p -- python $ARGS > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p3 -o p -- python $ARGS > /dev/null 2>&1
+python - <<'PY'
+import csv, collections, json
+def load(d):
+    cnt = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter(); dur = collections.Counter()
+    ids = {}
+    for r in csv.DictReader(open(f'/tmp/{d}/p_kernel_trace.csv')):
+        ids[r['Dispatch_Id']] = (r['Kernel_Name'], int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    seen = set()
+    for r in csv.DictReader(open(f'/tmp/{d}/p_counter_collection.csv')):
+        name = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+        cnt[name][r['Counter_Name']] += float(r['Counter_Value'])
+        if r['Dispatch_Id'] not in seen:
+            seen.add(r['Dispatch_Id']); n[name] += 1
+            if r['Dispatch_Id'] in ids: dur[name] += ids[r['Dispatch_Id']][1]
+    return cnt, n, dur
+c1, n1, d1 = load('p1'); c2, n2, d2 = load('p2'); c3, n3, d3 = load('p3')
+out = {}
+for name in sorted(n1, key=lambda k: -d1[k])[:14]:
+    c = c1[name]
+    kernel_cycles = c['SQ_BUSY_CYCLES'] / 32.0
+    rec = {'launches': n1[name], 'time_ms': d1[name] / 1e6,
+           'mfma_util': c['SQ_VALU_MFMA_BUSY_CYCLES'] / max(kernel_cycles * 1024, 1),
+           'wait_any_frac': c['SQ_WAIT_ANY'] / max(c['SQ_WAVE_CYCLES'], 1),
+           'wait_inst_frac': c['SQ_WAIT_INST_ANY'] / max(c['SQ_WAVE_CYCLES'], 1),
+           'active_inst_frac': c['SQ_ACTIVE_INST_ANY'] / max(c['SQ_WAVE_CYCLES'], 1),
+           'hbm_read_bytes_per_launch': 2.0 * c2[name]['FETCH_SIZE'] * 1024 / max(n2[name], 1) if 'FETCH_SIZE' in c2[name] else None,
+           'hbm_write_bytes_per_launch': c3[name]['WRITE_SIZE'] * 1024 / max(n3[name], 1) if 'WRITE_SIZE' in c3[name] else None}
+    out[name] = rec
+json.dump(out, open('gpurun_out/pmc/pmc_summary.json', 'w'), indent=1)
+for k, v in out.items():
+    print(f"{k[:60]:60s} n={v['launches']:5d} {v['time_ms']:8.2f} ms mfma {100*v['mfma_util']:5.1f}% wait {100*v['wait_any_frac']:4.1f}% instwait {100*v['wait_inst_frac']:4.1f}% rd/launch {(v['hbm_read_bytes_per_launch'] or 0)/1e6:8.2f} MB wr {(v['hbm_write_bytes_per_launch'] or 0)/1e6:8.2f} MB")
+PY
+head -3 /tmp/p2/p_counter_collection.csv | cut -c1-300
