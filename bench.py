@@ -191,6 +191,9 @@ def main():
                                  'unit': 'TFLOP/s', 'frac': fl['total'] * sps / 1e3 / world / PEAK_F32_MFMA_TFLOPS},
                'final_model_loss': loss}
     # ---- kernel roofline: HIP events around every launch of the fp32-MFMA GEMM kernel in one extra step
+    if rank != 0 and world > 1 and not args.no_kernel_profile:
+        one_step(ag, batch)              # the profiled extra step contains collectives: every rank takes part
+        torch.cuda.synchronize()
     if rank == 0 and not args.no_kernel_profile:
         ops.gemm_profile = []
         ov, ag.cfg.overlap_detached = ag.cfg.overlap_detached, False   # single stream: clean per-launch durations

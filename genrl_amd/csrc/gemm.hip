@@ -43,6 +43,9 @@ extern "C" void genrl_dbg_read(unsigned long long* out, int nslots) {
   hipMemcpyFromSymbol(out, HIP_SYMBOL(genrl_dbg_cycles), sizeof(unsigned long long) * 6 * nslots);
 }
 #endif
+#ifndef GENRL_BIG_WAVES
+#define GENRL_BIG_WAVES 3   /* min waves per SIMD requested for the 128x128 tile (register budget 512/n) */
+#endif
 #ifndef GENRL_MID_AT
 #define GENRL_MID_AT 3   /* staging after MFMA pair 3 of the 8 per step (KS/2 - 1 = last = old order) */
 #endif
@@ -68,7 +71,7 @@ __device__ __forceinline__ int fdiv(int x, int d, float inv) {
 }
 
 template <int BM, int BN, int BK, int KG, int PD, bool FAST, bool A_KC, bool B_KC, int G = 0>
-__global__ __launch_bounds__(256 * KG) void sgemm_kernel(
+__global__ __launch_bounds__(256 * KG, (BM == 128 && KG == 1) ? GENRL_BIG_WAVES : 1) void sgemm_kernel(
     const float* __restrict__ A, long a_ld, const float* __restrict__ B, long b_ld,
     float* __restrict__ C, long ldc, const float* __restrict__ bias, int M, int N, int Ktot,
     int accumulate, int a_vec, int b_vec, int tiles_n, int ntiles, int k_per_split, float* __restrict__ ws,
@@ -599,7 +602,7 @@ constexpr int SMALL_BK = GENRL_SMALL_BK, SMALL_KG = GENRL_SMALL_KG;
 struct SplitPlan {
   int big, splits, k_per_split;
 };
-constexpr int BIG_WG_PER_CU = GENRL_BIG_KG == 1 ? 3 : 2;   // 256-thread WGs at 140 VGPRs: 3; 512-thread: 2
+constexpr int BIG_WG_PER_CU = GENRL_BIG_KG == 1 ? GENRL_BIG_WAVES : 2;   // 256-thread WGs: one wave per SIMD each
 inline double reduce_cost(long sp, long M, long N) { return sp > 1 ? 5.0 + (double)sp * M * N * 4.0 / 3.0e6 : 0.0; }
 inline SplitPlan plan_split(int M, int N, int K) {
   static const char* force = getenv("GENRL_GEMM_FORCE");   // calibration only: "s,<splits>" / "b,<splits>"
