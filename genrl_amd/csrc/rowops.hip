@@ -262,13 +262,38 @@ __global__ void reduce_chunks2_kernel(const float* __restrict__ part, float* __r
   float* o = j < N ? out0 + j : (j < 2 * N ? out1 + (j - N) : out2 + (j - 2 * N));
   *o = accumulate ? *o + s : s;
 }
-// helper: part[nchunk][N] -> out[N]; `tmp` must hold 16*N floats when nchunk > 16
+// one-launch version for a moderate number of partial rows (17..256): 64 columns x 4 interleaved row
+// subsets per block, summed through LDS (fixed order)
+__global__ __launch_bounds__(256) void reduce_chunks2m_kernel(const float* __restrict__ part, float* __restrict__ out0,
+                                                              float* __restrict__ out1, float* __restrict__ out2,
+                                                              int nchunk, int N, int np, int accumulate) {
+  __shared__ float sm[4][64];
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  const long stride = (long)np * N;
+  float s = 0.f;
+  if (j < np * N) {
+#pragma unroll 4
+    for (int c = sub; c < nchunk; c += 4) s += part[(long)c * stride + j];
+  }
+  sm[sub][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sub == 0 && j < np * N) {
+    const int l = threadIdx.x;
+    const float t = sm[0][l] + sm[1][l] + sm[2][l] + sm[3][l];
+    float* o = j < N ? out0 + j : (j < 2 * N ? out1 + (j - N) : out2 + (j - 2 * N));
+    *o = accumulate ? *o + t : t;
+  }
+}
+// helper: part[nchunk][N] -> out[N]; `tmp` must hold 16*N floats when nchunk > 256
 static inline void reduce_cols(const float* part, float* tmp, float* out, int nchunk, int N, int accumulate,
                                hipStream_t s) {
-  if (nchunk > 16) {
+  if (nchunk > 256) {
     const int G = 16, per = cdiv(nchunk, G);
     hipLaunchKernelGGL(reduce_chunksA_kernel, dim3(cdiv(N, 64), G), dim3(256), 0, s, part, tmp, nchunk, N, per);
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, tmp, out, G, (long)N, accumulate);
+  } else if (nchunk > 16) {
+    hipLaunchKernelGGL(reduce_chunks2m_kernel, dim3(cdiv(N, 64)), dim3(256), 0, s, part, out, (float*)nullptr,
+                       (float*)nullptr, nchunk, N, 1, accumulate);
   } else {
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, part, out, nchunk, (long)N, accumulate);
   }
@@ -277,7 +302,10 @@ static inline void reduce_cols(const float* part, float* tmp, float* out, int nc
 static inline void reduce_params(const float* part, float* tmp, float* out0, float* out1, int nchunk, int N,
                                  int accumulate, hipStream_t s, float* out2 = nullptr) {
   const int np = out2 ? 3 : 2;
-  if (nchunk > 16) {
+  if (nchunk > 16 && nchunk <= 256) {
+    hipLaunchKernelGGL(reduce_chunks2m_kernel, dim3(cdiv(np * N, 64)), dim3(256), 0, s, part, out0, out1, out2, nchunk, N,
+                       np, accumulate);
+  } else if (nchunk > 16) {
     const int G = 16, per = cdiv(nchunk, G);
     hipLaunchKernelGGL(reduce_chunksA_kernel, dim3(cdiv(np * N, 64), G), dim3(256), 0, s, part, tmp, nchunk, np * N, per);
     hipLaunchKernelGGL(reduce_chunks2_kernel, dim3(cdiv((long)np * N, 256)), dim3(256), 0, s, tmp, out0, out1, out2, G, N,
