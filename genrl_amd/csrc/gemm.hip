@@ -43,6 +43,9 @@ extern "C" void genrl_dbg_read(unsigned long long* out, int nslots) {
   hipMemcpyFromSymbol(out, HIP_SYMBOL(genrl_dbg_cycles), sizeof(unsigned long long) * 6 * nslots);
 }
 #endif
+#ifndef GENRL_SKINNY_MAX_M
+#define GENRL_SKINNY_MAX_M 32   /* rows up to which the weight-streaming kernel replaces the tiled GEMM */
+#endif
 #ifndef GENRL_BIG_WAVES
 #define GENRL_BIG_WAVES 3   /* min waves per SIMD requested for the 128x128 tile (register budget 512/n) */
 #endif
@@ -489,6 +492,7 @@ __global__ __launch_bounds__(1024) void skinny_kernel(const float* __restrict__ 
   __shared__ float red[NW][MB][4][64];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, q = l >> 4;
   const int n0 = blockIdx.x * 16;
+  const int m_base = blockIdx.z * (16 * MB);     // gridDim.z row groups of 16*MB rows (M up to a few hundred)
   const int col = min(n0 + li, N - 1);
   f32x4 acc[MB];
 #pragma unroll
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(1024) void skinny_kernel(const float* __restrict__ 
   bool rok[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    const int r = li + 16 * mb;
+    const int r = m_base + li + 16 * mb;
     rok[mb] = r < M;
     arow[mb] = A + (long)min(r, M - 1) * a_ld;
   }
@@ -567,10 +571,10 @@ __global__ __launch_bounds__(1024) void skinny_kernel(const float* __restrict__ 
     float sum = 0.f;
 #pragma unroll
     for (int ww = 0; ww < NW; ++ww) sum += red[ww][mb][v][lane];
-    const int oc = n0 + cj;
-    if (r < M && oc < N) {
+    const int oc = n0 + cj, orow = m_base + r;
+    if (orow < M && oc < N) {
       if (bias) sum += bias[oc];
-      float* cp = C + (long)r * ldc + oc;
+      float* cp = C + (long)orow * ldc + oc;
       *cp = accumulate ? *cp + sum : sum;
     }
   }
@@ -742,16 +746,17 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
   if (K <= 0 || (a_rs != 1 && a_ks != 1) || (b_rs != 1 && b_ks != 1)) return GENRL_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
 #ifndef GENRL_NO_SKINNY
-  if (M <= 32 && a_ks == 1 && G == 0) {
+  if (M <= GENRL_SKINNY_MAX_M && a_ks == 1 && G == 0) {
     const bool b_kc = (b_ks == 1);
     const long b_ld = b_kc ? b_rs : b_ks;
     const int vec = ((a_rs & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
                     (!b_kc || (((b_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0)));
-    dim3 grid(cdiv(N, 16)), block(1024);
+    dim3 grid(cdiv(N, 16), 1, M <= 32 ? 1 : cdiv(M, 64)), block(1024);
 #define GO(MB, BKC) \
   hipLaunchKernelGGL((skinny_kernel<MB, BKC>), grid, block, 0, s, A, a_rs, B, b_ld, C, ldc, bias, M, N, K, accumulate, vec, 0L)
     if (M <= 16) { if (b_kc) GO(1, true); else GO(1, false); }
-    else { if (b_kc) GO(2, true); else GO(2, false); }
+    else if (M <= 32) { if (b_kc) GO(2, true); else GO(2, false); }
+    else { if (b_kc) GO(4, true); else GO(4, false); }
 #undef GO
     GENRL_CHECK_LAUNCH();
     return GENRL_OK;
