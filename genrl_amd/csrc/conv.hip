@@ -99,6 +99,22 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ c
     nterm[t] = nt;
   }
   __syncthreads();
+  if (!OUT_NCHW && (C & 3) == 0) {      // 16-byte lanes over the channel runs
+    const int C4 = C >> 2, items4 = rp * C4;
+    for (int w = threadIdx.x; w < items4; w += 256) {
+      const int pix = w / C4, c = (w - pix * C4) << 2;
+      const long m = m0 + pix;
+      if (m >= Mout) break;
+      const int nt = nterm[pix];
+      float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int t = 0; t < nt; ++t) {
+        const float4 v = *reinterpret_cast<const float4*>(cols + rowoff[pix * 9 + t] + kofs[pix * 9 + t] + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      *reinterpret_cast<float4*>(out + m * C + c) = acc;
+    }
+    return;
+  }
   const int items = rp * C;
   for (int w = threadIdx.x; w < items; w += 256) {
     const int pix = w / C, c = w - pix * C;
@@ -160,7 +176,7 @@ int genrl_col2im_s2(const float* cols, const float* bias, float* out, int Nimg, 
   const long M = (long)Nimg * Ho * Wo;
   if (M <= 0) return GENRL_OK;
   if (k > 6 || k < 1) return GENRL_EINVAL;
-  int rp = cdiv(1024, C);
+  int rp = cdiv(((C & 3) == 0 && !out_nchw) ? 4096 : 1024, C);    // ~4 work items per thread
   rp = rp < 32 ? 32 : (rp > 512 ? 512 : rp);
   const size_t smem = (size_t)rp * 9 * 8 + (size_t)rp * 9 * 4 + (size_t)rp * 4;
   dim3 grid(cdiv(M, rp)), block(256);
