@@ -25,81 +25,85 @@ def env_reward(agent, seq):  # ref :16-17
     return agent.wm.heads['reward'](seq['feat']).mean
 
 
-class DreamerAgent(Module):  # ref :19-118
+class DreamerAgent(Module):
+    """Acting + training facade over a WorldModel and an ActorCritic (agent/dreamer.py:19-118).
+    `train.py` / `collect_data.py` use: act, update_wm, update_acting_behavior, update, report,
+    init_meta / update_meta / get_meta_specs."""
     def __init__(self, name, cfg, obs_space, act_spec, **kwargs):
         super().__init__()
-        self.name = name
-        self.cfg = cfg
-        self.cfg.update(**kwargs)
-        self.obs_space = obs_space
-        self.act_spec = act_spec
-        self._use_amp = (cfg.precision == 16)
+        cfg.update(**kwargs)
+        self.name, self.cfg, self.obs_space, self.act_spec = name, cfg, obs_space, act_spec
         self.device = cfg.device
         self.act_dim = act_spec.shape[0]
+        self._use_amp = cfg.precision == 16
         self.wm = WorldModel(cfg, obs_space, self.act_dim)
         self.instantiate_acting_behavior()
-        self.to(cfg.device)
-        self.requires_grad_(requires_grad=False)
+        self.to(self.device)
+        self.requires_grad_(requires_grad=False)       # every update switches on exactly what it trains
 
     def instantiate_acting_behavior(self):
         self._acting_behavior = ActorCritic(self.cfg, self.act_spec, self.wm.inp_size).to(self.device)
 
-    def act(self, obs, meta, step, eval_mode, state):  # ref :41-64
+    # ------------------------------------------------------------------ acting (agent/dreamer.py:41-64)
+    def act(self, obs, meta, step, eval_mode, state):
+        """One environment step: filter the latent with the new observation, then query the actor.
+        `state` is (latent, previous action) or None at episode start."""
         if self.cfg.only_random_actions:
             return np.random.uniform(-1, 1, self.act_dim).astype(self.act_spec.dtype), (None, None)
-        obs = {k: torch.as_tensor(np.copy(v), device=self.device).unsqueeze(0) for k, v in obs.items()}
-        if state is None:
-            latent = self.wm.rssm.initial(len(obs['reward']))
-            action = torch.zeros((len(obs['reward']),) + self.act_spec.shape, device=self.device)
+        batch = {k: torch.as_tensor(np.copy(v), device=self.device).unsqueeze(0) for k, v in obs.items()}
+        if state is not None:
+            latent, prev_action = state
         else:
-            latent, action = state
+            n = len(batch['reward'])
+            latent = self.wm.rssm.initial(n)
+            prev_action = torch.zeros((n,) + tuple(self.act_spec.shape), device=self.device)
+        sample_latent = (not eval_mode) or (not self.cfg.eval_state_mean)
         with torch.no_grad():
-            embed = self.wm.encoder(self.wm.preprocess(obs))
-            should_sample = (not eval_mode) or (not self.cfg.eval_state_mean)
-            latent, _ = self.wm.rssm.obs_step(latent, action, embed, obs['is_first'], should_sample)
-            actor = self._acting_behavior.actor(self.wm.rssm.get_stoch(latent), latent['deter'])
-            action = actor.mean if eval_mode else actor.sample()
+            embed = self.wm.encoder(self.wm.preprocess(batch))
+            latent, _ = self.wm.rssm.obs_step(latent, prev_action, embed, batch['is_first'], sample_latent)
+            policy = self._acting_behavior.actor(self.wm.rssm.get_stoch(latent), latent['deter'])
+            action = policy.mean if eval_mode else policy.sample()
         return action.cpu().numpy()[0], (latent, action)
 
-    def update_wm(self, data, step):  # ref :66-71
-        metrics = {}
-        state, outputs, mets = self.wm.update(data, state=None)
+    # ------------------------------------------------------------------ training entry points
+    def update_wm(self, data, step):  # agent/dreamer.py:66-71
+        state, outputs, wm_metrics = self.wm.update(data, state=None)
         outputs['is_terminal'] = data['is_terminal']
-        metrics.update(mets)
-        return state, outputs, metrics
+        return state, outputs, dict(wm_metrics)
 
-    def update_acting_behavior(self, state=None, outputs=None, metrics={}, data=None, reward_fn=None):  # ref :73-92
+    def _posterior_for(self, outputs, data):
+        """Posterior states to start imagination from: the world-model update's, or a fresh
+        no-grad observe pass over `data`."""
+        if outputs is not None:
+            return outputs['post'], outputs['is_terminal']
+        data = self.wm.preprocess(data)
+        with torch.no_grad():
+            post, _ = self.wm.rssm.observe(self.wm.encoder(data), data['action'], data['is_first'])
+        return post, data['is_terminal']
+
+    def update_acting_behavior(self, state=None, outputs=None, metrics={}, data=None, reward_fn=None):  # :73-92
         if self.cfg.only_random_actions:
             return {}, metrics
-        if outputs is not None:
-            post, is_terminal = outputs['post'], outputs['is_terminal']
-        else:
-            data = self.wm.preprocess(data)
-            with torch.no_grad():
-                post, _ = self.wm.rssm.observe(self.wm.encoder(data), data['action'], data['is_first'])
-            is_terminal = data['is_terminal']
+        post, is_terminal = self._posterior_for(outputs, data)
         start = {k: stop_gradient(v) for k, v in post.items()}
-        if reward_fn is None:
-            acting_reward_fn = lambda seq: globals()[self.cfg.acting_reward_fn](self, seq)
-        else:
-            acting_reward_fn = lambda seq: reward_fn(self, seq)
-        metrics.update(self._acting_behavior.update(self.wm, start, is_terminal, acting_reward_fn))
+        fn = reward_fn if reward_fn is not None else globals()[self.cfg.acting_reward_fn]
+        metrics.update(self._acting_behavior.update(self.wm, start, is_terminal, lambda seq: fn(self, seq)))
         return start, metrics
 
     def update(self, data, step):
         state, outputs, metrics = self.update_wm(data, step)
-        start, metrics = self.update_acting_behavior(state, outputs, metrics, data)
+        _, metrics = self.update_acting_behavior(state, outputs, metrics, data)
         return state, metrics
 
-    def report(self, data):  # ref :99-109
-        report = {}
+    def report(self, data):  # agent/dreamer.py:99-109
         data = self.wm.preprocess(data)
+        videos = {}
         with torch.no_grad():
             for key in self.wm.heads['decoder'].cnn_keys:
-                report[f'openl_{key.replace("/", "_")}'] = self.wm.video_pred(data, key)
-            for fn in getattr(self.cfg, 'additional_report_fns', []):
-                report.update(globals()[fn](self, data))
-        return report
+                videos['openl_' + key.replace('/', '_')] = self.wm.video_pred(data, key)
+            for extra in getattr(self.cfg, 'additional_report_fns', []):
+                videos.update(globals()[extra](self, data))
+        return videos
 
     def get_meta_specs(self):
         return tuple()

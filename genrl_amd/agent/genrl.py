@@ -1,94 +1,107 @@
-"""MI355X-native `agent/genrl.py`: GenRLAgent and the connector update hook with the reference's
-API (mazpie/genrl agent/genrl.py)."""
+"""GenRLAgent for the MI355X-native hot path.
+
+Drop-in for the class `train.py` instantiates through `agent.genrl.GenRLAgent` (same constructor
+keywords, attributes, method names and metric keys — SURVEY.md §8b): a DreamerAgent whose world
+model carries a video-language *connector* (VideoSSM) that is trained next to it, and whose
+imagination behaviour is rewarded by a language/video target instead of the environment.
+Reference locations are cited per member; the bodies are organised around the batched HIP ops.
+"""
 import torch
 
 from .dreamer import DreamerAgent, ActorCritic, stop_gradient, env_reward
 from . import dreamer_utils as common
 from . import video_utils
 from .. import streams
-from ..tools.genrl_utils import *          # reward fns looked up through globals(), ref :5,122
+from ..tools.genrl_utils import *          # reward functions are resolved by NAME from this namespace
 
 
-def connector_update_fn(self, module_name, data, outputs, metrics):  # ref :7-25
-    connector = getattr(self, module_name)
+N_FRAMES = 8                                # frames summarised by one InternVideo2 clip embedding
+DEFAULT_EMBED_DIM = 512
+
+
+def connector_update_fn(self, module_name, data, outputs, metrics):
+    """`update_fn` registered with WorldModel.add_module_to_update (agent/genrl.py:7-25): trains the
+    connector on the batch's clip embeddings against the world model's (detached) posterior."""
     if not getattr(self.cfg, 'viclip_encode', False):
         raise NotImplementedError('on-the-fly InternVideo2 embedding is host-side preprocessing; provide '
                                   "data['clip_video'] (viclip_encode=True), as process_dataset.py does")
-    return connector.update(data['clip_video'], outputs['post'])
+    return getattr(self, module_name).update(data['clip_video'], outputs['post'])
 
 
-class GenRLAgent(DreamerAgent):  # ref :27-124
-    def __init__(self, **kwargs):
+def _chunk_embeddings(clip, n_frames, first, B, T):
+    """One embedding per aligned n_frames chunk (taken at the chunk's last frame, starting at
+    index `first`), held for the whole chunk: (B, T, E)."""
+    picked = clip[:B, first::n_frames]
+    return picked.reshape(B, T // n_frames, 1, -1).expand(-1, -1, n_frames, -1).reshape(B, T, -1)
+
+
+class GenRLAgent(DreamerAgent):
+    def __init__(self, **kwargs):  # agent/genrl.py:28-49
         super().__init__(**kwargs)
-        self.n_frames = 8
-        self.viclip_emb_dim = 512
+        self.n_frames = N_FRAMES
         assert self.cfg.batch_length % self.n_frames == 0, 'Fix batch length param'
-        if 'clip_video' in self.obs_space:
-            self.viclip_emb_dim = self.obs_space['clip_video'].shape[0]
-        connector = video_utils.VideoSSM(**self.cfg.connector, **self.cfg.connector_rssm,
-                                         connector_kl=self.cfg.connector_kl, n_frames=self.n_frames,
-                                         action_dim=self.viclip_emb_dim + self.n_frames,
-                                         clip_add_noise=self.cfg.clip_add_noise,
-                                         clip_lafite_noise=self.cfg.clip_lafite_noise,
-                                         device=self.device, cell_input='stoch')
-        connector.to(self.device)
-        connector.requires_grad_(False)
-        self.wm.add_module_to_update('connector', connector, connector_update_fn,
-                                     detached=self.cfg.connector.detached_post)
+        clip_spec = self.obs_space['clip_video'] if 'clip_video' in self.obs_space else None
+        self.viclip_emb_dim = clip_spec.shape[0] if clip_spec is not None else DEFAULT_EMBED_DIM
+        self._attach_connector()
         if getattr(self.cfg, 'imag_reward_fn', None) is not None:
             self.instantiate_imag_behavior()
 
-    def instantiate_imag_behavior(self):
-        self._imag_behavior = ActorCritic(self.cfg, self.act_spec, self.wm.inp_size, name='imag').to(self.device)
-        self._imag_behavior.requires_grad_(False)
-        self._imag_behavior.rewnorm = common.StreamNorm(**self.cfg.imag_reward_norm, device=self.device)
+    def _attach_connector(self):
+        cfg = self.cfg
+        opts = dict(cfg.connector)
+        opts.update(cfg.connector_rssm)
+        opts.update(connector_kl=cfg.connector_kl, n_frames=self.n_frames, cell_input='stoch', device=self.device,
+                    action_dim=self.viclip_emb_dim + self.n_frames,      # embedding + per-frame slots
+                    clip_add_noise=cfg.clip_add_noise, clip_lafite_noise=cfg.clip_lafite_noise)
+        connector = video_utils.VideoSSM(**opts).to(self.device)
+        connector.requires_grad_(False)
+        self.wm.add_module_to_update('connector', connector, connector_update_fn, detached=cfg.connector.detached_post)
 
-    def finetune_mode(self):
-        self._acting_behavior = self._imag_behavior
-        self.wm.detached_update_fns = {}
-        self.wm.e2e_update_fns = {}
+    def instantiate_imag_behavior(self):  # agent/genrl.py:51-54
+        behavior = ActorCritic(self.cfg, self.act_spec, self.wm.inp_size, name='imag').to(self.device)
+        behavior.requires_grad_(False)
+        behavior.rewnorm = common.StreamNorm(**self.cfg.imag_reward_norm, device=self.device)
+        self._imag_behavior = behavior
+
+    def finetune_mode(self):  # agent/genrl.py:56-60
+        self.wm.detached_update_fns, self.wm.e2e_update_fns = {}, {}
         self.wm.grad_heads.append('reward')
+        self._acting_behavior = self._imag_behavior
 
     def update_wm(self, data, step):
         return super().update_wm(data, step)
 
-    def report(self, data, key='observation', nvid=8):  # ref :64-106
+    # ------------------------------------------------------------------ reporting (agent/genrl.py:64-106)
+    def report(self, data, key='observation', nvid=8):
+        """Adds 'video_clip_pred': ground truth | reconstruction of the first chunk followed by the
+        connector's open-loop video prediction from the later chunks' embeddings | error."""
+        assert getattr(self.cfg, 'viclip_encode', False)
+        wm, nf = self.wm, self.wm.connector.n_frames
         with torch.no_grad():
-            n_frames = self.wm.connector.n_frames
-            obs = data['observation'][:nvid, n_frames:]
-            B, T = obs.shape[:2]
-            report_data = super().report(data)
-            wm = self.wm
+            out = super().report(data)
+            rows, horizon = data['observation'][:nvid, nf:].shape[:2]
+            decode = lambda states: wm.heads['decoder'](wm.decoder_input_fn(states))[key].mean
+            # context: posterior over the first chunk
+            embed = wm.encoder(wm.preprocess(data))
+            context, _ = wm.rssm.observe(embed[:nvid, :nf], data['action'][:nvid, :nf], data['is_first'][:nvid, :nf])
+            last = {name: value[:, -1] for name, value in context.items()}
+            # continuation: connector rollout driven by the remaining chunks' clip embeddings
+            clips = _chunk_embeddings(data['clip_video'].to(self.device), nf, 2 * nf - 1, rows, horizon)
+            dreamed = wm.connector.video_imagine(clips, last, reset_every_n_frames=False)
+            frames = torch.cat([decode(context)[:nvid, :nf] + 0.5, decode(dreamed) + 0.5], 1).clamp(0, 1)
             truth = data[key][:nvid].float() / 255
-            decoder = wm.heads['decoder']
-            pre = wm.preprocess(data)
-            embed = wm.encoder(pre)
-            states, _ = wm.rssm.observe(embed[:nvid, :n_frames], data['action'][:nvid, :n_frames],
-                                        data['is_first'][:nvid, :n_frames])
-            recon = decoder(wm.decoder_input_fn(states))[key].mean[:nvid]
-            dreamer_init = {k: v[:, -1] for k, v in states.items()}
-            assert getattr(self.cfg, 'viclip_encode', False)
-            video_embed = data['clip_video'][:nvid, n_frames * 2 - 1::n_frames].to(self.device)
-            video_embed = video_embed.reshape(B, T // n_frames, -1).unsqueeze(2).repeat(1, 1, n_frames, 1).reshape(B, T, -1)
-            prior = wm.connector.video_imagine(video_embed, dreamer_init, reset_every_n_frames=False)
-            prior_recon = decoder(wm.decoder_input_fn(prior))[key].mean
-            model = torch.clip(torch.cat([recon[:, :n_frames] + 0.5, prior_recon + 0.5], 1), 0, 1)
-            error = (model - truth + 1) / 2
-            report_data['video_clip_pred'] = torch.cat([truth, model, error], 3)
-        return report_data
+            out['video_clip_pred'] = torch.cat([truth, frames, (frames - truth + 1) / 2], 3)
+        return out
 
-    def update_imag_behavior(self, state=None, outputs=None, metrics={}, seq_data=None):  # ref :108-124
-        if getattr(self.cfg, 'imag_reward_fn', None) is None:
+    # ------------------------------------------------------------------ imagination (agent/genrl.py:108-124)
+    def update_imag_behavior(self, state=None, outputs=None, metrics={}, seq_data=None):
+        name = getattr(self.cfg, 'imag_reward_fn', None)
+        if name is None:
             return outputs['post'], metrics
-        if outputs is not None:
-            post, is_terminal = outputs['post'], outputs['is_terminal']
-        else:
-            seq_data = self.wm.preprocess(seq_data)
-            with torch.no_grad():
-                post, _ = self.wm.rssm.observe(self.wm.encoder(seq_data), seq_data['action'], seq_data['is_first'])
-            is_terminal = seq_data['is_terminal']
+        post, is_terminal = self._posterior_for(outputs, seq_data)
         start = {k: stop_gradient(v) for k, v in post.items()}
-        imag_reward_fn = lambda seq: globals()[self.cfg.imag_reward_fn](self, seq, **self.cfg.imag_reward_args)
-        metrics.update(self._imag_behavior.update(self.wm, start, is_terminal, imag_reward_fn))
+        reward = globals()[name]                                    # e.g. video_text_reward
+        extra = self.cfg.imag_reward_args
+        metrics.update(self._imag_behavior.update(self.wm, start, is_terminal, lambda seq: reward(self, seq, **extra)))
         streams.join()          # side-stream connector updates (cfg.overlap_detached) are ordered from here on
         return start, metrics
