@@ -38,7 +38,10 @@ def run_product(name, lr_zero, cfg_over, ocfg_over, overlap=False):
         pytest.skip('needs MI355X')
     from genrl_amd import config, noise as gnoise
     from genrl_amd.agent import dreamer_utils as common
-    g = dict(np.load(os.path.join(G, name)))
+    if isinstance(name, dict):           # synthetic configuration without a golden file: {'meta': (B,T,A,S,K,H,seed), 'img': px}
+        g = {'meta': np.array(list(name['meta']) + [0]), 'img': np.array(name.get('img', 64))}
+    else:
+        g = dict(np.load(os.path.join(G, name)))
     B, T, A, S, K, H, seed, _ = [int(x) for x in g['meta']]
     over = dict(cfg_over)
     if lr_zero:
@@ -219,3 +222,27 @@ def test_c3_dreamer_agent_vs_reference_and_oracle():
         for name, gref in res['grads'][ph].items():
             a, b = grads[ph][name].numpy(), gref.numpy()
             np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-5 * max(1.0, np.abs(b).max()), err_msg=f'{ph}.{name}')
+
+
+def test_c2_full_size_vs_oracle_and_determinism():
+    """BASELINE configs[1] at its full size (B32 x T32, 64x64x3, H=16, A=10, default widths): every
+    loss / metric of the iteration against the CPU oracle on the same weights, batch and noise
+    (1e-3 relative, north_star), and bit-identical metrics when the same iteration is run twice
+    (all reductions of the HIP path have a fixed order)."""
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    meta = {'meta': (32, 32, 10, 32, 32, 16, 3)}
+    g, ocfg, p, batch, noise, ag, outputs, mets_wm, mets, grads = run_product(meta, True, {}, {})
+    res = run_iteration(p, ocfg, batch, noise, FakeClip().get_txt_feat(''), apply_updates=False)
+    om = {k: float(v) for k, v in res['metrics'].items()}
+    checked = 0
+    for k, v in mets.items():
+        if k in om and np.isfinite(om[k]):
+            np.testing.assert_allclose(v, om[k], rtol=1e-3, atol=1e-5, err_msg=k)
+            checked += 1
+    assert checked >= 20, checked
+    for ph in ('wm', 'conn2', 'actor', 'critic'):      # whole-phase gradient norms
+        a = np.sqrt(sum(float((t.double() ** 2).sum()) for t in grads[ph].values()))
+        b = np.sqrt(sum(float((t.double() ** 2).sum()) for t in res['grads'][ph].values()))
+        np.testing.assert_allclose(a, b, rtol=1e-3, err_msg=ph)
+    _, _, _, _, _, _, _, mets_wm2, mets2, _ = run_product(meta, True, {}, {})
+    assert mets_wm2 == mets_wm and mets2 == mets, 'HIP path is not run-to-run deterministic'
