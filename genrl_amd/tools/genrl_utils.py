@@ -10,6 +10,9 @@ from .. import ops
 
 # task -> prompt; populated by the integrator. Fallback: the task name in words.
 TASK2PROMPT = {}
+# domain -> list of behaviour descriptions decoded by report_text2video; same integration hook
+# (reference table: tools/genrl_utils.py DOMAIN2PREDICATES).  Fallback: the task name in words.
+DOMAIN2PREDICATES = {}
 
 
 def max_cosine_similarity(u, v, dim=-1):  # ref :240-242
@@ -87,3 +90,21 @@ def video_video_reward(agent, seq, **kwargs):  # ref :372-409
         agent.unconditional_target = _build_target(agent, wm.video_prompt_embed.to(agent.device).float(), T, B,
                                                    kwargs['sample_for_target'], kwargs['skip_first_target'])
     return video_text_reward(agent, seq, **kwargs)
+
+
+def report_text2video(agent, data):
+    """`additional_report_fns` entry (agent/genrl.yaml:10; tools/genrl_utils.py:202-238): decode what the
+    connector imagines for every behaviour description of the task's domain — text embedding held for
+    one chunk of n_frames, denoised by the aligner, rolled out open-loop in mode (no sampling beyond
+    the initial latent), frames = decoder mean + 0.5.  -> {'text_to_video': (labels, n_frames, C, H, W)}"""
+    wm = agent.wm
+    if not hasattr(wm, 'viclip_model'):
+        raise RuntimeError('report_text2video needs agent.wm.viclip_model.get_txt_feat(text) -> (1, E)')
+    domain = agent.cfg.task.split('_')[0]
+    labels = DOMAIN2PREDICATES.get(domain, [agent.cfg.task.replace('_', ' ')])
+    with torch.no_grad():
+        feats = torch.stack([wm.viclip_model.get_txt_feat(text) for text in labels], 0).to(agent.device)   # (L,1,E)
+        rollout = wm.connector.video_imagine(feats.repeat(1, wm.connector.n_frames, 1), dreamer_init=None,
+                                             sample=False, reset_every_n_frames=False, denoise=True)
+        frames = wm.heads['decoder'](wm.decoder_input_fn(rollout))['observation'].mean + 0.5
+    return {'text_to_video': frames}
