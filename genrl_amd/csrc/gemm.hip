@@ -43,6 +43,9 @@ extern "C" void genrl_dbg_read(unsigned long long* out, int nslots) {
   hipMemcpyFromSymbol(out, HIP_SYMBOL(genrl_dbg_cycles), sizeof(unsigned long long) * 6 * nslots);
 }
 #endif
+#ifndef GENRL_MID_TILES
+#define GENRL_MID_TILES 512    /* 64x64 tiles from which the 256-thread variant of the small tile is used */
+#endif
 #ifndef GENRL_SKINNY_MAX_M
 #define GENRL_SKINNY_MAX_M 32   /* rows up to which the weight-streaming kernel replaces the tiled GEMM */
 #endif
@@ -770,6 +773,10 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
   if (p.big)
     rc = launch_cfg<128, 128, GENRL_BIG_BK, GENRL_BIG_KG, GENRL_BIG_PD>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate,
                                                             p.splits, p.k_per_split, wsp, s, G, gp);
+  else if (p.splits == 1 && (long)cdiv(M, 64) * cdiv(N, 64) >= GENRL_MID_TILES)
+    // several 64x64 tiles per CU: 256-thread workgroups (one wave per SIMD each, 4+ resident per CU,
+    // independent barriers) beat the single 1024-thread workgroup per CU by 10-13 % (measured)
+    rc = launch_cfg<64, 64, 16, 1, 2>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, 1, K, nullptr, s, G, gp);
   else
     rc = launch_cfg<64, 64, SMALL_BK, SMALL_KG, GENRL_SMALL_PD>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K,
                                                                accumulate, p.splits, p.k_per_split, wsp, s, G, gp);
