@@ -84,14 +84,24 @@ __global__ __launch_bounds__(256 * KG, (BM == 128 && KG == 1) ? GENRL_BIG_WAVES 
     int tiles_m, int xcd_m, Gather g) {
   static_assert(G == 0 || (FAST && ((G == 1 && A_KC && B_KC) || (G == 2 && !A_KC && !B_KC))), "gather variants");
   constexpr int NT = 256 * KG;
-  // k-contiguous operands are written to LDS with scalar (transposing) stores: an odd leading
-  // dimension keeps those at <= 2-way bank conflicts; row-contiguous operands use 16-B stores.
-  constexpr int LDA = A_KC ? BM + 1 : BM + 4, LDB = B_KC ? BN + 1 : BN + 4;
+  // LDS images.  Row-contiguous operand: k-major [k][rows + 4], 16-B stores, 4-B fragment reads.
+  // k-contiguous operand: kept row-major [row][BK + 4] (16-B stores, no transpose); a lane reads the
+  // 16 bytes A[row][8j + 4*lk .. +3] with one ds_read_b128 and feeds 4 MFMAs from it — MFMA e of
+  // group j then contracts k = {8j+e, 8j+4+e}: any pairing is valid as long as both operands use it,
+  // so the row-contiguous side reads k = 8j + 4*lk + e.  (+4 floats of padding: the 8 lanes served
+  // together hit 8 different 16-B bank groups for BK = 16 and 64.)
+#ifdef GENRL_KC_TRANSPOSED            /* previous layout: transposing 4-B stores, k-major image */
+  constexpr bool KCV = false;
+#else
+  constexpr bool KCV = true;
+#endif
+  constexpr int LDA = A_KC ? (KCV ? BK + 4 : BM + 1) : BM + 4, LDB = B_KC ? (KCV ? BK + 4 : BN + 1) : BN + 4;
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int AV = BM * BK / 4 / NT, BV = BN * BK / 4 / NT;   // float4 loads per thread per tile
   static_assert(AV >= 1 && BV >= 1, "tile too small for the thread count");
   constexpr int KS = BK / KG;                                   // k-slice per k-group
-  constexpr int A_SZ = BK * LDA, B_SZ = BK * LDB;
+  constexpr int A_SZ = (A_KC && KCV) ? BM * LDA : BK * LDA, B_SZ = (B_KC && KCV) ? BN * LDB : BK * LDB;
+  static_assert(!KCV || (BK / KG) % 8 == 0, "k-slice per k-group must be a multiple of 8");
   constexpr int RED_SZ = (KG - 1) * 4 * TM * TN * 16 * 64;       // KG owners x (KG-1) slots x 16/KG regs
   constexpr int LDS_FLOATS = (2 * (A_SZ + B_SZ) > RED_SZ) ? 2 * (A_SZ + B_SZ) : RED_SZ;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
@@ -217,10 +227,14 @@ __global__ __launch_bounds__(256 * KG, (BM == 128 && KG == 1) ? GENRL_BIG_WAVES 
   auto store_tile = [&](float* S, int lds_ld, bool kc, int bdim, const float4& val, int v) {
     if (kc) {
       const int row = v / (BK / 4), kq = (v % (BK / 4)) << 2;
-      S[(kq + 0) * lds_ld + row] = val.x;
-      S[(kq + 1) * lds_ld + row] = val.y;
-      S[(kq + 2) * lds_ld + row] = val.z;
-      S[(kq + 3) * lds_ld + row] = val.w;
+      if (KCV) {
+        *reinterpret_cast<float4*>(&S[row * lds_ld + kq]) = val;
+      } else {
+        S[(kq + 0) * lds_ld + row] = val.x;
+        S[(kq + 1) * lds_ld + row] = val.y;
+        S[(kq + 2) * lds_ld + row] = val.z;
+        S[(kq + 3) * lds_ld + row] = val.w;
+      }
     } else {
       const int per = bdim >> 2;
       const int k = v / per, rq = (v % per) << 2;
@@ -261,6 +275,69 @@ __global__ __launch_bounds__(256 * KG, (BM == 128 && KG == 1) ? GENRL_BIG_WAVES 
   // the wave does its LDS stores and walks into the barrier, instead of the whole workgroup draining the
   // pipe first (staging after the last MFMA left it idle for the store + barrier + first-read latency
   // of every step).
+#ifndef GENRL_KC_TRANSPOSED
+  // MFMAs of one BK step from LDS buffer `buf`; `mid()` runs after MFMA pair GENRL_MID_AT.
+  // The register->LDS staging of the next tile goes there: queued MFMAs keep the matrix pipe busy while
+  // the wave does its LDS stores and walks into the barrier, instead of the whole workgroup draining the
+  // pipe first.  Operands come in groups of 4 MFMA k-pairs (8 k per k-group slice): one ds_read_b128 per
+  // k-contiguous operand fragment, four 4-byte reads per row-contiguous one.
+  auto compute = [&](int buf, auto&& mid) {
+    constexpr int NG = KS / 8;
+    const float* as = As + buf * A_SZ + (A_KC ? kg * KS : kg * KS * LDA);
+    const float* bs = Bs + buf * B_SZ + (B_KC ? kg * KS : kg * KS * LDB);
+    auto fetch_group = [&](int j, float (&a4)[TM][4], float (&b4)[TN][4]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (A_KC) {
+          const float4 v = *reinterpret_cast<const float4*>(&as[(wm0 + i * 32 + lrow) * LDA + 8 * j + 4 * lk]);
+          a4[i][0] = v.x; a4[i][1] = v.y; a4[i][2] = v.z; a4[i][3] = v.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a4[i][e] = as[(8 * j + 4 * lk + e) * LDA + wm0 + i * 32 + lrow];
+        }
+      }
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) {
+        if (B_KC) {
+          const float4 v = *reinterpret_cast<const float4*>(&bs[(wn0 + jn * 32 + lrow) * LDB + 8 * j + 4 * lk]);
+          b4[jn][0] = v.x; b4[jn][1] = v.y; b4[jn][2] = v.z; b4[jn][3] = v.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b4[jn][e] = bs[(8 * j + 4 * lk + e) * LDB + wn0 + jn * 32 + lrow];
+        }
+      }
+    };
+    // 64x64 tile: every group of the step is requested up front (16 registers); 128x128 tile: one group
+    // ahead of the MFMAs (issuing 4*TM*TN MFMAs covers the LDS latency) to stay at 3 waves/SIMD
+    constexpr bool PRELOAD = (BM == 64);
+    constexpr int NB = PRELOAD ? NG : 2;
+    float ga[NB][TM][4], gb[NB][TN][4];
+    if (PRELOAD) {
+#pragma unroll
+      for (int j = 0; j < NG; ++j) fetch_group(j, ga[j], gb[j]);
+    } else {
+      fetch_group(0, ga[0], gb[0]);
+    }
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int cur = PRELOAD ? j : (j & 1);
+      if (!PRELOAD) {
+        if (j + 1 < NG) fetch_group(j + 1, ga[(j + 1) & 1], gb[(j + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs (hipcc sinks them otherwise)
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn)
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[cur][i][e], gb[cur][jn][e], acc[i][jn], 0, 0, 0);
+        if (4 * j + e == GENRL_MID_AT) mid();
+      }
+      if (!PRELOAD) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+#else
   auto compute = [&](int buf, auto&& mid) {
     const float* as = As + buf * A_SZ + kg * KS * LDA;
     const float* bs = Bs + buf * B_SZ + kg * KS * LDB;
@@ -316,6 +393,8 @@ __global__ __launch_bounds__(256 * KG, (BM == 128 && KG == 1) ? GENRL_BIG_WAVES 
       if (kk == GENRL_MID_AT) mid();
     }
   };
+
+#endif
 
   // Software pipeline (register stages alternate, LDS double-buffered, one barrier per BK):
   //   step kt: issue global loads of tile kt+2 | MFMA on LDS[kt&1] | registers(tile kt+1) -> LDS[(kt+1)&1]
