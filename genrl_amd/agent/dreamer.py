@@ -270,30 +270,45 @@ class WorldModel(Module):  # ref :120-321
                        getattr(policy, f'norm{i}')._layer.weight, getattr(policy, f'norm{i}')._layer.bias,
                        getattr(policy, f'norm{i}')._layer.eps) for i in range(policy._layers)]
             tape = ops.ActorTape(horizon, N, layers, head_w, head_b, dev)
-        for h in range(horizon):
-            stoch, deter = seq['stoch'][-1], seq['deter'][-1]
-            s_flat = stoch.reshape(N, -1)
-            if tape is not None:
-                raw = tape.step(h, stop_gradient(s_flat), stop_gradient(deter))
-            else:
-                raw = ops.linear(policy.trunk(stop_gradient(s_flat), stop_gradient(deter)), head_w, head_b)
-            raws.append(raw)
-            if eval_policy:
-                action = ops.actor_mean_std(raw, policy._out._min_std, policy._out._max_std)[0]
-            else:
-                action = ops.actor_sample(raw, eps[h], policy._out._min_std, policy._out._max_std)
-            x = common._dense_ln_silu(s_flat, rssm._img_in[0], rssm._img_in[1], action)
-            deter = ops.gru_step(x, deter, rssm._cell._layer.weight, rssm._cell._norm.weight, rssm._cell._norm.bias)
-            logit = rssm._prior_logits(deter)
-            stoch = ops.onehot_sample(logit, q[h])
-            for key, value in dict(stoch=stoch, deter=deter, logit=logit, action=action).items():
-                seq[key].append(value)
-        seq = {k: torch.stack(v, 0) for k, v in seq.items()}
-        if tape is not None:     # layer-0 inputs of all steps = the stacked rollout states (no copies)
-            tape.inputs = (seq['stoch'].detach().reshape(horizon + 1, N, -1), seq['deter'].detach())
-        # policy outputs at states 0..H-1 — exactly what ActorCritic.actor_loss re-evaluates for its
-        # entropy metric (agent/dreamer.py:397: actor(sg(feat[:-2]))): kept to avoid a second forward
-        self._last_actor_raw = torch.stack(raws, 0)          # (H, N, 2A), attached to the actor's graph
+        fused = (tape is not None and not eval_policy and set(start) == {'stoch', 'deter', 'logit'}
+                 and not os.environ.get('GENRL_NO_ROLLOUT_NODE'))
+        if fused:
+            # the whole H-step loop as one autograd node (ops._Rollout): dynamics dgrad chain + policy tape
+            inl, inn = rssm._img_in[0], rssm._img_in[1]._layer
+            outl, outn = rssm._ensemble_img_out[0][0], rssm._ensemble_img_out[0][1]._layer
+            dist = rssm._ensemble_img_dist[0]
+            spec = ops.RolloutSpec(tape, inl.weight, inl.bias, inn.weight, inn.bias, inn.eps,
+                                   rssm._cell._layer.weight, rssm._cell._norm.weight, rssm._cell._norm.bias,
+                                   outl.weight, outl.bias, outn.weight, outn.bias, outn.eps, dist.weight, dist.bias,
+                                   rssm._stoch, rssm._discrete, policy._out._min_std, policy._out._max_std)
+            st, de, lg, ac, raw_all = ops.imagine_rollout(start['stoch'], start['deter'], start['logit'], eps, q, spec)
+            seq = {'stoch': st, 'deter': de, 'logit': lg, 'action': ac}
+            self._last_actor_raw = raw_all
+        else:
+            for h in range(horizon):
+                stoch, deter = seq['stoch'][-1], seq['deter'][-1]
+                s_flat = stoch.reshape(N, -1)
+                if tape is not None:
+                    raw = tape.step(h, stop_gradient(s_flat), stop_gradient(deter))
+                else:
+                    raw = ops.linear(policy.trunk(stop_gradient(s_flat), stop_gradient(deter)), head_w, head_b)
+                raws.append(raw)
+                if eval_policy:
+                    action = ops.actor_mean_std(raw, policy._out._min_std, policy._out._max_std)[0]
+                else:
+                    action = ops.actor_sample(raw, eps[h], policy._out._min_std, policy._out._max_std)
+                x = common._dense_ln_silu(s_flat, rssm._img_in[0], rssm._img_in[1], action)
+                deter = ops.gru_step(x, deter, rssm._cell._layer.weight, rssm._cell._norm.weight, rssm._cell._norm.bias)
+                logit = rssm._prior_logits(deter)
+                stoch = ops.onehot_sample(logit, q[h])
+                for key, value in dict(stoch=stoch, deter=deter, logit=logit, action=action).items():
+                    seq[key].append(value)
+            seq = {k: torch.stack(v, 0) for k, v in seq.items()}
+            if tape is not None:     # layer-0 inputs of all steps = the stacked rollout states (no copies)
+                tape.inputs = (seq['stoch'].detach().reshape(horizon + 1, N, -1), seq['deter'].detach())
+            # policy outputs at states 0..H-1 — exactly what ActorCritic.actor_loss re-evaluates for its
+            # entropy metric (agent/dreamer.py:397: actor(sg(feat[:-2]))): kept to avoid a second forward
+            self._last_actor_raw = torch.stack(raws, 0)          # (H, N, 2A), attached to the actor's graph
         seq['feat'] = rssm.get_feat(seq)
         disc = torch.ones(list(seq['deter'].shape[:-1]) + [1], device=dev)       # no discount head
         seq['discount'] = disc * self.cfg.discount

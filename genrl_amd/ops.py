@@ -637,6 +637,146 @@ class _ActorStep(Function):
         return (None, None, dWh, dbh, None, None, *flat)
 
 
+class RolloutSpec:
+    """Frozen world-model weights + shapes of one imagination rollout (plain container handed to _Rollout)."""
+    def __init__(self, tape, in_w, in_b, in_g, in_be, in_eps, gru_w, gru_g, gru_be, out_w, out_b, out_g, out_be, out_eps,
+                 dist_w, dist_b, S, K, min_std, max_std):
+        self.tape = tape
+        self.in_w, self.in_b, self.in_g, self.in_be, self.in_eps = in_w, in_b, in_g, in_be, float(in_eps)
+        self.gru_w, self.gru_g, self.gru_be = gru_w, gru_g, gru_be
+        self.out_w, self.out_b, self.out_g, self.out_be, self.out_eps = out_w, out_b, out_g, out_be, float(out_eps)
+        self.dist_w, self.dist_b = dist_w, dist_b
+        self.S, self.K, self.min_std, self.max_std = S, K, float(min_std), float(max_std)
+
+
+def _ln_fwd_raw(pre_ptr, gamma, beta, y_ptr, mean_ptr, rstd_ptr, M, N, eps):
+    check(lib().genrl_ln_act_fwd(pre_ptr, N, _p(gamma), _p(beta), y_ptr, N, mean_ptr, rstd_ptr, M, N, eps, 1, _stream()),
+          'ln_act_fwd')
+
+
+def _ln_bwd_raw(dy_ptr, pre_ptr, gamma, beta, mean_ptr, rstd_ptr, dpre_ptr, M, N):
+    check(lib().genrl_ln_act_bwd(dy_ptr, N, pre_ptr, N, _p(gamma), _p(beta), mean_ptr, rstd_ptr, dpre_ptr, N, None, None, None,
+                                 None, M, N, 1, 0, _stream()), 'ln_act_bwd')
+
+
+class _Rollout(Function):
+    """WorldModel.imagine's H-step loop (agent/dreamer.py:262-270) as ONE autograd node.
+
+    Per step: policy(sg(feat)) -> rsample -> img_step (img_in + GRU + img_out + dist) -> one-hot sample.
+    The world model is frozen here, so the backward is a pure dgrad chain; doing it in one node lets
+    every gradient sum happen inside a kernel (GEMM `accumulate` epilogues into the cloned time-major
+    gradient buffers, the gate-backward's two-input add) instead of ~150 autograd add / stack / zero
+    kernels per rollout, and hands the policy's gradients to ActorTape in place.
+    Returns time-major stoch (H+1,N,S,K), deter (H+1,N,D), logit (H+1,N,S,K), action (H+1,N,A), raw (H,N,2A)."""
+    @staticmethod
+    def forward(ctx, stoch0, deter0, logit0, eps, q, spec, head_w, head_b, *actor_params):
+        ctx.set_materialize_grads(False)
+        sp, tape = spec, spec.tape
+        H, N = tape.H, tape.N
+        S, K = sp.S, sp.K
+        SK, D = S * K, deter0.shape[1]
+        A = eps.shape[-1]
+        U = sp.in_w.shape[0]
+        dev = deter0.device
+        f = lambda *shape: torch.empty(*shape, device=dev)
+        stoch = f(H + 1, N, SK); deter = f(H + 1, N, D); logit = f(H + 1, N, SK); action = torch.zeros(H + 1, N, A, device=dev)
+        raws = f(H, N, 2 * A)
+        stoch[0].copy_(stoch0.reshape(N, SK)); deter[0].copy_(deter0); logit[0].copy_(logit0.reshape(N, SK))
+        x_pre, x = f(H, N, U), f(H, N, U)
+        g_pre = f(H, N, 3 * D)
+        o_pre, o = f(H, N, U), f(H, N, U)
+        st = {k: f(H, N) for k in ('xm', 'xr', 'gm', 'gr', 'om', 'or')}
+        eps = _f32(eps).contiguous(); q = _f32(q).contiguous()
+        Kin, Kg = sp.in_w.shape[1], sp.gru_w.shape[1]
+        pt = lambda t, off: t.data_ptr() + 4 * off
+        for h in range(H):
+            sN, dN = h * N * SK, h * N * D
+            raw = tape._forward(h, stoch[h], deter[h])
+            raws[h].copy_(raw)
+            check(lib().genrl_actor_head_fwd(pt(raws, h * N * 2 * A), pt(eps, h * N * A), pt(action, (h + 1) * N * A), None, None,
+                                             N, A, sp.min_std, sp.max_std, _stream()), 'actor_head_fwd')
+            # img_in: [stoch_h | action_{h+1}] -> hidden, LN + SiLU
+            sgemm(stoch, SK, 1, sp.in_w, Kin, 1, x_pre, U, sp.in_b, N, U, SK, a_off=sN, c_off=h * N * U)
+            sgemm(action, A, 1, sp.in_w, Kin, 1, x_pre, U, None, N, U, A, accumulate=True, a_off=(h + 1) * N * A, b_off=SK,
+                  c_off=h * N * U)
+            _ln_fwd_raw(pt(x_pre, h * N * U), sp.in_g, sp.in_be, pt(x, h * N * U), pt(st['xm'], h * N), pt(st['xr'], h * N),
+                        N, U, sp.in_eps)
+            # GRU
+            sgemm(x, U, 1, sp.gru_w, Kg, 1, g_pre, 3 * D, None, N, 3 * D, U, a_off=h * N * U, c_off=h * N * 3 * D)
+            sgemm(deter, D, 1, sp.gru_w, Kg, 1, g_pre, 3 * D, None, N, 3 * D, D, accumulate=True, a_off=dN, b_off=U,
+                  c_off=h * N * 3 * D)
+            _gru_fwd_raw(pt(g_pre, h * N * 3 * D), pt(deter, dN), sp.gru_g, sp.gru_be, pt(deter, dN + N * D), None, None,
+                         pt(st['gm'], h * N), pt(st['gr'], h * N), N, D)
+            # prior head: img_out (+LN+SiLU), dist
+            sgemm(deter, D, 1, sp.out_w, D, 1, o_pre, U, sp.out_b, N, U, D, a_off=dN + N * D, c_off=h * N * U)
+            _ln_fwd_raw(pt(o_pre, h * N * U), sp.out_g, sp.out_be, pt(o, h * N * U), pt(st['om'], h * N), pt(st['or'], h * N),
+                        N, U, sp.out_eps)
+            sgemm(o, U, 1, sp.dist_w, U, 1, logit, SK, sp.dist_b, N, SK, U, a_off=h * N * U, c_off=sN + N * SK)
+            check(lib().genrl_onehot_fwd(pt(logit, sN + N * SK), pt(q, h * N * SK), pt(stoch, sN + N * SK), None, N * S, K,
+                                         UNIMIX, _stream()), 'onehot_fwd')
+        tape.inputs = (stoch, deter)
+        ctx.sp = sp
+        ctx.bufs = (stoch, deter, logit, raws, eps, x_pre, g_pre, o_pre, st)
+        ctx.nparams = len(actor_params)
+        ctx.dims = (H, N, S, K, D, A, U)
+        return stoch.reshape(H + 1, N, S, K), deter, logit.reshape(H + 1, N, S, K), action, raws
+
+    @staticmethod
+    def backward(ctx, d_stoch, d_deter, d_logit, d_action, d_raws):
+        sp, tape = ctx.sp, ctx.sp.tape
+        stoch, deter, logit, raws, eps, x_pre, g_pre, o_pre, st = ctx.bufs
+        H, N, S, K, D, A, U = ctx.dims
+        SK = S * K
+        dev = deter.device
+        z = lambda *shape: torch.zeros(*shape, device=dev)
+        ds = d_stoch.reshape(H + 1, N, SK).clone() if d_stoch is not None else z(H + 1, N, SK)
+        dd = d_deter.clone() if d_deter is not None else z(H + 1, N, D)
+        dl_in = d_logit.reshape(H + 1, N, SK).contiguous() if d_logit is not None else None
+        da_in = d_action.contiguous() if d_action is not None else None
+        Kin, Kg = sp.in_w.shape[1], sp.gru_w.shape[1]
+        f = lambda *shape: torch.empty(*shape, device=dev)
+        dlg, do, do_pre, dg_pre, dx, dx_pre, dact = f(N, SK), f(N, U), f(N, U), f(N, 3 * D), f(N, U), f(N, U), f(N, A)
+        dha, dhb = f(N, D), f(N, D)
+        cur, nxt = dha, None                              # ping-pong: recurrent gradient into deter_h from step h's GRU
+        pt = lambda t, off: t.data_ptr() + 4 * off
+        for h in range(H - 1, -1, -1):
+            sN, dN = h * N * SK, h * N * D
+            # grad wrt stoch_{h+1} (complete in ds[h+1]) -> logits (straight-through), plus any direct logit gradient
+            if dl_in is not None:
+                dlg.copy_(dl_in[h + 1])
+            check(lib().genrl_onehot_bwd(pt(logit, sN + N * SK), pt(ds, sN + N * SK), _p(dlg), N * S, K, UNIMIX,
+                                         int(dl_in is not None), _stream()), 'onehot_bwd')
+            sgemm(dlg, SK, 1, sp.dist_w, 1, U, do, U, None, N, U, SK)
+            _ln_bwd_raw(_p(do), pt(o_pre, h * N * U), sp.out_g, sp.out_be, pt(st['om'], h * N), pt(st['or'], h * N), _p(do_pre),
+                        N, U)
+            sgemm(do_pre, U, 1, sp.out_w, 1, D, dd, D, None, N, D, U, accumulate=True, c_off=dN + N * D)
+            # GRU: upstream = dd[h+1] (+ recurrent part from step h+1's GRU, held in `nxt`)
+            _gru_bwd_raw(pt(dd, dN + N * D), nxt.data_ptr() if nxt is not None else None, None, pt(g_pre, h * N * 3 * D),
+                         pt(deter, dN), sp.gru_g, sp.gru_be, pt(st['gm'], h * N), pt(st['gr'], h * N), _p(dg_pre), _p(cur),
+                         None, None, None, N, D, False)
+            sgemm(dg_pre, 3 * D, 1, sp.gru_w, 1, Kg, cur, D, None, N, D, 3 * D, accumulate=True, b_off=U)
+            sgemm(dg_pre, 3 * D, 1, sp.gru_w, 1, Kg, dx, U, None, N, U, 3 * D)
+            _ln_bwd_raw(_p(dx), pt(x_pre, h * N * U), sp.in_g, sp.in_be, pt(st['xm'], h * N), pt(st['xr'], h * N), _p(dx_pre), N, U)
+            sgemm(dx_pre, U, 1, sp.in_w, 1, Kin, ds, SK, None, N, SK, U, accumulate=True, c_off=sN)
+            if da_in is not None:
+                dact.copy_(da_in[h + 1])
+            sgemm(dx_pre, U, 1, sp.in_w, 1, Kin, dact, A, None, N, A, U, accumulate=da_in is not None, b_off=SK)
+            check(lib().genrl_actor_head_bwd(_p(dact), pt(raws, h * N * 2 * A), pt(eps, h * N * A), pt(tape.d_raw, h * N * 2 * A),
+                                             N, A, sp.min_std, sp.max_std, _stream()), 'actor_head_bwd')
+            nxt, cur = cur, (dhb if cur is dha else dha)
+        if d_raws is not None:
+            tape.d_raw += d_raws
+        dWh, dbh, grads = tape._backward()
+        flat = [g for lg in grads for g in lg]
+        return (None, None, None, None, None, None, dWh, dbh, *flat)
+
+
+def imagine_rollout(stoch0, deter0, logit0, eps, q, spec):
+    tape = spec.tape
+    flat = [qq for l in tape.layers for qq in l[:4]]
+    return _Rollout.apply(stoch0, deter0, logit0, eps, q, spec, tape.head_w, tape.head_b, *flat)
+
+
 # ------------------------------------------------------------------ stride-2 convolutions (NHWC)
 
 def _im2col(x, Nimg, Hi, Wi, C, k, mode):
