@@ -14,26 +14,27 @@
 // is measured against (157.3 TFLOP/s).
 //
 // Tiling.  A workgroup owns a BMxBN output tile and has KG "k-groups" of 4 waves (2x2 over the
-// tile, each wave TMxTN 32x32 MFMA tiles).  A BK-deep operand tile is staged in LDS k-major
-// ([k][row]: a wave's fragment read is two contiguous 32-float rows, conflict-free); k-group g
-// multiplies the g-th BK/KG slice of it into its own accumulators, and the KG partial tiles are
-// summed through LDS at the end.  Two shapes are instantiated:
-//   128x128, BK=16, KG=1 (256 threads)  - problems with >= 512 such tiles (M >= ~16K rows);
-//    64x 64, BK=64, KG=4 (1024 threads) - everything else.  The GEMMs of this workload are mostly
-//        M=N=1024 (256 tiles): one workgroup per CU; the 16 waves (4 per SIMD) are what hides the
-//        global->LDS latency, which a 4-wave workgroup per CU cannot (measured 26 -> 52 TF/s with
-//        a global split-K, which in turn costs a reduce pass; the in-workgroup k-groups do not).
-// Global->LDS goes through registers with the next tile's loads issued before the MFMA loop and
-// LDS double-buffered: one barrier per BK.  fp32 MFMA needs one float per operand per lane per
-// 64-cycle instruction, so LDS bandwidth is a non-issue; what matters is waves in flight.
+// tile, each wave TMxTN 32x32 MFMA tiles).  A BK-deep operand tile is staged in LDS (row-contiguous
+// operands k-major [k][rows+4]; k-contiguous operands row-major [row][BK+4], read with ds_read_b128
+// and a k-pairing shared by both operands); k-group g multiplies the g-th BK/KG slice into its own
+// accumulators, and the KG partial tiles are summed through LDS at the end.  Three shapes:
+//   128x128, BK=16, KG=1 (256 threads, 3 per CU)  - problems with >= 512 such tiles (M >= ~16K rows)
+//                                                   or few tiles with a very long K (split-K);
+//    64x 64, BK=16, KG=1 (256 threads, ~8 per CU) - >= 512 tiles of 64x64 (independent barriers);
+//    64x 64, BK=64, KG=4 (1024 threads, 1 per CU) - everything else.  The GEMMs of this workload are
+//        mostly M=N=1024 (256 tiles): one workgroup per CU; the 16 waves (4 per SIMD) are what hides
+//        the global->LDS latency there.
+// Global->LDS goes through registers (branch-free clamped loads two tiles ahead), LDS double-buffered,
+// one barrier per BK; the staging stores sit in the middle of the step's MFMA sequence.
+// M <= 32 rows: skinny_kernel (below).  Implicit stride-2 convolution operands: Gather (below).
 //
-// Split-K over blockIdx.y (deterministic two-pass through a caller workspace) remains for outputs
-// with very few tiles and long reductions (conv weight gradients: 1..54 tiles, K up to ~10^6; the
-// M=32 GEMMs of the observe scan).
+// Launch plan (tile shape x deterministic split-K through a caller workspace): plan_split().
 //
 // Workgroup -> tile mapping is XCD-aware: the dispatcher places block b on XCD b%8, so blocks are
-// remapped such that each XCD walks a contiguous range of tiles (neighbouring tiles share the A
-// row-panel in that XCD's private L2).
+// remapped such that each XCD owns a compact 2-D sub-block of the tile grid (operand panels stay
+// in that XCD's private L2).
+// Yardstick (scripts/blas_ref.py): the vendor's asm-scheduled fp32 kernels reach 95-134 TF/s on these
+// shapes; this file reaches 79-116 (and wins on M <= 128).
 #include "common.h"
 
 #ifdef GENRL_DBG_TIMING
@@ -90,11 +91,7 @@ __global__ __launch_bounds__(256 * KG, (BM == 128 && KG == 1) ? GENRL_BIG_WAVES 
   // group j then contracts k = {8j+e, 8j+4+e}: any pairing is valid as long as both operands use it,
   // so the row-contiguous side reads k = 8j + 4*lk + e.  (+4 floats of padding: the 8 lanes served
   // together hit 8 different 16-B bank groups for BK = 16 and 64.)
-#ifdef GENRL_KC_TRANSPOSED            /* previous layout: transposing 4-B stores, k-major image */
-  constexpr bool KCV = false;
-#else
   constexpr bool KCV = true;
-#endif
   constexpr int LDA = A_KC ? (KCV ? BK + 4 : BM + 1) : BM + 4, LDB = B_KC ? (KCV ? BK + 4 : BN + 1) : BN + 4;
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int AV = BM * BK / 4 / NT, BV = BN * BK / 4 / NT;   // float4 loads per thread per tile
@@ -227,14 +224,7 @@ __global__ __launch_bounds__(256 * KG, (BM == 128 && KG == 1) ? GENRL_BIG_WAVES 
   auto store_tile = [&](float* S, int lds_ld, bool kc, int bdim, const float4& val, int v) {
     if (kc) {
       const int row = v / (BK / 4), kq = (v % (BK / 4)) << 2;
-      if (KCV) {
-        *reinterpret_cast<float4*>(&S[row * lds_ld + kq]) = val;
-      } else {
-        S[(kq + 0) * lds_ld + row] = val.x;
-        S[(kq + 1) * lds_ld + row] = val.y;
-        S[(kq + 2) * lds_ld + row] = val.z;
-        S[(kq + 3) * lds_ld + row] = val.w;
-      }
+      *reinterpret_cast<float4*>(&S[row * lds_ld + kq]) = val;
     } else {
       const int per = bdim >> 2;
       const int k = v / per, rq = (v % per) << 2;
@@ -275,7 +265,6 @@ __global__ __launch_bounds__(256 * KG, (BM == 128 && KG == 1) ? GENRL_BIG_WAVES 
   // the wave does its LDS stores and walks into the barrier, instead of the whole workgroup draining the
   // pipe first (staging after the last MFMA left it idle for the store + barrier + first-read latency
   // of every step).
-#ifndef GENRL_KC_TRANSPOSED
   // MFMAs of one BK step from LDS buffer `buf`; `mid()` runs after MFMA pair GENRL_MID_AT.
   // The register->LDS staging of the next tile goes there: queued MFMAs keep the matrix pipe busy while
   // the wave does its LDS stores and walks into the barrier, instead of the whole workgroup draining the
@@ -337,64 +326,6 @@ __global__ __launch_bounds__(256 * KG, (BM == 128 && KG == 1) ? GENRL_BIG_WAVES 
       if (!PRELOAD) __builtin_amdgcn_sched_barrier(0);
     }
   };
-#else
-  auto compute = [&](int buf, auto&& mid) {
-    const float* as = As + buf * A_SZ + kg * KS * LDA;
-    const float* bs = Bs + buf * B_SZ + kg * KS * LDB;
-    // all LDS operands of the step are requested up front (64x64 tile: 16 registers); the 128x128
-    // tile reads them pair by pair to stay at 3 waves/SIMD
-    constexpr bool PRELOAD = (BM == 64);
-    float av[PRELOAD ? KS / 2 : 1][TM], bv[PRELOAD ? KS / 2 : 1][TN];
-    if (PRELOAD) {
-#pragma unroll
-    for (int kk = 0; kk < KS / 2; ++kk) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) av[kk][i] = as[(2 * kk + lk) * LDA + wm0 + i * 32 + lrow];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bv[kk][j] = bs[(2 * kk + lk) * LDB + wn0 + j * 32 + lrow];
-    }
-    }
-    // 128x128 tile: operands of pair kk+1 are requested BEFORE the MFMAs of pair kk are issued (issuing
-    // TM*TN MFMAs takes >= 256 cycles, which covers the LDS latency), instead of read -> wait -> MFMA
-    float an[TM], bn[TN];
-    if (!PRELOAD) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) an[i] = as[lk * LDA + wm0 + i * 32 + lrow];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bn[j] = bs[lk * LDB + wn0 + j * 32 + lrow];
-    }
-#pragma unroll
-    for (int kk = 0; kk < KS / 2; ++kk) {
-      float a[TM], b[TN];
-      if (PRELOAD) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = av[kk][i];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = bv[kk][j];
-      } else {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = an[i];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = bn[j];
-        if (kk + 1 < KS / 2) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i) an[i] = as[(2 * (kk + 1) + lk) * LDA + wm0 + i * 32 + lrow];
-#pragma unroll
-          for (int j = 0; j < TN; ++j) bn[j] = bs[(2 * (kk + 1) + lk) * LDB + wn0 + j * 32 + lrow];
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs (hipcc sinks them otherwise)
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-      if (!PRELOAD) __builtin_amdgcn_sched_barrier(0);
-      if (kk == GENRL_MID_AT) mid();
-    }
-  };
-
-#endif
 
   // Software pipeline (register stages alternate, LDS double-buffered, one barrier per BK):
   //   step kt: issue global loads of tile kt+2 | MFMA on LDS[kt&1] | registers(tile kt+1) -> LDS[(kt+1)&1]
@@ -422,14 +353,9 @@ __global__ __launch_bounds__(256 * KG, (BM == 128 && KG == 1) ? GENRL_BIG_WAVES 
       // AFTER this step's MFMAs are queued: right after the barrier every wave of the workgroup
       // would hit the CU's single address unit at once (32 KB per step = 512 issue cycles) with the
       // MFMA pipe idle; behind the MFMAs the waves arrive staggered and the issue is hidden.
-#ifdef GENRL_FETCH_EARLY
-      if (kt + 2 < nk) fetch(0, kt + 2);
-#endif
       TICK(0);
       compute(0, [&]() {
-#ifndef GENRL_FETCH_EARLY
         if (kt + 2 < nk) fetch(0, kt + 2);
-#endif
         if (kt + 1 < nk) stage(1, 1);
       });
       TICK(1);
@@ -438,14 +364,9 @@ __global__ __launch_bounds__(256 * KG, (BM == 128 && KG == 1) ? GENRL_BIG_WAVES 
       TICK(3);
       if (kt + 1 >= nk) break;
       // LDS[1] holds tile kt+1, register stage 0 holds tile kt+2
-#ifdef GENRL_FETCH_EARLY
-      if (kt + 3 < nk) fetch(1, kt + 3);
-#endif
       TICK(0);
       compute(1, [&]() {
-#ifndef GENRL_FETCH_EARLY
         if (kt + 3 < nk) fetch(1, kt + 3);
-#endif
         if (kt + 2 < nk) stage(0, 0);
       });
       TICK(1);
