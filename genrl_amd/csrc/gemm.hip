@@ -609,6 +609,10 @@ constexpr int SMALL_BK = GENRL_SMALL_BK, SMALL_KG = GENRL_SMALL_KG;
 struct SplitPlan {
   int big, splits, k_per_split;
 };
+inline bool force_mid() {       // calibration only: GENRL_GEMM_FORCE=m,<splits>
+  static const char* f = getenv("GENRL_GEMM_FORCE");
+  return f && f[0] == 'm';
+}
 constexpr int BIG_WG_PER_CU = GENRL_BIG_KG == 1 ? GENRL_BIG_WAVES : 2;   // 256-thread WGs: one wave per SIMD each
 inline double reduce_cost(long sp, long M, long N) { return sp > 1 ? 5.0 + (double)sp * M * N * 4.0 / 3.0e6 : 0.0; }
 inline SplitPlan plan_split(int M, int N, int K) {
@@ -773,10 +777,11 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
   if (p.big)
     rc = launch_cfg<128, 128, GENRL_BIG_BK, GENRL_BIG_KG, GENRL_BIG_PD>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate,
                                                             p.splits, p.k_per_split, wsp, s, G, gp);
-  else if (p.splits == 1 && (long)cdiv(M, 64) * cdiv(N, 64) >= GENRL_MID_TILES)
+  else if ((p.splits == 1 && (long)cdiv(M, 64) * cdiv(N, 64) >= GENRL_MID_TILES) || force_mid())
     // several 64x64 tiles per CU: 256-thread workgroups (one wave per SIMD each, 4+ resident per CU,
     // independent barriers) beat the single 1024-thread workgroup per CU by 10-13 % (measured)
-    rc = launch_cfg<64, 64, 16, 1, 2>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, 1, K, nullptr, s, G, gp);
+    rc = launch_cfg<64, 64, 16, 1, 2>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, p.splits,
+                                      p.k_per_split, wsp, s, G, gp);
   else
     rc = launch_cfg<64, 64, SMALL_BK, SMALL_KG, GENRL_SMALL_PD>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K,
                                                                accumulate, p.splits, p.k_per_split, wsp, s, G, gp);
