@@ -88,6 +88,16 @@ class OneHotDist:
     def mode(self):
         return ops.onehot_mode(self.logits_raw)
 
+    @property
+    def probs(self):
+        """Class probabilities after the 1 % uniform mix (what OneHotCategorical(probs=...) holds, ref :179-183)."""
+        K = self.logits_raw.shape[-1]
+        return ops.UNIMIX * torch.softmax(self.logits_raw.float(), -1) + (1.0 - ops.UNIMIX) / K
+
+    @property
+    def mean(self):          # OneHotCategorical.mean; train.py:297 stores it as the start 'logit' of data-free rollouts
+        return self.probs
+
     def entropy(self):
         return ops.cat_entropy(self.logits_raw)
 
