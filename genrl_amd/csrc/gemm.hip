@@ -78,13 +78,15 @@ __device__ __forceinline__ int fdiv(int x, int d, float inv) {
 }
 
 template <int BM, int BN, int BK, int KG, int PD, bool FAST, bool A_KC, bool B_KC, int G = 0>
-__global__ __launch_bounds__(256 * KG, (BM == 128 && KG == 1) ? GENRL_BIG_WAVES : 1) void sgemm_kernel(
+__global__ __launch_bounds__(64 * (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1) * KG, (BM == 128 && KG == 1) ? GENRL_BIG_WAVES : 1) void sgemm_kernel(
     const float* __restrict__ A, long a_ld, const float* __restrict__ B, long b_ld,
     float* __restrict__ C, long ldc, const float* __restrict__ bias, int M, int N, int Ktot,
     int accumulate, int a_vec, int b_vec, int tiles_n, int ntiles, int k_per_split, float* __restrict__ ws,
     int tiles_m, int xcd_m, Gather g) {
   static_assert(G == 0 || (FAST && ((G == 1 && A_KC && B_KC) || (G == 2 && !A_KC && !B_KC))), "gather variants");
-  constexpr int NT = 256 * KG;
+  // waves of one k-group: WGM x WGN over the tile (2x2 from 64x64 up, a single wave for a 32x32 tile)
+  constexpr int WGM = BM >= 64 ? 2 : 1, WGN = BN >= 64 ? 2 : 1, WPG = WGM * WGN;
+  constexpr int NT = 64 * WPG * KG;
   // LDS images.  Row-contiguous operand: k-major [k][rows + 4], 16-B stores, 4-B fragment reads.
   // k-contiguous operand: kept row-major [row][BK + 4] (16-B stores, no transpose); a lane reads the
   // 16 bytes A[row][8j + 4*lk .. +3] with one ds_read_b128 and feeds 4 MFMAs from it — MFMA e of
@@ -93,13 +95,13 @@ __global__ __launch_bounds__(256 * KG, (BM == 128 && KG == 1) ? GENRL_BIG_WAVES 
   // together hit 8 different 16-B bank groups for BK = 16 and 64.)
   constexpr bool KCV = true;
   constexpr int LDA = A_KC ? (KCV ? BK + 4 : BM + 1) : BM + 4, LDB = B_KC ? (KCV ? BK + 4 : BN + 1) : BN + 4;
-  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
   constexpr int AV = BM * BK / 4 / NT, BV = BN * BK / 4 / NT;   // float4 loads per thread per tile
   static_assert(AV >= 1 && BV >= 1, "tile too small for the thread count");
   constexpr int KS = BK / KG;                                   // k-slice per k-group
   constexpr int A_SZ = (A_KC && KCV) ? BM * LDA : BK * LDA, B_SZ = (B_KC && KCV) ? BN * LDB : BK * LDB;
   static_assert(!KCV || (BK / KG) % 8 == 0, "k-slice per k-group must be a multiple of 8");
-  constexpr int RED_SZ = (KG - 1) * 4 * TM * TN * 16 * 64;       // KG owners x (KG-1) slots x 16/KG regs
+  constexpr int RED_SZ = (KG - 1) * WPG * TM * TN * 16 * 64;       // KG owners x (KG-1) slots x 16/KG regs
   constexpr int LDS_FLOATS = (2 * (A_SZ + B_SZ) > RED_SZ) ? 2 * (A_SZ + B_SZ) : RED_SZ;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   float* As = lds;                 // [2][A_SZ]
@@ -137,8 +139,8 @@ __global__ __launch_bounds__(256 * KG, (BM == 128 && KG == 1) ? GENRL_BIG_WAVES 
     accumulate = 0;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kg = wave >> 2, w4 = wave & 3;
-  const int wm0 = (w4 >> 1) * (BM / 2), wn0 = (w4 & 1) * (BN / 2);
+  const int kg = wave / WPG, w4 = wave % WPG;
+  const int wm0 = (w4 / WGN) * (BM / WGM), wn0 = (w4 % WGN) * (BN / WGN);
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256 * KG, (BM == 128 && KG == 1) ? GENRL_BIG_WAVES 
     };
     // 64x64 tile: every group of the step is requested up front (16 registers); 128x128 tile: one group
     // ahead of the MFMAs (issuing 4*TM*TN MFMAs covers the LDS latency) to stay at 3 waves/SIMD
-    constexpr bool PRELOAD = (BM == 64);
+    constexpr bool PRELOAD = (BM <= 64);
     constexpr int NB = PRELOAD ? NG : 2;
     float ga[NB][TM][4], gb[NB][TN][4];
     if (PRELOAD) {
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(256 * KG, (BM == 128 && KG == 1) ? GENRL_BIG_WAVES 
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < RPG; ++r)
-            red[(((((o * (KG - 1) + slot) * 4 + w4) * TM * TN + i * TN + j) * RPG + r) * 64) + lane] =
+            red[(((((o * (KG - 1) + slot) * WPG + w4) * TM * TN + i * TN + j) * RPG + r) * 64) + lane] =
                 acc[i][j][o * RPG + r];
     }
     __syncthreads();
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(256 * KG, (BM == 128 && KG == 1) ? GENRL_BIG_WAVES 
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < RPG; ++r) {
-            const float v = red[(((((kg * (KG - 1) + slot) * 4 + w4) * TM * TN + i * TN + j) * RPG + r) * 64) + lane];
+            const float v = red[(((((kg * (KG - 1) + slot) * WPG + w4) * TM * TN + i * TN + j) * RPG + r) * 64) + lane];
             // static register index: select the owned register with a compile-time unrolled loop
 #pragma unroll
             for (int o = 0; o < KG; ++o)
@@ -685,7 +687,7 @@ int launch_cfg(const float* A, long a_rs, long a_ks, const float* B, long b_rs, 
     else b_vec = ok && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
   }
   const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN), ntiles = tiles_m * tiles_n;
-  dim3 grid(ntiles, splits), block(256 * KG);
+  dim3 grid(ntiles, splits), block(64 * (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1) * KG);
   // XCD sub-block shape: xcd_m x (8/xcd_m) XCDs over the tile grid, minimising the per-XCD operand
   // footprint  sub_m*BM*K (A panels) + sub_n*BN*K (B panels)
   int xcd_m = 0;
