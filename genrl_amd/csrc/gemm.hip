@@ -36,6 +36,7 @@
 // Yardstick (scripts/blas_ref.py): the vendor's asm-scheduled fp32 kernels reach 95-134 TF/s on these
 // shapes; this file reaches 79-116 (and wins on M <= 128).
 #include "common.h"
+#include <type_traits>
 
 #ifdef GENRL_DBG_TIMING
 // per-wave phase cycle counts of the most recent launch: [slot = (block*16 + wave) % 65536][6]
@@ -461,6 +462,275 @@ __global__ __launch_bounds__(64 * (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1) * KG, 
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Register-resident-operand variant (64x64 tile, BK = 64, 256 threads = 2x2 waves of 32x32, ONE LDS
+// buffer).  Structure of one K iteration, per wave:
+//   1. every LDS fragment of the tile is read into registers up front (64 VGPRs: 4 k-groups x 2
+//      fragments x 4 values per operand) while the first MFMAs run;
+//   2. barrier: the LDS tile is dead for every wave; the tile after it (global loads issued a whole
+//      iteration ago) is stored to the SAME buffer, one 16-byte store + one new global load at a time,
+//      spread between the remaining MFMAs;
+//   3. barrier: next tile visible.
+// 64 MFMAs (v_mfma_f32_16x16x4_f32, four independent 16x16 accumulators = no dependent-issue stalls)
+// per iteration and only two barriers; no second LDS buffer, so several workgroups fit per CU.
+// Same operand conventions / loaders / epilogue as sgemm_kernel (FAST preconditions required).
+template <bool A_KC, bool B_KC, int G, bool KX>
+__global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
+    const float* __restrict__ A, long a_ld, const float* __restrict__ B, long b_ld,
+    float* __restrict__ C, long ldc, const float* __restrict__ bias, int M, int N, int Ktot,
+    int accumulate, int tiles_n, int ntiles, int k_per_split, float* __restrict__ ws, int tiles_m, int xcd_m, Gather g) {
+  constexpr int BM = 64, BN = 64, BK = 64, NT = 256, NV = 4;       // NV float4 per thread per operand
+  constexpr int LDA = A_KC ? BK + 4 : BM + 4, LDB = B_KC ? BK + 4 : BN + 4;
+  constexpr int A_SZ = A_KC ? BM * LDA : BK * LDA, B_SZ = B_KC ? BN * LDB : BK * LDB;
+  __shared__ __attribute__((aligned(16))) float lds[A_SZ + B_SZ];
+  float* As = lds;
+  float* Bs = lds + A_SZ;
+  int bid = blockIdx.x, tile_m, tile_n;
+  {
+    const int x = bid % 8, i = bid / 8;
+    if (xcd_m > 0) {
+      const int sub_m = tiles_m / xcd_m, sub_n = tiles_n / (8 / xcd_m);
+      const int xm = x / (8 / xcd_m), xn = x % (8 / xcd_m);
+      tile_m = xm * sub_m + i / sub_n;
+      tile_n = xn * sub_n + i % sub_n;
+    } else {
+      const int q = ntiles / 8, r = ntiles % 8;
+      bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+      tile_m = bid / tiles_n;
+      tile_n = bid % tiles_n;
+    }
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kbeg = blockIdx.y * k_per_split;
+  const int K = min(Ktot, kbeg + k_per_split);
+  if (ws) {
+    C = ws + (long)blockIdx.y * M * N;
+    ldc = N;
+    bias = nullptr;
+    accumulate = 0;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+  const int l16 = lane & 15, q4 = lane >> 4;
+
+  auto gbase = [&](int m) -> long {
+    const int n = fdiv(m, g.ohw, g.inv_ohw), r = m - n * g.ohw;
+    const int oy = fdiv(r, g.ow, g.inv_ow), ox = r - oy * g.ow;
+    return (long)n * g.sn + (long)oy * g.sy + (long)ox * g.sx;
+  };
+  auto gseg = [&](int kk) -> long {
+    const int sgi = fdiv(kk, g.seg_len, g.inv_seg);
+    return (long)sgi * g.seg_stride + (kk - sgi * g.seg_len);
+  };
+  // branch-free clamped loads (see sgemm_kernel::load_fast); returns the in-bounds flag
+  auto gload = [&](const float* __restrict__ P, long ld, int rows_total, int r0, int k0, bool kc, float4& out, int v,
+                   bool gath) -> bool {
+    bool inb;
+    if (kc) {
+      const int row = r0 + v / (BK / 4), k = k0 + ((v % (BK / 4)) << 2);
+      inb = k < K;
+      const int rc = min(row, rows_total - 1), kc_ = min(k, Ktot - 4);
+      out = gath ? *reinterpret_cast<const float4*>(P + gbase(rc) + gseg(kc_))
+                 : *reinterpret_cast<const float4*>(P + (long)rc * ld + kc_);
+    } else {
+      const int k = k0 + v / 16, row = r0 + ((v % 16) << 2);
+      inb = (k < K) && (row < rows_total);
+      const int kc_ = min(k, Ktot - 1), rc = min(row, rows_total - 4);
+      out = gath ? *reinterpret_cast<const float4*>(P + gbase(kc_) + gseg(rc))
+                 : *reinterpret_cast<const float4*>(P + (long)kc_ * ld + rc);
+    }
+    return inb;
+  };
+  auto lstore = [&](float* S, int ld, bool kc, float4 val, bool inb, int v) {
+    if (!KX && !inb) val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kc) *reinterpret_cast<float4*>(&S[(v / (BK / 4)) * ld + ((v % (BK / 4)) << 2)]) = val;
+    else *reinterpret_cast<float4*>(&S[(v / 16) * ld + ((v % 16) << 2)]) = val;
+  };
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // two register sets: tile kt+1 waits in one while tile kt+2 is still in flight into the other (a load
+  // has two whole iterations to land: MALL/HBM latency exceeds one ~1 us iteration)
+  float4 ra[2][NV], rb[2][NV];
+  bool ia[2][NV], ib[2][NV];
+  const int nk = (K - kbeg + BK - 1) / BK;
+  // KX (every split's K range is a whole number of BK steps, no gather): each staged vector has a
+  // per-thread pointer that simply advances by one tile per load — no clamps, flags or selects in the
+  // loop (rows beyond M/N are clamped once; their outputs are never stored).  Loads past the last tile
+  // wrap to the operand's first tile (always valid memory, never consumed).
+  const float* pa[NV];
+  const float* pb[NV];
+  const long stepA = A_KC ? BK : (long)BK * a_ld, stepB = B_KC ? BK : (long)BK * b_ld;
+  int lefta = nk, leftb = nk;              // tiles still to be fetched (scalar)
+  if (KX) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + i * NT;
+      if (A_KC) pa[i] = A + (long)min(m0 + v / 16, M - 1) * a_ld + kbeg + ((v % 16) << 2);
+      else pa[i] = A + (long)(kbeg + v / 16) * a_ld + min(m0 + ((v % 16) << 2), M - 4);
+      if (B_KC) pb[i] = B + (long)min(n0 + v / 16, N - 1) * b_ld + kbeg + ((v % 16) << 2);
+      else pb[i] = B + (long)(kbeg + v / 16) * b_ld + min(n0 + ((v % 16) << 2), N - 4);
+      ia[0][i] = ib[0][i] = ia[1][i] = ib[1][i] = true;
+    }
+  }
+  auto nextA = [&](int st, int i) {        // KX: load the thread's i-th A vector of the next unfetched tile
+    ra[st][i] = *reinterpret_cast<const float4*>(pa[i]);
+    pa[i] += (lefta > 1) ? stepA : 0;      // (uniform) stay on the last tile once it has been fetched
+  };
+  auto nextB = [&](int st, int i) {
+    rb[st][i] = *reinterpret_cast<const float4*>(pb[i]);
+    pb[i] += (leftb > 1) ? stepB : 0;
+  };
+  auto fetch_all = [&](int st, int kt) {
+    if (KX) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) nextA(st, i);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) nextB(st, i);
+      --lefta; --leftb;
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) ia[st][i] = gload(A, a_ld, M, m0, kbeg + kt * BK, A_KC, ra[st][i], tid + i * NT, G == 1);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) ib[st][i] = gload(B, b_ld, N, n0, kbeg + kt * BK, B_KC, rb[st][i], tid + i * NT, G == 2);
+  };
+  // prologue: tile 0 -> LDS, tile 1 -> register set 1, tile 2 -> register set 0
+  fetch_all(0, 0);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) lstore(As, LDA, A_KC, ra[0][i], ia[0][i], tid + i * NT);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) lstore(Bs, LDB, B_KC, rb[0][i], ib[0][i], tid + i * NT);
+  fetch_all(1, 1);
+  fetch_all(0, 2);
+  __syncthreads();
+
+  // fragments: fa[j][bi][e] = A(row = wm0 + 16 bi + lane%16, k = 16 j + 4 (lane/16) + e), same for B
+  float fa[4][2][4], fb[4][2][4];
+  auto read_frags = [&](int j) {
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi) {
+      if (A_KC) {
+        const float4 v = *reinterpret_cast<const float4*>(&As[(wm0 + 16 * bi + l16) * LDA + 16 * j + 4 * q4]);
+        fa[j][bi][0] = v.x; fa[j][bi][1] = v.y; fa[j][bi][2] = v.z; fa[j][bi][3] = v.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fa[j][bi][e] = As[(16 * j + 4 * q4 + e) * LDA + wm0 + 16 * bi + l16];
+      }
+      if (B_KC) {
+        const float4 v = *reinterpret_cast<const float4*>(&Bs[(wn0 + 16 * bi + l16) * LDB + 16 * j + 4 * q4]);
+        fb[j][bi][0] = v.x; fb[j][bi][1] = v.y; fb[j][bi][2] = v.z; fb[j][bi][3] = v.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fb[j][bi][e] = Bs[(16 * j + 4 * q4 + e) * LDB + wn0 + 16 * bi + l16];
+      }
+    }
+  };
+  auto mma4 = [&](int j, int e) {
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj)
+        acc[bi][bj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j][bi][e], fb[j][bj][e], acc[bi][bj], 0, 0, 0);
+  };
+  read_frags(0);
+  auto iteration = [&](int kt, auto ST) {
+    constexpr int st = decltype(ST)::value;     // register set holding tile kt+1; refilled with tile kt+3
+    // 1. the rest of tile kt's fragments -> registers, behind the first 16 MFMAs
+#ifndef RR_NO_READS
+    read_frags(1); read_frags(2); read_frags(3);
+#endif
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mma4(0, e);
+#ifndef RR_NO_BARRIER
+    __syncthreads();                       // 2. the LDS tile is dead: refill it behind the next 44 MFMAs
+#endif
+    // after each of the first 8 of the next 11 groups of 4 MFMAs one staged vector goes to LDS and its registers are re-armed
+    // with the load for tile kt+2.  Everything is unconditional (clamped addresses are always valid; the
+    // final iterations stage zeros nobody reads): one basic block, counted waits.
+    const int k2 = kbeg + (kt + 3) * BK;
+#pragma unroll
+    for (int gi = 0; gi < 11; ++gi) {
+      mma4(1 + gi / 4, gi % 4);
+#ifndef RR_NO_STAGE
+      if (gi < 2 * NV) {                           // stores early: the last three groups cover their latency
+        const int u = gi;                          // before the barrier
+        if (u < NV) {
+          lstore(As, LDA, A_KC, ra[st][u], ia[st][u], tid + u * NT);
+          if (KX) nextA(st, u);
+          else ia[st][u] = gload(A, a_ld, M, m0, k2, A_KC, ra[st][u], tid + u * NT, G == 1);
+        } else {
+          lstore(Bs, LDB, B_KC, rb[st][u - NV], ib[st][u - NV], tid + (u - NV) * NT);
+          if (KX) nextB(st, u - NV);
+          else ib[st][u - NV] = gload(B, b_ld, N, n0, k2, B_KC, rb[st][u - NV], tid + (u - NV) * NT, G == 2);
+        }
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (KX) { --lefta; --leftb; }
+#ifndef RR_NO_BARRIER
+    __syncthreads();                       // 3. next tile visible
+#endif
+    //: its first fragments are requested behind the
+    float na[2][4], nb[2][4];              //    last 4 MFMAs of this one
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi) {
+      if (A_KC) {
+        const float4 v = *reinterpret_cast<const float4*>(&As[(wm0 + 16 * bi + l16) * LDA + 4 * q4]);
+        na[bi][0] = v.x; na[bi][1] = v.y; na[bi][2] = v.z; na[bi][3] = v.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) na[bi][e] = As[(4 * q4 + e) * LDA + wm0 + 16 * bi + l16];
+      }
+      if (B_KC) {
+        const float4 v = *reinterpret_cast<const float4*>(&Bs[(wn0 + 16 * bi + l16) * LDB + 4 * q4]);
+        nb[bi][0] = v.x; nb[bi][1] = v.y; nb[bi][2] = v.z; nb[bi][3] = v.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) nb[bi][e] = Bs[(4 * q4 + e) * LDB + wn0 + 16 * bi + l16];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma4(3, 3);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        fa[0][bi][e] = na[bi][e];
+        fb[0][bi][e] = nb[bi][e];
+      }
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    iteration(kt, std::integral_constant<int, 1>{});
+    if (kt + 1 < nk) iteration(kt + 1, std::integral_constant<int, 0>{});
+  }
+
+  // ---- epilogue: 16x16 blocks, D[row = 4*(lane/16) + v][col = lane%16]
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+      const int col = n0 + wn0 + 16 * bj + l16;
+      if (col >= N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = m0 + wm0 + 16 * bi + 4 * q4 + v;
+        if (row < M) {
+          float* c = C + (long)row * ldc + col;
+          float val = acc[bi][bj][v] + bv;
+          if (accumulate) val += *c;
+          *c = val;
+        }
+      }
+    }
+}
+
 // C[m,n] = sum_s ws[s][m][n] (+bias[n]) (+C[m,n])
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, long ldc,
                                      const float* __restrict__ bias, int M, int N, int splits, int accumulate) {
@@ -611,6 +881,16 @@ constexpr int SMALL_BK = GENRL_SMALL_BK, SMALL_KG = GENRL_SMALL_KG;
 struct SplitPlan {
   int big, splits, k_per_split;
 };
+// sgemm_rr_kernel (256 threads, one wave per SIMD per workgroup, several workgroups per CU) is the default for
+// every 64x64-tile product whose operands meet the vector-load preconditions; the 1024-thread k-group kernel
+// remains the fallback for the others.  Measured alone the two are within 2 % on 1024^3 (27.0 vs 26.6 us) and rr
+// wins from 512 tiles up and for K >= 2048 (1024x3072x1024: 70 vs 74 us, 1024x1024x3072: 70 vs 79 us); inside
+// the training step, where kernels of other streams share the CUs, rr everywhere is 0.85 ms / step faster.
+// GENRL_GEMM_RR=0 disables it (calibration).
+inline bool use_rr(int M, int N, int K, int splits) {
+  static const char* f = getenv("GENRL_GEMM_RR");
+  return !(f && f[0] == '0');
+}
 inline bool force_mid() {       // calibration only: GENRL_GEMM_FORCE=m,<splits>
   static const char* f = getenv("GENRL_GEMM_FORCE");
   return f && f[0] == 'm';
@@ -734,6 +1014,58 @@ int launch_cfg(const float* A, long a_rs, long a_ks, const float* B, long b_rs, 
   return GENRL_OK;
 }
 
+// launch the register-resident-operand 64x64 kernel (FAST preconditions hold; returns -1 if they do not)
+int launch_rr(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks, float* C, long ldc,
+              const float* bias, int M, int N, int K, int accumulate, int splits, int kps, float* ws, hipStream_t s,
+              int G, const Gather* gp) {
+  const bool a_kc = (a_ks == 1), b_kc = (b_ks == 1);
+  const long a_ld = a_kc ? a_rs : a_ks, b_ld = b_kc ? b_rs : b_ks;
+  int a_vec = ((a_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  int b_vec = ((b_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  Gather g{};
+  if (G) {
+    g = *gp;
+    const int ok = ((g.seg_len | g.seg_stride | g.sn | g.sy | g.sx) & 3) == 0;
+    if (G == 1) a_vec = ok && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    else b_vec = ok && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  }
+  const bool k4 = (K % 4 == 0) && K >= 4;
+  const bool fast = a_vec && b_vec && ((!a_kc && !b_kc) || k4) && (a_kc || (M % 4 == 0 && M >= 4)) &&
+                    (b_kc || (N % 4 == 0 && N >= 4));
+  if (!fast || (G == 1 && !(a_kc && b_kc)) || (G == 2 && (a_kc || b_kc))) return -1;
+  const int tiles_m = cdiv(M, 64), tiles_n = cdiv(N, 64), ntiles = tiles_m * tiles_n;
+  int xcd_m = 0;
+  {
+    double best = 1e30;
+    for (int xm = 1; xm <= 8; xm *= 2) {
+      const int xn = 8 / xm;
+      if (tiles_m % xm || tiles_n % xn) continue;
+      const double fp = (double)(tiles_m / xm) * 64 + (double)(tiles_n / xn) * 64;
+      if (fp < best) {
+        best = fp;
+        xcd_m = xm;
+      }
+    }
+  }
+  dim3 grid(ntiles, splits), block(256);
+  const bool kx = !G && (K % 64 == 0) && (kps % 64 == 0) && M >= 4 && N >= 4;
+#define GO(AK, BKC, GG, KXV)                                                                                        \
+  hipLaunchKernelGGL((sgemm_rr_kernel<AK, BKC, GG, KXV>), grid, block, 0, s, A, a_ld, B, b_ld, C, ldc, bias, M, N, K, \
+                     accumulate, tiles_n, ntiles, kps, ws, tiles_m, xcd_m, g)
+#define GO2(AK, BKC) \
+  if (kx) GO(AK, BKC, 0, true); else GO(AK, BKC, 0, false)
+  if (G == 1) GO(true, true, 1, false);
+  else if (G == 2) GO(false, false, 2, false);
+  else if (a_kc && b_kc) { GO2(true, true); }
+  else if (a_kc && !b_kc) { GO2(true, false); }
+  else if (!a_kc && b_kc) { GO2(false, true); }
+  else { GO2(false, false); }
+#undef GO2
+#undef GO
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}
+
 }  // namespace
 
 static int g_last_error = 0;
@@ -779,6 +1111,9 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
   if (p.big)
     rc = launch_cfg<128, 128, GENRL_BIG_BK, GENRL_BIG_KG, GENRL_BIG_PD>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate,
                                                             p.splits, p.k_per_split, wsp, s, G, gp);
+  else if (use_rr(M, N, K, p.splits) && (rc = launch_rr(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, p.splits,
+                                       (p.k_per_split + 63) / 64 * 64, wsp, s, G, gp)) >= 0)
+    ;
   else if ((p.splits == 1 && (long)cdiv(M, 64) * cdiv(N, 64) >= GENRL_MID_TILES) || force_mid())
     // several 64x64 tiles per CU: 256-thread workgroups (one wave per SIMD each, 4+ resident per CU,
     // independent barriers) beat the single 1024-thread workgroup per CU by 10-13 % (measured)
