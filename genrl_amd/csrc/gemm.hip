@@ -45,6 +45,9 @@ extern "C" void genrl_dbg_read(unsigned long long* out, int nslots) {
   hipMemcpyFromSymbol(out, HIP_SYMBOL(genrl_dbg_cycles), sizeof(unsigned long long) * 6 * nslots);
 }
 #endif
+#ifndef GENRL_RR_PD4
+#define GENRL_RR_PD4(WB) 2   /* register sets (tiles in flight) of sgemm_rr_kernel */
+#endif
 #ifndef GENRL_MID_TILES
 #define GENRL_MID_TILES 512    /* 64x64 tiles from which the 256-thread variant of the small tile is used */
 #endif
@@ -463,23 +466,31 @@ __global__ __launch_bounds__(64 * (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1) * KG, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Register-resident-operand variant (64x64 tile, BK = 64, 256 threads = 2x2 waves of 32x32, ONE LDS
-// buffer).  Structure of one K iteration, per wave:
-//   1. every LDS fragment of the tile is read into registers up front (64 VGPRs: 4 k-groups x 2
-//      fragments x 4 values per operand) while the first MFMAs run;
-//   2. barrier: the LDS tile is dead for every wave; the tile after it (global loads issued a whole
-//      iteration ago) is stored to the SAME buffer, one 16-byte store + one new global load at a time,
-//      spread between the remaining MFMAs;
-//   3. barrier: next tile visible.
-// 64 MFMAs (v_mfma_f32_16x16x4_f32, four independent 16x16 accumulators = no dependent-issue stalls)
-// per iteration and only two barriers; no second LDS buffer, so several workgroups fit per CU.
-// Same operand conventions / loaders / epilogue as sgemm_kernel (FAST preconditions required).
-template <bool A_KC, bool B_KC, int G, bool KX>
+// Register-resident-operand kernels: 256 threads = 2x2 waves, ONE LDS buffer, MFMA 16x16x4 with
+// WB x WB independent 16x16 accumulators per wave (no dependent-issue stalls).
+//   WB = 2: 64x64 tile,  BK = 64, global loads two tiles ahead (two register sets);
+//   WB = 4: 128x128 tile, BK = 32, two tiles ahead as well (164-222 VGPRs: 2 waves per SIMD either way).
+// One K iteration, per wave:
+//   1. the LDS fragments of the tile that are not yet in registers are read while the MFMAs of the
+//      first k-group (preloaded at the end of the previous iteration) run;
+//   2. barrier: the LDS tile is dead for every wave; the next tile (global loads issued one / two
+//      iterations ago) is stored into the SAME buffer, one 16-byte store + one re-arming global load at
+//      a time, spread between the following MFMAs;
+//   3. barrier: next tile visible; its first fragments are requested behind the last MFMAs.
+// Two barriers per 64 (WB=2) / 128 (WB=4) MFMAs and no second LDS buffer, so several workgroups fit per
+// CU and their barriers are independent.  Same operand conventions / loaders / epilogue as
+// sgemm_kernel (vector-load preconditions required).  KX: every split's K range is a whole number of
+// BK steps and no gather -> per-thread pointers that just advance, no clamps/flags/selects in the loop.
+template <int WB, bool A_KC, bool B_KC, int G, bool KX>
 __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
     const float* __restrict__ A, long a_ld, const float* __restrict__ B, long b_ld,
     float* __restrict__ C, long ldc, const float* __restrict__ bias, int M, int N, int Ktot,
     int accumulate, int tiles_n, int ntiles, int k_per_split, float* __restrict__ ws, int tiles_m, int xcd_m, Gather g) {
-  constexpr int BM = 64, BN = 64, BK = 64, NT = 256, NV = 4;       // NV float4 per thread per operand
+  constexpr int BM = 32 * WB, BN = 32 * WB, BK = WB == 2 ? 64 : 32, NT = 256;
+  constexpr int NV = BM * BK / 4 / NT;                              // float4 per thread per operand (= 4)
+  constexpr int NJ = BK / 16, KV = BK / 4, RV = BM / 4;             // k-groups of 16; vectors per k-row / per tile row
+  constexpr int PDEPTH = GENRL_RR_PD4(WB);
+  constexpr int WT = 16 * WB;                                       // wave tile edge
   constexpr int LDA = A_KC ? BK + 4 : BM + 4, LDB = B_KC ? BK + 4 : BN + 4;
   constexpr int A_SZ = A_KC ? BM * LDA : BK * LDA, B_SZ = B_KC ? BN * LDB : BK * LDB;
   __shared__ __attribute__((aligned(16))) float lds[A_SZ + B_SZ];
@@ -510,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
     accumulate = 0;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+  const int wm0 = (wave >> 1) * WT, wn0 = (wave & 1) * WT;
   const int l16 = lane & 15, q4 = lane >> 4;
 
   auto gbase = [&](int m) -> long {
@@ -527,13 +538,13 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
                    bool gath) -> bool {
     bool inb;
     if (kc) {
-      const int row = r0 + v / (BK / 4), k = k0 + ((v % (BK / 4)) << 2);
+      const int row = r0 + v / KV, k = k0 + ((v % KV) << 2);
       inb = k < K;
       const int rc = min(row, rows_total - 1), kc_ = min(k, Ktot - 4);
       out = gath ? *reinterpret_cast<const float4*>(P + gbase(rc) + gseg(kc_))
                  : *reinterpret_cast<const float4*>(P + (long)rc * ld + kc_);
     } else {
-      const int k = k0 + v / 16, row = r0 + ((v % 16) << 2);
+      const int k = k0 + v / RV, row = r0 + ((v % RV) << 2);
       inb = (k < K) && (row < rows_total);
       const int kc_ = min(k, Ktot - 1), rc = min(row, rows_total - 4);
       out = gath ? *reinterpret_cast<const float4*>(P + gbase(kc_) + gseg(rc))
@@ -543,24 +554,20 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
   };
   auto lstore = [&](float* S, int ld, bool kc, float4 val, bool inb, int v) {
     if (!KX && !inb) val = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (kc) *reinterpret_cast<float4*>(&S[(v / (BK / 4)) * ld + ((v % (BK / 4)) << 2)]) = val;
-    else *reinterpret_cast<float4*>(&S[(v / 16) * ld + ((v % 16) << 2)]) = val;
+    if (kc) *reinterpret_cast<float4*>(&S[(v / KV) * ld + ((v % KV) << 2)]) = val;
+    else *reinterpret_cast<float4*>(&S[(v / RV) * ld + ((v % RV) << 2)]) = val;
   };
 
-  f32x4 acc[2][2];
+  f32x4 acc[WB][WB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WB; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // two register sets: tile kt+1 waits in one while tile kt+2 is still in flight into the other (a load
-  // has two whole iterations to land: MALL/HBM latency exceeds one ~1 us iteration)
-  float4 ra[2][NV], rb[2][NV];
-  bool ia[2][NV], ib[2][NV];
+    for (int j = 0; j < WB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // register sets of staged tiles (PDEPTH 2: tile kt+1 waits in one while tile kt+2 is in flight into the
+  // other — a load then has two whole iterations to land; MALL/HBM latency exceeds one ~1 us iteration)
+  float4 ra[PDEPTH][NV], rb[PDEPTH][NV];
+  bool ia[PDEPTH][NV], ib[PDEPTH][NV];
   const int nk = (K - kbeg + BK - 1) / BK;
-  // KX (every split's K range is a whole number of BK steps, no gather): each staged vector has a
-  // per-thread pointer that simply advances by one tile per load — no clamps, flags or selects in the
-  // loop (rows beyond M/N are clamped once; their outputs are never stored).  Loads past the last tile
-  // wrap to the operand's first tile (always valid memory, never consumed).
   const float* pa[NV];
   const float* pb[NV];
   const long stepA = A_KC ? BK : (long)BK * a_ld, stepB = B_KC ? BK : (long)BK * b_ld;
@@ -569,11 +576,12 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int v = tid + i * NT;
-      if (A_KC) pa[i] = A + (long)min(m0 + v / 16, M - 1) * a_ld + kbeg + ((v % 16) << 2);
-      else pa[i] = A + (long)(kbeg + v / 16) * a_ld + min(m0 + ((v % 16) << 2), M - 4);
-      if (B_KC) pb[i] = B + (long)min(n0 + v / 16, N - 1) * b_ld + kbeg + ((v % 16) << 2);
-      else pb[i] = B + (long)(kbeg + v / 16) * b_ld + min(n0 + ((v % 16) << 2), N - 4);
-      ia[0][i] = ib[0][i] = ia[1][i] = ib[1][i] = true;
+      if (A_KC) pa[i] = A + (long)min(m0 + v / KV, M - 1) * a_ld + kbeg + ((v % KV) << 2);
+      else pa[i] = A + (long)(kbeg + v / RV) * a_ld + min(m0 + ((v % RV) << 2), M - 4);
+      if (B_KC) pb[i] = B + (long)min(n0 + v / KV, N - 1) * b_ld + kbeg + ((v % KV) << 2);
+      else pb[i] = B + (long)(kbeg + v / RV) * b_ld + min(n0 + ((v % RV) << 2), N - 4);
+#pragma unroll
+      for (int st = 0; st < PDEPTH; ++st) ia[st][i] = ib[st][i] = true;
     }
   }
   auto nextA = [&](int st, int i) {        // KX: load the thread's i-th A vector of the next unfetched tile
@@ -598,66 +606,61 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
 #pragma unroll
     for (int i = 0; i < NV; ++i) ib[st][i] = gload(B, b_ld, N, n0, kbeg + kt * BK, B_KC, rb[st][i], tid + i * NT, G == 2);
   };
-  // prologue: tile 0 -> LDS, tile 1 -> register set 1, tile 2 -> register set 0
+  // prologue: tile 0 -> LDS; tile 1 (-> set PDEPTH-1) and, with two sets, tile 2 (-> set 0) -> registers
   fetch_all(0, 0);
 #pragma unroll
   for (int i = 0; i < NV; ++i) lstore(As, LDA, A_KC, ra[0][i], ia[0][i], tid + i * NT);
 #pragma unroll
   for (int i = 0; i < NV; ++i) lstore(Bs, LDB, B_KC, rb[0][i], ib[0][i], tid + i * NT);
-  fetch_all(1, 1);
-  fetch_all(0, 2);
+  fetch_all(PDEPTH - 1, 1);
+  if (PDEPTH == 2) fetch_all(0, 2);
   __syncthreads();
 
   // fragments: fa[j][bi][e] = A(row = wm0 + 16 bi + lane%16, k = 16 j + 4 (lane/16) + e), same for B
-  float fa[4][2][4], fb[4][2][4];
-  auto read_frags = [&](int j) {
+  float fa[NJ][WB][4], fb[NJ][WB][4];
+  auto read_frag = [&](const float* S, int ld, bool kc, int w0, int j, int bi, float (&out)[4]) {
+    if (kc) {
+      const float4 v = *reinterpret_cast<const float4*>(&S[(w0 + 16 * bi + l16) * ld + 16 * j + 4 * q4]);
+      out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else {
 #pragma unroll
-    for (int bi = 0; bi < 2; ++bi) {
-      if (A_KC) {
-        const float4 v = *reinterpret_cast<const float4*>(&As[(wm0 + 16 * bi + l16) * LDA + 16 * j + 4 * q4]);
-        fa[j][bi][0] = v.x; fa[j][bi][1] = v.y; fa[j][bi][2] = v.z; fa[j][bi][3] = v.w;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) fa[j][bi][e] = As[(16 * j + 4 * q4 + e) * LDA + wm0 + 16 * bi + l16];
-      }
-      if (B_KC) {
-        const float4 v = *reinterpret_cast<const float4*>(&Bs[(wn0 + 16 * bi + l16) * LDB + 16 * j + 4 * q4]);
-        fb[j][bi][0] = v.x; fb[j][bi][1] = v.y; fb[j][bi][2] = v.z; fb[j][bi][3] = v.w;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) fb[j][bi][e] = Bs[(16 * j + 4 * q4 + e) * LDB + wn0 + 16 * bi + l16];
-      }
+      for (int e = 0; e < 4; ++e) out[e] = S[(16 * j + 4 * q4 + e) * ld + w0 + 16 * bi + l16];
     }
   };
-  auto mma4 = [&](int j, int e) {
+  auto read_frags = [&](int j) {
 #pragma unroll
-    for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-      for (int bj = 0; bj < 2; ++bj)
-        acc[bi][bj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j][bi][e], fb[j][bj][e], acc[bi][bj], 0, 0, 0);
+    for (int bi = 0; bi < WB; ++bi) {
+      read_frag(As, LDA, A_KC, wm0, j, bi, fa[j][bi]);
+      read_frag(Bs, LDB, B_KC, wn0, j, bi, fb[j][bi]);
+    }
   };
+  // one "step" = the WB MFMAs of (j, e, bi) over bj; NJ*4*WB steps per iteration
+  auto step = [&](int sidx) {
+    const int bi = sidx % WB, e = (sidx / WB) % 4, j = sidx / (4 * WB);
+#pragma unroll
+    for (int bj = 0; bj < WB; ++bj)
+      acc[bi][bj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j][bi][e], fb[j][bj][e], acc[bi][bj], 0, 0, 0);
+  };
+  constexpr int NSTEP = NJ * 4 * WB, PRE = 4 * WB, LAST = 4 / WB + (WB == 4), UEVERY = WB == 2 ? 2 : 1;
+  static_assert((NSTEP - PRE - LAST) >= 2 * NV * UEVERY, "not enough MFMA steps to interleave the staging");
   read_frags(0);
   auto iteration = [&](int kt, auto ST) {
-    constexpr int st = decltype(ST)::value;     // register set holding tile kt+1; refilled with tile kt+3
-    // 1. the rest of tile kt's fragments -> registers, behind the first 16 MFMAs
-#ifndef RR_NO_READS
-    read_frags(1); read_frags(2); read_frags(3);
-#endif
+    constexpr int st = decltype(ST)::value;     // register set holding tile kt+1; refilled with tile kt+1+PDEPTH
+    // 1. the rest of tile kt's fragments -> registers, behind the MFMAs of k-group 0
 #pragma unroll
-    for (int e = 0; e < 4; ++e) mma4(0, e);
-#ifndef RR_NO_BARRIER
-    __syncthreads();                       // 2. the LDS tile is dead: refill it behind the next 44 MFMAs
-#endif
-    // after each of the first 8 of the next 11 groups of 4 MFMAs one staged vector goes to LDS and its registers are re-armed
-    // with the load for tile kt+2.  Everything is unconditional (clamped addresses are always valid; the
-    // final iterations stage zeros nobody reads): one basic block, counted waits.
-    const int k2 = kbeg + (kt + 3) * BK;
+    for (int j = 1; j < NJ; ++j) read_frags(j);
 #pragma unroll
-    for (int gi = 0; gi < 11; ++gi) {
-      mma4(1 + gi / 4, gi % 4);
-#ifndef RR_NO_STAGE
-      if (gi < 2 * NV) {                           // stores early: the last three groups cover their latency
-        const int u = gi;                          // before the barrier
+    for (int sidx = 0; sidx < PRE; ++sidx) step(sidx);
+    __syncthreads();                       // 2. the LDS tile is dead: refill it behind the following MFMAs
+    // one staged vector goes to LDS after each of the first 2*NV (every UEVERY-th) steps and its registers are
+    // re-armed with the load for a later tile.  Everything is unconditional (clamped addresses are always
+    // valid; the final iterations stage data nobody reads): one basic block, counted waits.
+    const int k2 = kbeg + (kt + 1 + PDEPTH) * BK;
+#pragma unroll
+    for (int m = 0; m < NSTEP - PRE - LAST; ++m) {
+      step(PRE + m);
+      if (m % UEVERY == 0 && m / UEVERY < 2 * NV) {
+        const int u = m / UEVERY;
         if (u < NV) {
           lstore(As, LDA, A_KC, ra[st][u], ia[st][u], tid + u * NT);
           if (KX) nextA(st, u);
@@ -668,53 +671,42 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
           else ib[st][u - NV] = gload(B, b_ld, N, n0, k2, B_KC, rb[st][u - NV], tid + (u - NV) * NT, G == 2);
         }
       }
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     if (KX) { --lefta; --leftb; }
-#ifndef RR_NO_BARRIER
-    __syncthreads();                       // 3. next tile visible
-#endif
-    //: its first fragments are requested behind the
-    float na[2][4], nb[2][4];              //    last 4 MFMAs of this one
+    __syncthreads();                       // 3. next tile visible: its k-group-0 fragments are requested behind
+    float na[WB][4], nb[WB][4];            //    the last MFMAs of this one
 #pragma unroll
-    for (int bi = 0; bi < 2; ++bi) {
-      if (A_KC) {
-        const float4 v = *reinterpret_cast<const float4*>(&As[(wm0 + 16 * bi + l16) * LDA + 4 * q4]);
-        na[bi][0] = v.x; na[bi][1] = v.y; na[bi][2] = v.z; na[bi][3] = v.w;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) na[bi][e] = As[(4 * q4 + e) * LDA + wm0 + 16 * bi + l16];
-      }
-      if (B_KC) {
-        const float4 v = *reinterpret_cast<const float4*>(&Bs[(wn0 + 16 * bi + l16) * LDB + 4 * q4]);
-        nb[bi][0] = v.x; nb[bi][1] = v.y; nb[bi][2] = v.z; nb[bi][3] = v.w;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) nb[bi][e] = Bs[(4 * q4 + e) * LDB + wn0 + 16 * bi + l16];
-      }
+    for (int bi = 0; bi < WB; ++bi) {
+      read_frag(As, LDA, A_KC, wm0, 0, bi, na[bi]);
+      read_frag(Bs, LDB, B_KC, wn0, 0, bi, nb[bi]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    mma4(3, 3);
+#pragma unroll
+    for (int sidx = NSTEP - LAST; sidx < NSTEP; ++sidx) step(sidx);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int bi = 0; bi < 2; ++bi)
+    for (int bi = 0; bi < WB; ++bi)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         fa[0][bi][e] = na[bi][e];
         fb[0][bi][e] = nb[bi][e];
       }
   };
-  for (int kt = 0; kt < nk; kt += 2) {
-    iteration(kt, std::integral_constant<int, 1>{});
-    if (kt + 1 < nk) iteration(kt + 1, std::integral_constant<int, 0>{});
+  if (PDEPTH == 2) {
+    for (int kt = 0; kt < nk; kt += 2) {
+      iteration(kt, std::integral_constant<int, PDEPTH - 1>{});
+      if (kt + 1 < nk) iteration(kt + 1, std::integral_constant<int, 0>{});
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) iteration(kt, std::integral_constant<int, 0>{});
   }
 
   // ---- epilogue: 16x16 blocks, D[row = 4*(lane/16) + v][col = lane%16]
 #pragma unroll
-  for (int bi = 0; bi < 2; ++bi)
+  for (int bi = 0; bi < WB; ++bi)
 #pragma unroll
-    for (int bj = 0; bj < 2; ++bj) {
+    for (int bj = 0; bj < WB; ++bj) {
       const int col = n0 + wn0 + 16 * bj + l16;
       if (col >= N) continue;
       const float bv = bias ? bias[col] : 0.f;
@@ -891,6 +883,10 @@ inline bool use_rr(int M, int N, int K, int splits) {
   static const char* f = getenv("GENRL_GEMM_RR");
   return !(f && f[0] == '0');
 }
+inline bool use_rr_big() {       // 128x128 products through sgemm_rr_kernel<4> (5-8 % faster than sgemm_kernel<128,128,..>);
+  static const char* f = getenv("GENRL_GEMM_RR128");      // GENRL_GEMM_RR128=0 disables (calibration)
+  return !(f && f[0] == '0');
+}
 inline bool force_mid() {       // calibration only: GENRL_GEMM_FORCE=m,<splits>
   static const char* f = getenv("GENRL_GEMM_FORCE");
   return f && f[0] == 'm';
@@ -1015,6 +1011,7 @@ int launch_cfg(const float* A, long a_rs, long a_ks, const float* B, long b_rs, 
 }
 
 // launch the register-resident-operand 64x64 kernel (FAST preconditions hold; returns -1 if they do not)
+template <int WB>
 int launch_rr(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks, float* C, long ldc,
               const float* bias, int M, int N, int K, int accumulate, int splits, int kps, float* ws, hipStream_t s,
               int G, const Gather* gp) {
@@ -1033,14 +1030,15 @@ int launch_rr(const float* A, long a_rs, long a_ks, const float* B, long b_rs, l
   const bool fast = a_vec && b_vec && ((!a_kc && !b_kc) || k4) && (a_kc || (M % 4 == 0 && M >= 4)) &&
                     (b_kc || (N % 4 == 0 && N >= 4));
   if (!fast || (G == 1 && !(a_kc && b_kc)) || (G == 2 && (a_kc || b_kc))) return -1;
-  const int tiles_m = cdiv(M, 64), tiles_n = cdiv(N, 64), ntiles = tiles_m * tiles_n;
+  constexpr int BT = 32 * WB, BKR = WB == 2 ? 64 : 32;
+  const int tiles_m = cdiv(M, BT), tiles_n = cdiv(N, BT), ntiles = tiles_m * tiles_n;
   int xcd_m = 0;
   {
     double best = 1e30;
     for (int xm = 1; xm <= 8; xm *= 2) {
       const int xn = 8 / xm;
       if (tiles_m % xm || tiles_n % xn) continue;
-      const double fp = (double)(tiles_m / xm) * 64 + (double)(tiles_n / xn) * 64;
+      const double fp = (double)(tiles_m / xm) * BT + (double)(tiles_n / xn) * BT;
       if (fp < best) {
         best = fp;
         xcd_m = xm;
@@ -1048,9 +1046,9 @@ int launch_rr(const float* A, long a_rs, long a_ks, const float* B, long b_rs, l
     }
   }
   dim3 grid(ntiles, splits), block(256);
-  const bool kx = !G && (K % 64 == 0) && (kps % 64 == 0) && M >= 4 && N >= 4;
+  const bool kx = !G && (K % BKR == 0) && (kps % BKR == 0) && M >= 4 && N >= 4;
 #define GO(AK, BKC, GG, KXV)                                                                                        \
-  hipLaunchKernelGGL((sgemm_rr_kernel<AK, BKC, GG, KXV>), grid, block, 0, s, A, a_ld, B, b_ld, C, ldc, bias, M, N, K, \
+  hipLaunchKernelGGL((sgemm_rr_kernel<WB, AK, BKC, GG, KXV>), grid, block, 0, s, A, a_ld, B, b_ld, C, ldc, bias, M, N, K, \
                      accumulate, tiles_n, ntiles, kps, ws, tiles_m, xcd_m, g)
 #define GO2(AK, BKC) \
   if (kx) GO(AK, BKC, 0, true); else GO(AK, BKC, 0, false)
@@ -1108,10 +1106,14 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
   if (!split) p.splits = 1, p.k_per_split = K;
   float* wsp = split ? ws : nullptr;
   int rc;
-  if (p.big)
+  if (p.big && use_rr_big() &&
+      (rc = launch_rr<4>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, p.splits, (p.k_per_split + 63) / 64 * 64,
+                         wsp, s, G, gp)) >= 0)
+    ;
+  else if (p.big)
     rc = launch_cfg<128, 128, GENRL_BIG_BK, GENRL_BIG_KG, GENRL_BIG_PD>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate,
                                                             p.splits, p.k_per_split, wsp, s, G, gp);
-  else if (use_rr(M, N, K, p.splits) && (rc = launch_rr(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, p.splits,
+  else if (use_rr(M, N, K, p.splits) && (rc = launch_rr<2>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, p.splits,
                                        (p.k_per_split + 63) / 64 * 64, wsp, s, G, gp)) >= 0)
     ;
   else if ((p.splits == 1 && (long)cdiv(M, 64) * cdiv(N, 64) >= GENRL_MID_TILES) || force_mid())
