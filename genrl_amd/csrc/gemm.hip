@@ -512,8 +512,12 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
     }
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int kbeg = blockIdx.y * k_per_split;
-  const int K = min(Ktot, kbeg + k_per_split);
+  int kbeg = blockIdx.y * k_per_split;
+  int K = min(Ktot, kbeg + k_per_split);
+  if (kbeg >= Ktot) {                      // empty split (can only come from a forced plan): contributes zeros
+    kbeg = 0;
+    K = 0;
+  }
   if (ws) {
     C = ws + (long)blockIdx.y * M * N;
     ldc = N;
