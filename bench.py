@@ -230,7 +230,7 @@ def main():
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')))
-            gk = [v for k_, v in pm.items() if k_.startswith('sgemm_kernel')]
+            gk = [v for k_, v in pm.items() if k_.startswith('sgemm_')]
             nl = sum(v['launches'] for v in gk)
             traffic = sum((v['hbm_read_bytes_per_launch'] + v['hbm_write_bytes_per_launch']) * v['launches'] for v in gk) / nl
         except Exception:
@@ -239,7 +239,7 @@ def main():
                            'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
                            'traffic_note': 'HBM bytes per launch (read+write) from profiles/r01_pmc.json; algorithmic '
                                            f'operand bytes per launch {sum(4.0 * (p_[0] * p_[2] + p_[1] * p_[2] + p_[0] * p_[1]) for p_ in prof) / max(len(prof), 1):.3g}',
-                           'kernel': 'sgemm_kernel<BM,BN,*> (gemm.hip, v_mfma_f32_32x32x2_f32), all instantiations',
+                           'kernel': 'sgemm_rr_kernel<2|4> (+ sgemm_kernel fallback) — gemm.hip, v_mfma_f32_16x16x4_f32 / 32x32x2_f32, all instantiations',
                            'launches_per_step': len(prof), 'avg_launch_us': 1e3 * tot_ms / len(prof),
                            'gemm_gflop_per_step': tot_fl / 1e9, 'gemm_ms_per_step': tot_ms,
                            'skinny_kernel': {'launches_per_step': len(skinny), 'ms_per_step': sk_ms,

@@ -13,28 +13,26 @@
 // gfx950 has no TF32/xf32 path, so this is the roofline the dense part of the GenRL hot path
 // is measured against (157.3 TFLOP/s).
 //
-// Tiling.  A workgroup owns a BMxBN output tile and has KG "k-groups" of 4 waves (2x2 over the
-// tile, each wave TMxTN 32x32 MFMA tiles).  A BK-deep operand tile is staged in LDS (row-contiguous
-// operands k-major [k][rows+4]; k-contiguous operands row-major [row][BK+4], read with ds_read_b128
-// and a k-pairing shared by both operands); k-group g multiplies the g-th BK/KG slice into its own
-// accumulators, and the KG partial tiles are summed through LDS at the end.  Three shapes:
-//   128x128, BK=16, KG=1 (256 threads, 3 per CU)  - problems with >= 512 such tiles (M >= ~16K rows)
-//                                                   or few tiles with a very long K (split-K);
-//    64x 64, BK=16, KG=1 (256 threads, ~8 per CU) - >= 512 tiles of 64x64 (independent barriers);
-//    64x 64, BK=64, KG=4 (1024 threads, 1 per CU) - everything else.  The GEMMs of this workload are
-//        mostly M=N=1024 (256 tiles): one workgroup per CU; the 16 waves (4 per SIMD) are what hides
-//        the global->LDS latency there.
-// Global->LDS goes through registers (branch-free clamped loads two tiles ahead), LDS double-buffered,
-// one barrier per BK; the staging stores sit in the middle of the step's MFMA sequence.
-// M <= 32 rows: skinny_kernel (below).  Implicit stride-2 convolution operands: Gather (below).
-//
+// Kernels in this file:
+//   sgemm_rr_kernel<WB>  - the default.  256 threads (2x2 waves), ONE LDS buffer, every LDS fragment of a
+//       K tile pulled into registers (ds_read_b128 for k-contiguous operands), v_mfma_f32_16x16x4_f32 with
+//       WB x WB independent accumulators per wave, global loads two tiles ahead in two register sets, the
+//       register->LDS staging interleaved one 16-byte store at a time between the MFMAs, two barriers per
+//       iteration.  WB = 2: 64x64 tile (BK 64); WB = 4: 128x128 tile (BK 32, >= 512 such tiles or long-K
+//       split-K plans).  Several workgroups per CU with independent barriers.
+//   sgemm_kernel<BM,BN,BK,KG,..> - fallback for operands that miss the vector-load preconditions (odd
+//       leading dimensions / K), k-groups of 4 waves sharing a double-buffered LDS tile.
+//   skinny_kernel        - M <= 32 rows: weight stream, MFMA 16x16x4 straight from global memory.
+//   splitk_reduce_kernel - second pass of the deterministic split-K.
+// Operand conventions shared by all: one of the two strides of each operand is 1; LDS images are k-major
+// [k][rows+4] for row-contiguous and row-major [row][BK+4] for k-contiguous operands, with a k-pairing
+// shared by both MFMA operands; optional implicit stride-2 convolution operand (Gather).
 // Launch plan (tile shape x deterministic split-K through a caller workspace): plan_split().
-//
 // Workgroup -> tile mapping is XCD-aware: the dispatcher places block b on XCD b%8, so blocks are
 // remapped such that each XCD owns a compact 2-D sub-block of the tile grid (operand panels stay
 // in that XCD's private L2).
-// Yardstick (scripts/blas_ref.py): the vendor's asm-scheduled fp32 kernels reach 95-134 TF/s on these
-// shapes; this file reaches 79-116 (and wins on M <= 128).
+// Yardstick (scripts/blas_ref.py): the vendor's asm-scheduled fp32 kernels reach 98 / 105 / 131 TF/s on
+// 1024^3 / 1024x3072x1024 / 16384x1024x1024; this file reaches 78 / 88 / 124 (and wins on M <= 128).
 #include "common.h"
 #include <type_traits>
 

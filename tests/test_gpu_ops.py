@@ -261,3 +261,23 @@ def test_align_index(ops):
     ref = (torch.clamp(torch.arange(T)[:, None] - best[None], min=0)) * N + torch.arange(N)[None]
     got = ops.align_index(ct.cuda(), ca.cuda(), nf).cpu()
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize('M,N,K', [(1024, 1024, 10), (100, 300, 7), (257, 1000, 32), (1024, 20, 1024), (77, 10, 333),
+                                   (2000, 32, 64)])
+def test_sgemm_thin_products(ops, M, N, K):
+    """Thin products (K <= 32: the action slice of the RSSM input layer; N <= 32: policy head, action gradient):
+    all four operand layouts, bias + accumulate, exact on small integers."""
+    A = (torch.arange(M * K, dtype=torch.float32).reshape(M, K) % 5 - 2)
+    B = ((torch.arange(N * K, dtype=torch.float32).reshape(N, K) * 3) % 7 - 3)
+    bias = torch.arange(N, dtype=torch.float32) % 3
+    want = A.double() @ B.double().T
+    C = torch.full((M, N), 1.0, device='cuda')
+    ops.sgemm(A.cuda(), K, 1, B.cuda(), K, 1, C, N, bias.cuda(), M, N, K, accumulate=True)
+    assert torch.equal(C.cpu().double(), want + bias.double() + 1.0)
+    At, Bt = A.T.contiguous().cuda(), B.T.contiguous().cuda()
+    for (a, ars, aks) in ((A.cuda(), K, 1), (At, 1, M)):
+        for (b, brs, bks) in ((B.cuda(), K, 1), (Bt, 1, N)):
+            C2 = torch.empty(M, N, device='cuda')
+            ops.sgemm(a, ars, aks, b, brs, bks, C2, N, None, M, N, K)
+            assert torch.equal(C2.cpu().double(), want), (ars, aks, brs, bks)
