@@ -341,28 +341,28 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 __global__ void actor_head_fwd_kernel(const float* __restrict__ raw, const float* __restrict__ eps,
                                       float* __restrict__ action, float* __restrict__ mean_out,
                                       float* __restrict__ std_out, long n, int A, float min_std,
-                                      float max_std) {
+                                      float max_std, long ld_action) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const long r = i / A;
   const int a = (int)(i % A);
   const float mean = tanhf(raw[r * 2 * A + a]);
   const float sd = (max_std - min_std) * sigmoidf_(raw[r * 2 * A + A + a] + 2.0f) + min_std;
-  if (action) action[i] = mean + sd * (eps ? eps[i] : 0.f);
+  if (action) action[r * ld_action + a] = mean + sd * (eps ? eps[i] : 0.f);
   if (mean_out) mean_out[i] = mean;
   if (std_out) std_out[i] = sd;
 }
 
 __global__ void actor_head_bwd_kernel(const float* __restrict__ daction, const float* __restrict__ raw,
                                       const float* __restrict__ eps, float* __restrict__ draw, long n, int A,
-                                      float min_std, float max_std) {
+                                      float min_std, float max_std, long ld_action) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const long r = i / A;
   const int a = (int)(i % A);
   const float mean = tanhf(raw[r * 2 * A + a]);
   const float sg = sigmoidf_(raw[r * 2 * A + A + a] + 2.0f);
-  const float g = daction[i];
+  const float g = daction[r * ld_action + a];
   draw[r * 2 * A + a] = g * (1.0f - mean * mean);
   draw[r * 2 * A + A + a] = g * eps[i] * (max_std - min_std) * sg * (1.0f - sg);
 }
@@ -925,23 +925,23 @@ int genrl_gru_gates_bwd(const float* dhout, long lddo, const float* dhout2, cons
 }
 
 int genrl_actor_head_fwd(const float* raw, const float* eps, float* action, float* mean, float* std, long R, int A,
-                         float min_std, float max_std, void* stream) {
+                         float min_std, float max_std, long ld_action, void* stream) {
   GENRL_ENTER();
   const long n = R * A;
   if (n <= 0) return GENRL_OK;
   hipLaunchKernelGGL(actor_head_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, raw, eps, action,
-                     mean, std, n, A, min_std, max_std);
+                     mean, std, n, A, min_std, max_std, ld_action > 0 ? ld_action : (long)A);
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }
 
 int genrl_actor_head_bwd(const float* daction, const float* raw, const float* eps, float* draw, long R, int A,
-                         float min_std, float max_std, void* stream) {
+                         float min_std, float max_std, long ld_action, void* stream) {
   GENRL_ENTER();
   const long n = R * A;
   if (n <= 0) return GENRL_OK;
   hipLaunchKernelGGL(actor_head_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, daction, raw, eps,
-                     draw, n, A, min_std, max_std);
+                     draw, n, A, min_std, max_std, ld_action > 0 ? ld_action : (long)A);
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }

@@ -496,7 +496,7 @@ class _ActorHead(Function):
         A = A2 // 2
         e = eps.reshape(R, A).contiguous()
         act = torch.empty(R, A, device=raw.device)
-        check(lib().genrl_actor_head_fwd(_p(r2), _p(e), _p(act), None, None, R, A, min_std, max_std, _stream()),
+        check(lib().genrl_actor_head_fwd(_p(r2), _p(e), _p(act), None, None, R, A, min_std, max_std, 0, _stream()),
               'actor_head_fwd')
         ctx.save_for_backward(r2, e)
         ctx.cfg = (min_std, max_std, raw.shape)
@@ -509,7 +509,7 @@ class _ActorHead(Function):
         R, A2 = r2.shape
         d = torch.empty_like(r2)
         check(lib().genrl_actor_head_bwd(_p(g.reshape(R, A2 // 2).contiguous()), _p(r2), _p(e), _p(d), R, A2 // 2,
-                                         min_std, max_std, _stream()), 'actor_head_bwd')
+                                         min_std, max_std, 0, _stream()), 'actor_head_bwd')
         return d.reshape(rshape), None, None, None
 
 
@@ -523,7 +523,7 @@ def actor_mean_std(raw, min_std=0.1, max_std=1.0):
     R, A2 = r2.shape
     A = A2 // 2
     mean = torch.empty(R, A, device=raw.device); std = torch.empty(R, A, device=raw.device)
-    check(lib().genrl_actor_head_fwd(_p(r2), None, None, _p(mean), _p(std), R, A, min_std, max_std, _stream()),
+    check(lib().genrl_actor_head_fwd(_p(r2), None, None, _p(mean), _p(std), R, A, min_std, max_std, 0, _stream()),
           'actor_head_fwd')
     return mean.reshape(*raw.shape[:-1], A), std.reshape(*raw.shape[:-1], A)
 
@@ -679,7 +679,13 @@ class _Rollout(Function):
         U = sp.in_w.shape[0]
         dev = deter0.device
         f = lambda *shape: torch.empty(*shape, device=dev)
-        stoch = f(H + 1, N, SK); deter = f(H + 1, N, D); logit = f(H + 1, N, SK); action = torch.zeros(H + 1, N, A, device=dev)
+        # actions live in rows of AP = A rounded up to 4 floats (zero padded) and the action slice of the input
+        # layer's weight is copied once into a (U, AP) zero-padded matrix: both thin products of a step
+        # (x += action W_a^T, d action = dx W_a) then meet the vector-load preconditions of the GEMM
+        AP = (A + 3) // 4 * 4
+        stoch = f(H + 1, N, SK); deter = f(H + 1, N, D); logit = f(H + 1, N, SK); action = torch.zeros(H + 1, N, AP, device=dev)
+        wa = torch.zeros(sp.in_w.shape[0], AP, device=dev)
+        wa[:, :A].copy_(sp.in_w[:, SK:SK + A])
         raws = f(H, N, 2 * A)
         stoch[0].copy_(stoch0.reshape(N, SK)); deter[0].copy_(deter0); logit[0].copy_(logit0.reshape(N, SK))
         x_pre, x = f(H, N, U), f(H, N, U)
@@ -693,12 +699,11 @@ class _Rollout(Function):
             sN, dN = h * N * SK, h * N * D
             raw = tape._forward(h, stoch[h], deter[h])
             raws[h].copy_(raw)
-            check(lib().genrl_actor_head_fwd(pt(raws, h * N * 2 * A), pt(eps, h * N * A), pt(action, (h + 1) * N * A), None, None,
-                                             N, A, sp.min_std, sp.max_std, _stream()), 'actor_head_fwd')
+            check(lib().genrl_actor_head_fwd(pt(raws, h * N * 2 * A), pt(eps, h * N * A), pt(action, (h + 1) * N * AP), None, None,
+                                             N, A, sp.min_std, sp.max_std, AP, _stream()), 'actor_head_fwd')
             # img_in: [stoch_h | action_{h+1}] -> hidden, LN + SiLU
             sgemm(stoch, SK, 1, sp.in_w, Kin, 1, x_pre, U, sp.in_b, N, U, SK, a_off=sN, c_off=h * N * U)
-            sgemm(action, A, 1, sp.in_w, Kin, 1, x_pre, U, None, N, U, A, accumulate=True, a_off=(h + 1) * N * A, b_off=SK,
-                  c_off=h * N * U)
+            sgemm(action, AP, 1, wa, AP, 1, x_pre, U, None, N, U, AP, accumulate=True, a_off=(h + 1) * N * AP, c_off=h * N * U)
             _ln_fwd_raw(pt(x_pre, h * N * U), sp.in_g, sp.in_be, pt(x, h * N * U), pt(st['xm'], h * N), pt(st['xr'], h * N),
                         N, U, sp.in_eps)
             # GRU
@@ -716,15 +721,15 @@ class _Rollout(Function):
                                          UNIMIX, _stream()), 'onehot_fwd')
         tape.inputs = (stoch, deter)
         ctx.sp = sp
-        ctx.bufs = (stoch, deter, logit, raws, eps, x_pre, g_pre, o_pre, st)
+        ctx.bufs = (stoch, deter, logit, raws, eps, x_pre, g_pre, o_pre, st, wa)
         ctx.nparams = len(actor_params)
         ctx.dims = (H, N, S, K, D, A, U)
-        return stoch.reshape(H + 1, N, S, K), deter, logit.reshape(H + 1, N, S, K), action, raws
+        return stoch.reshape(H + 1, N, S, K), deter, logit.reshape(H + 1, N, S, K), action[:, :, :A], raws
 
     @staticmethod
     def backward(ctx, d_stoch, d_deter, d_logit, d_action, d_raws):
         sp, tape = ctx.sp, ctx.sp.tape
-        stoch, deter, logit, raws, eps, x_pre, g_pre, o_pre, st = ctx.bufs
+        stoch, deter, logit, raws, eps, x_pre, g_pre, o_pre, st, wa = ctx.bufs
         H, N, S, K, D, A, U = ctx.dims
         SK = S * K
         dev = deter.device
@@ -735,7 +740,8 @@ class _Rollout(Function):
         da_in = d_action.contiguous() if d_action is not None else None
         Kin, Kg = sp.in_w.shape[1], sp.gru_w.shape[1]
         f = lambda *shape: torch.empty(*shape, device=dev)
-        dlg, do, do_pre, dg_pre, dx, dx_pre, dact = f(N, SK), f(N, U), f(N, U), f(N, 3 * D), f(N, U), f(N, U), f(N, A)
+        AP = wa.shape[1]
+        dlg, do, do_pre, dg_pre, dx, dx_pre, dact = f(N, SK), f(N, U), f(N, U), f(N, 3 * D), f(N, U), f(N, U), f(N, AP)
         dha, dhb = f(N, D), f(N, D)
         cur, nxt = dha, None                              # ping-pong: recurrent gradient into deter_h from step h's GRU
         pt = lambda t, off: t.data_ptr() + 4 * off
@@ -759,10 +765,11 @@ class _Rollout(Function):
             _ln_bwd_raw(_p(dx), pt(x_pre, h * N * U), sp.in_g, sp.in_be, pt(st['xm'], h * N), pt(st['xr'], h * N), _p(dx_pre), N, U)
             sgemm(dx_pre, U, 1, sp.in_w, 1, Kin, ds, SK, None, N, SK, U, accumulate=True, c_off=sN)
             if da_in is not None:
-                dact.copy_(da_in[h + 1])
-            sgemm(dx_pre, U, 1, sp.in_w, 1, Kin, dact, A, None, N, A, U, accumulate=da_in is not None, b_off=SK)
+                dact.zero_()
+                dact[:, :A].copy_(da_in[h + 1])
+            sgemm(dx_pre, U, 1, wa, 1, AP, dact, AP, None, N, AP, U, accumulate=da_in is not None)
             check(lib().genrl_actor_head_bwd(_p(dact), pt(raws, h * N * 2 * A), pt(eps, h * N * A), pt(tape.d_raw, h * N * 2 * A),
-                                             N, A, sp.min_std, sp.max_std, _stream()), 'actor_head_bwd')
+                                             N, A, sp.min_std, sp.max_std, AP, _stream()), 'actor_head_bwd')
             nxt, cur = cur, (dhb if cur is dha else dha)
         if d_raws is not None:
             tape.d_raw += d_raws

@@ -72,9 +72,9 @@ int genrl_gru_gates_bwd(const float* dhout, long lddo, const float* dhout2, cons
 
 /* ---- actor Normal head: DistLayer 'normal' + rsample (agent/dreamer_utils.py:814-819) */
 int genrl_actor_head_fwd(const float* raw, const float* eps, float* action, float* mean, float* std, long R, int A,
-                         float min_std, float max_std, void* stream);
+                         float min_std, float max_std, long ld_action /* 0 = A */, void* stream);
 int genrl_actor_head_bwd(const float* daction, const float* raw, const float* eps, float* draw, long R, int A,
-                         float min_std, float max_std, void* stream);
+                         float min_std, float max_std, long ld_action /* 0 = A */, void* stream);
 
 /* strided 2-D copy with optional per-row scale (is_first reset mask, agent/dreamer_utils.py:433-435;
  * torch.cat of [stoch, action] / [x, deter], :461,:777) */
