@@ -43,6 +43,9 @@ extern "C" void genrl_dbg_read(unsigned long long* out, int nslots) {
   hipMemcpyFromSymbol(out, HIP_SYMBOL(genrl_dbg_cycles), sizeof(unsigned long long) * 6 * nslots);
 }
 #endif
+#ifndef RR_LDS_BUFS
+#define RR_LDS_BUFS 1   /* LDS tile images of sgemm_rr_kernel: 1 (two barriers per iteration) or 2 = ping-pong (one barrier; measured equal) */
+#endif
 #ifndef GENRL_RR_PD4
 #define GENRL_RR_PD4(WB) 2   /* register sets (tiles in flight) of sgemm_rr_kernel */
 #endif
@@ -491,9 +494,8 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
   constexpr int WT = 16 * WB;                                       // wave tile edge
   constexpr int LDA = A_KC ? BK + 4 : BM + 4, LDB = B_KC ? BK + 4 : BN + 4;
   constexpr int A_SZ = A_KC ? BM * LDA : BK * LDA, B_SZ = B_KC ? BN * LDB : BK * LDB;
-  __shared__ __attribute__((aligned(16))) float lds[A_SZ + B_SZ];
-  float* As = lds;
-  float* Bs = lds + A_SZ;
+  constexpr int T_SZ = A_SZ + B_SZ;                                 // one tile image; two of them (ping-pong)
+  __shared__ __attribute__((aligned(16))) float lds[RR_LDS_BUFS * T_SZ];
   int bid = blockIdx.x, tile_m, tile_n;
   {
     const int x = bid % 8, i = bid / 8;
@@ -611,9 +613,9 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
   // prologue: tile 0 -> LDS; tile 1 (-> set PDEPTH-1) and, with two sets, tile 2 (-> set 0) -> registers
   fetch_all(0, 0);
 #pragma unroll
-  for (int i = 0; i < NV; ++i) lstore(As, LDA, A_KC, ra[0][i], ia[0][i], tid + i * NT);
+  for (int i = 0; i < NV; ++i) lstore(lds, LDA, A_KC, ra[0][i], ia[0][i], tid + i * NT);
 #pragma unroll
-  for (int i = 0; i < NV; ++i) lstore(Bs, LDB, B_KC, rb[0][i], ib[0][i], tid + i * NT);
+  for (int i = 0; i < NV; ++i) lstore(lds + A_SZ, LDB, B_KC, rb[0][i], ib[0][i], tid + i * NT);
   fetch_all(PDEPTH - 1, 1);
   if (PDEPTH == 2) fetch_all(0, 2);
   __syncthreads();
@@ -629,11 +631,11 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
       for (int e = 0; e < 4; ++e) out[e] = S[(16 * j + 4 * q4 + e) * ld + w0 + 16 * bi + l16];
     }
   };
-  auto read_frags = [&](int j) {
+  auto read_frags = [&](const float* T, int j) {      // T: tile image (A part, then B part)
 #pragma unroll
     for (int bi = 0; bi < WB; ++bi) {
-      read_frag(As, LDA, A_KC, wm0, j, bi, fa[j][bi]);
-      read_frag(Bs, LDB, B_KC, wn0, j, bi, fb[j][bi]);
+      read_frag(T, LDA, A_KC, wm0, j, bi, fa[j][bi]);
+      read_frag(T + A_SZ, LDB, B_KC, wn0, j, bi, fb[j][bi]);
     }
   };
   // one "step" = the WB MFMAs of (j, e, bi) over bj; NJ*4*WB steps per iteration
@@ -645,15 +647,18 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
   };
   constexpr int NSTEP = NJ * 4 * WB, PRE = 4 * WB, LAST = 4 / WB + (WB == 4), UEVERY = WB == 2 ? 2 : 1;
   static_assert((NSTEP - PRE - LAST) >= 2 * NV * UEVERY, "not enough MFMA steps to interleave the staging");
-  read_frags(0);
-  auto iteration = [&](int kt, auto ST) {
+  read_frags(lds, 0);
+  auto iteration = [&](int kt, auto ST, auto CUR) {
     constexpr int st = decltype(ST)::value;     // register set holding tile kt+1; refilled with tile kt+1+PDEPTH
+    constexpr int cur = RR_LDS_BUFS == 2 ? decltype(CUR)::value : 0, nxt = RR_LDS_BUFS == 2 ? 1 - cur : 0;
+    const float* Tc = lds + cur * T_SZ;         // image of tile kt
+    float* Tn = lds + nxt * T_SZ;               // image of tile kt+1 (the same buffer when single-buffered)
     // 1. the rest of tile kt's fragments -> registers, behind the MFMAs of k-group 0
 #pragma unroll
-    for (int j = 1; j < NJ; ++j) read_frags(j);
+    for (int j = 1; j < NJ; ++j) read_frags(Tc, j);
 #pragma unroll
     for (int sidx = 0; sidx < PRE; ++sidx) step(sidx);
-    __syncthreads();                       // 2. the LDS tile is dead: refill it behind the following MFMAs
+    if (RR_LDS_BUFS == 1) __syncthreads(); // 2. (single buffer) the LDS tile is dead: refill it behind the following MFMAs
     // one staged vector goes to LDS after each of the first 2*NV (every UEVERY-th) steps and its registers are
     // re-armed with the load for a later tile.  Everything is unconditional (clamped addresses are always
     // valid; the final iterations stage data nobody reads): one basic block, counted waits.
@@ -664,11 +669,11 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
       if (m % UEVERY == 0 && m / UEVERY < 2 * NV) {
         const int u = m / UEVERY;
         if (u < NV) {
-          lstore(As, LDA, A_KC, ra[st][u], ia[st][u], tid + u * NT);
+          lstore(Tn, LDA, A_KC, ra[st][u], ia[st][u], tid + u * NT);
           if (KX) nextA(st, u);
           else ia[st][u] = gload(A, a_ld, M, m0, k2, A_KC, ra[st][u], tid + u * NT, G == 1);
         } else {
-          lstore(Bs, LDB, B_KC, rb[st][u - NV], ib[st][u - NV], tid + (u - NV) * NT);
+          lstore(Tn + A_SZ, LDB, B_KC, rb[st][u - NV], ib[st][u - NV], tid + (u - NV) * NT);
           if (KX) nextB(st, u - NV);
           else ib[st][u - NV] = gload(B, b_ld, N, n0, k2, B_KC, rb[st][u - NV], tid + (u - NV) * NT, G == 2);
         }
@@ -680,8 +685,8 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
     float na[WB][4], nb[WB][4];            //    the last MFMAs of this one
 #pragma unroll
     for (int bi = 0; bi < WB; ++bi) {
-      read_frag(As, LDA, A_KC, wm0, 0, bi, na[bi]);
-      read_frag(Bs, LDB, B_KC, wn0, 0, bi, nb[bi]);
+      read_frag(Tn, LDA, A_KC, wm0, 0, bi, na[bi]);
+      read_frag(Tn + A_SZ, LDB, B_KC, wn0, 0, bi, nb[bi]);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -695,13 +700,11 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
         fb[0][bi][e] = nb[bi][e];
       }
   };
-  if (PDEPTH == 2) {
-    for (int kt = 0; kt < nk; kt += 2) {
-      iteration(kt, std::integral_constant<int, PDEPTH - 1>{});
-      if (kt + 1 < nk) iteration(kt + 1, std::integral_constant<int, 0>{});
-    }
-  } else {
-    for (int kt = 0; kt < nk; ++kt) iteration(kt, std::integral_constant<int, 0>{});
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  for (int kt = 0; kt < nk; kt += 2) {     // (register set and LDS buffer parities are compile-time: unrolled by 2)
+    iteration(kt, std::integral_constant<int, PDEPTH - 1>{}, I0{});
+    if (kt + 1 < nk) iteration(kt + 1, I0{}, I1{});
   }
 
   // ---- epilogue: 16x16 blocks, D[row = 4*(lane/16) + v][col = lane%16]
