@@ -43,6 +43,9 @@ extern "C" void genrl_dbg_read(unsigned long long* out, int nslots) {
   hipMemcpyFromSymbol(out, HIP_SYMBOL(genrl_dbg_cycles), sizeof(unsigned long long) * 6 * nslots);
 }
 #endif
+#ifndef RR_VEC_EPI
+#define RR_VEC_EPI 1   /* sgemm_rr_kernel: swapped MFMA operands -> 16-byte C stores (0 = scalar stores) */
+#endif
 #ifndef RR_LDS_BUFS
 #define RR_LDS_BUFS 1   /* LDS tile images of sgemm_rr_kernel: 1 (two barriers per iteration) or 2 = ping-pong (one barrier; measured equal) */
 #endif
@@ -643,7 +646,11 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
     const int bi = sidx % WB, e = (sidx / WB) % 4, j = sidx / (4 * WB);
 #pragma unroll
     for (int bj = 0; bj < WB; ++bj)
+#if RR_VEC_EPI
+      acc[bi][bj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][bj][e], fa[j][bi][e], acc[bi][bj], 0, 0, 0);
+#else
       acc[bi][bj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j][bi][e], fb[j][bj][e], acc[bi][bj], 0, 0, 0);
+#endif
   };
   constexpr int NSTEP = NJ * 4 * WB, PRE = 4 * WB, LAST = 4 / WB + (WB == 4), UEVERY = WB == 2 ? 2 : 1;
   static_assert((NSTEP - PRE - LAST) >= 2 * NV * UEVERY, "not enough MFMA steps to interleave the staging");
@@ -707,7 +714,43 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
     if (kt + 1 < nk) iteration(kt + 1, I0{}, I1{});
   }
 
-  // ---- epilogue: 16x16 blocks, D[row = 4*(lane/16) + v][col = lane%16]
+#if RR_VEC_EPI
+  // ---- epilogue.  The MFMAs are issued with the operands swapped (B fragment first), so a 16x16 block holds
+  // its TRANSPOSE in the D layout: lane (l16, q4), register v = C[row = l16][col = 4*q4 + v] -> every lane owns
+  // 4 consecutive columns of one row and stores them with one 16-byte instruction.
+  const bool vec_c = ((ldc & 3) == 0) && (((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0);
+#pragma unroll
+  for (int bi = 0; bi < WB; ++bi) {
+    const int row = m0 + wm0 + 16 * bi + l16;
+    if (row >= M) continue;
+#pragma unroll
+    for (int bj = 0; bj < WB; ++bj) {
+      const int col = n0 + wn0 + 16 * bj + 4 * q4;
+      if (col >= N) continue;
+      float* c = C + (long)row * ldc + col;
+      float o[4] = {acc[bi][bj][0], acc[bi][bj][1], acc[bi][bj][2], acc[bi][bj][3]};
+      if (vec_c && col + 3 < N) {
+        if (bias) {
+          const float4 bv = *reinterpret_cast<const float4*>(bias + col);
+          o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+        }
+        if (accumulate) {
+          const float4 cv = *reinterpret_cast<const float4*>(c);
+          o[0] += cv.x; o[1] += cv.y; o[2] += cv.z; o[3] += cv.w;
+        }
+        *reinterpret_cast<float4*>(c) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (col + v < N) {
+            float val = o[v] + (bias ? bias[col + v] : 0.f);
+            if (accumulate) val += c[v];
+            c[v] = val;
+          }
+      }
+    }
+  }
+#else
 #pragma unroll
   for (int bi = 0; bi < WB; ++bi)
 #pragma unroll
@@ -718,14 +761,14 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int row = m0 + wm0 + 16 * bi + 4 * q4 + v;
-        if (row < M) {
-          float* c = C + (long)row * ldc + col;
-          float val = acc[bi][bj][v] + bv;
-          if (accumulate) val += *c;
-          *c = val;
-        }
+        if (row >= M) continue;
+        float* c = C + (long)row * ldc + col;
+        float val = acc[bi][bj][v] + bv;
+        if (accumulate) val += *c;
+        *c = val;
       }
     }
+#endif
 }
 
 // C[m,n] = sum_s ws[s][m][n] (+bias[n]) (+C[m,n])
