@@ -46,6 +46,21 @@ extern "C" void genrl_dbg_read(unsigned long long* out, int nslots) {
 #ifndef RR_VEC_EPI
 #define RR_VEC_EPI 1   /* sgemm_rr_kernel: swapped MFMA operands -> 16-byte C stores (0 = scalar stores) */
 #endif
+#ifndef RR_PAIRLOOP
+#define RR_PAIRLOOP 1
+#endif
+#ifndef RR_SPREAD_READS
+#define RR_SPREAD_READS 1
+#endif
+#ifndef RR_LAST
+#define RR_LAST(WB) ((WB) == 2 ? RR_LAST2 : RR_LAST4)   /* MFMA steps left behind the second barrier of an iteration */
+#endif
+#ifndef RR_LAST2
+#define RR_LAST2 8
+#endif
+#ifndef RR_LAST4
+#define RR_LAST4 8
+#endif
 #ifndef RR_LDS_BUFS
 #define RR_LDS_BUFS 1   /* LDS tile images of sgemm_rr_kernel: 1 (two barriers per iteration) or 2 = ping-pong (one barrier; measured equal) */
 #endif
@@ -652,7 +667,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
       acc[bi][bj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j][bi][e], fb[j][bj][e], acc[bi][bj], 0, 0, 0);
 #endif
   };
-  constexpr int NSTEP = NJ * 4 * WB, PRE = 4 * WB, LAST = 4 / WB + (WB == 4), UEVERY = WB == 2 ? 2 : 1;
+  constexpr int NSTEP = NJ * 4 * WB, PRE = 4 * WB, LAST = RR_LAST(WB), UEVERY = WB == 2 ? 2 : 1;
   static_assert((NSTEP - PRE - LAST) >= 2 * NV * UEVERY, "not enough MFMA steps to interleave the staging");
   read_frags(lds, 0);
   auto iteration = [&](int kt, auto ST, auto CUR) {
@@ -661,10 +676,26 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
     const float* Tc = lds + cur * T_SZ;         // image of tile kt
     float* Tn = lds + nxt * T_SZ;               // image of tile kt+1 (the same buffer when single-buffered)
     // 1. the rest of tile kt's fragments -> registers, behind the MFMAs of k-group 0
+#if RR_SPREAD_READS
+    // (requested one (j, bi) pair at a time between the MFMA steps, so that the LDS never sees the four waves'
+    // whole fragment sets at once and the wait in front of the barrier below is already satisfied)
+    constexpr int NU = (NJ - 1) * WB;
+#pragma unroll
+    for (int sidx = 0; sidx < PRE; ++sidx) {
+      if (sidx < NU) {
+        const int j = 1 + sidx / WB, bi = sidx % WB;
+        read_frag(Tc, LDA, A_KC, wm0, j, bi, fa[j][bi]);
+        read_frag(Tc + A_SZ, LDB, B_KC, wn0, j, bi, fb[j][bi]);
+      }
+      step(sidx);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
 #pragma unroll
     for (int j = 1; j < NJ; ++j) read_frags(Tc, j);
 #pragma unroll
     for (int sidx = 0; sidx < PRE; ++sidx) step(sidx);
+#endif
     if (RR_LDS_BUFS == 1) __syncthreads(); // 2. (single buffer) the LDS tile is dead: refill it behind the following MFMAs
     // one staged vector goes to LDS after each of the first 2*NV (every UEVERY-th) steps and its registers are
     // re-armed with the load for a later tile.  Everything is unconditional (clamped addresses are always
@@ -677,10 +708,12 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
         const int u = m / UEVERY;
         if (u < NV) {
           lstore(Tn, LDA, A_KC, ra[st][u], ia[st][u], tid + u * NT);
+          __builtin_amdgcn_sched_barrier(0);   // (a load hoisted over the store lands in fresh registers -> copies)
           if (KX) nextA(st, u);
           else ia[st][u] = gload(A, a_ld, M, m0, k2, A_KC, ra[st][u], tid + u * NT, G == 1);
         } else {
           lstore(Tn + A_SZ, LDB, B_KC, rb[st][u - NV], ib[st][u - NV], tid + (u - NV) * NT);
+          __builtin_amdgcn_sched_barrier(0);
           if (KX) nextB(st, u - NV);
           else ib[st][u - NV] = gload(B, b_ld, N, n0, k2, B_KC, rb[st][u - NV], tid + (u - NV) * NT, G == 2);
         }
@@ -709,10 +742,22 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
-  for (int kt = 0; kt < nk; kt += 2) {     // (register set and LDS buffer parities are compile-time: unrolled by 2)
+  // (register set and LDS buffer parities are compile-time: iterations come in pairs, one basic block per pair —
+  // a conditional second half makes the register allocator rotate the staged sets through copies, and a copy
+  // waits for its load a whole iteration early)
+#if RR_PAIRLOOP
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    iteration(kt, std::integral_constant<int, PDEPTH - 1>{}, I0{});
+    iteration(kt + 1, I0{}, I1{});
+  }
+  if (kt < nk) iteration(kt, std::integral_constant<int, PDEPTH - 1>{}, I0{});
+#else
+  for (int kt = 0; kt < nk; kt += 2) {
     iteration(kt, std::integral_constant<int, PDEPTH - 1>{}, I0{});
     if (kt + 1 < nk) iteration(kt + 1, I0{}, I1{});
   }
+#endif
 
 #if RR_VEC_EPI
   // ---- epilogue.  The MFMAs are issued with the operands swapped (B fragment first), so a 16x16 block holds
