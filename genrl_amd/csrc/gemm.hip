@@ -1040,6 +1040,22 @@ inline SplitPlan plan_split(int M, int N, int K) {
   return p;
 }
 
+// Row split of a 128x128-tile product whose tile count ends just above a multiple of the resident slots
+// (2 workgroups per CU): the last, mostly empty round costs a whole tile time (17408x1024x1024 = 1088 tiles
+// took 317 us against 261 us for the 1024 tiles of 16384x1024x1024).  The rows of the full rounds go out as one
+// launch and the remaining rows as a second product planned on its own (64x64 tiles fill the chip again).
+// Alone: 352 -> 324 us; inside the step, where other streams' kernels fill the last round, neutral.
+// Returns the rows of the first part, 0 = no split.  GENRL_GEMM_TAIL=0 disables it (calibration).
+inline int tail_split_rows(int M, int N, int K, const SplitPlan& p) {
+  static const char* f = getenv("GENRL_GEMM_TAIL");
+  if ((f && f[0] == '0') || !p.big || p.splits != 1 || K < 512 || !use_rr_big()) return 0;
+  const long tn = cdiv(N, 128), tm = cdiv(M, 128), tiles = tm * tn, slots = 512;
+  const long left = tiles % slots;
+  if (tiles < slots || left == 0 || left * 8 > slots * 3) return 0;
+  const long main_tm = (tiles - left) / tn;
+  return (main_tm > 0 && main_tm < tm) ? (int)(main_tm * 128) : 0;
+}
+
 template <int BM, int BN, int BK, int KG, int PD>
 int launch_cfg(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks, float* C,
                long ldc, const float* bias, int M, int N, int K, int accumulate, int splits, int kps, float* ws,
@@ -1167,6 +1183,10 @@ extern "C" const char* genrl_last_error(void) { return hipGetErrorString((hipErr
 extern "C" long genrl_sgemm_ws_floats(int M, int N, int K) {
   // (the skinny path (M <= 32, A k-contiguous) needs none; the stride-agnostic answer stays an upper bound)
   const SplitPlan p = plan_split(M, N, K);
+  if (const int m1 = tail_split_rows(M, N, K, p)) {
+    const SplitPlan q = plan_split(M - m1, N, K);
+    return q.splits > 1 ? (long)q.splits * (M - m1) * N : 0;
+  }
   return p.splits > 1 ? (long)p.splits * M * N : 0;
 }
 
@@ -1195,6 +1215,13 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
   }
 #endif
   SplitPlan p = plan_split(M, N, K);
+  if (G == 0)
+    if (const int m1 = tail_split_rows(M, N, K, p)) {
+      const int rc = sgemm_impl(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, m1, N, K, accumulate, nullptr, 0, stream, 0, nullptr);
+      if (rc) return rc;
+      return sgemm_impl(A + (long)m1 * a_rs, a_rs, a_ks, B, b_rs, b_ks, C + (long)m1 * ldc, ldc, bias, M - m1, N, K, accumulate, ws,
+                        ws_floats, stream, 0, nullptr);
+    }
   const bool split = p.splits > 1 && ws && ws_floats >= (long)p.splits * M * N;
   if (!split) p.splits = 1, p.k_per_split = K;
   float* wsp = split ? ws : nullptr;
