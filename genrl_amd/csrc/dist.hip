@@ -186,11 +186,11 @@ __device__ __forceinline__ TwoHot twohot_target(const float* __restrict__ bucket
 __global__ __launch_bounds__(256) void twohot_fwd_kernel(const float* __restrict__ logits,
                                                          const float* __restrict__ x,
                                                          const float* __restrict__ buckets, float* __restrict__ out,
-                                                         long R, int mode) {
+                                                         long R, int mode, long ld) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= R) return;
-  const float* lr = logits + row * 255;
+  const float* lr = logits + row * ld;
   float m = -INFINITY;
   for (int j = lane; j < 255; j += 64) m = fmaxf(m, lr[j]);
   m = wave_max(m);
@@ -215,11 +215,11 @@ __global__ __launch_bounds__(256) void twohot_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ x,
                                                          const float* __restrict__ buckets,
                                                          const float* __restrict__ gout, float* __restrict__ dlogits,
-                                                         long R, int mode) {
+                                                         long R, int mode, long ld, long ldd) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= R) return;
-  const float* lr = logits + row * 255;
+  const float* lr = logits + row * ld;
   float m = -INFINITY;
   for (int j = lane; j < 255; j += 64) m = fmaxf(m, lr[j]);
   m = wave_max(m);
@@ -232,7 +232,8 @@ __global__ __launch_bounds__(256) void twohot_bwd_kernel(const float* __restrict
   z = wave_sum(z);
   sb = wave_sum(sb);
   const float g = gout[row];
-  float* dr = dlogits + row * 255;
+  float* dr = dlogits + row * ldd;
+  if (ldd > 255 && lane == 63) dr[255] = 0.f;      // padded rows (ldd = 256): the pad column is a defined zero
   if (mode == 1) {
     const float mu = sb / z;
     const float ds = g * expf(fabsf(mu));  // d symexp
@@ -527,22 +528,24 @@ int genrl_cat_kl_bwd(const float* lp, const float* lq, const float* gp, const fl
   });
 }
 
-int genrl_twohot_fwd(const float* logits, const float* x, const float* buckets, float* out, long R, int mode,
+int genrl_twohot_fwd(const float* logits, long ld, const float* x, const float* buckets, float* out, long R, int mode,
                      void* stream) {
   GENRL_ENTER();
   if (R <= 0) return GENRL_OK;
+  if (ld < 255) return GENRL_EINVAL;
   hipLaunchKernelGGL(twohot_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, logits, x, buckets, out, R,
-                     mode);
+                     mode, ld);
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }
 
-int genrl_twohot_bwd(const float* logits, const float* x, const float* buckets, const float* gout, float* dlogits,
-                     long R, int mode, void* stream) {
+int genrl_twohot_bwd(const float* logits, long ld, const float* x, const float* buckets, const float* gout,
+                     float* dlogits, long ldd, long R, int mode, void* stream) {
   GENRL_ENTER();
   if (R <= 0) return GENRL_OK;
+  if (ld < 255 || ldd < 255) return GENRL_EINVAL;
   hipLaunchKernelGGL(twohot_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, logits, x, buckets, gout,
-                     dlogits, R, mode);
+                     dlogits, R, mode, ld, ldd);
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }

@@ -556,26 +556,35 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
     return (long)sgi * g.seg_stride + (kk - sgi * g.seg_len);
   };
   // branch-free clamped loads (see sgemm_kernel::load_fast); returns the in-bounds flag
+  // Returns how many of the 4 loaded elements are inside the operand (applied at lstore time, so that the mask does
+  // not wait for the load).  The extent along the vector may be any size as long as the lines are padded to a
+  // multiple of 4 floats (launch_rr checks ld >= roundup4(extent)): the clamp keeps the address aligned, and
+  // the elements past the end are masked (k-contiguous) or feed rows/columns that are never stored.
   auto gload = [&](const float* __restrict__ P, long ld, int rows_total, int r0, int k0, bool kc, float4& out, int v,
-                   bool gath) -> bool {
-    bool inb;
+                   bool gath) -> int {
+    int cnt;
     if (kc) {
       const int row = r0 + v / KV, k = k0 + ((v % KV) << 2);
-      inb = k < K;
-      const int rc = min(row, rows_total - 1), kc_ = min(k, Ktot - 4);
+      cnt = min(max(K - k, 0), 4);
+      const int rc = min(row, rows_total - 1), kc_ = min(k, ((Ktot + 3) & ~3) - 4);
       out = gath ? *reinterpret_cast<const float4*>(P + gbase(rc) + gseg(kc_))
                  : *reinterpret_cast<const float4*>(P + (long)rc * ld + kc_);
     } else {
       const int k = k0 + v / RV, row = r0 + ((v % RV) << 2);
-      inb = (k < K) && (row < rows_total);
-      const int kc_ = min(k, Ktot - 1), rc = min(row, rows_total - 4);
+      cnt = ((k < K) && (row < rows_total)) ? 4 : 0;
+      const int kc_ = min(k, Ktot - 1), rc = min(row, ((rows_total + 3) & ~3) - 4);
       out = gath ? *reinterpret_cast<const float4*>(P + gbase(kc_) + gseg(rc))
                  : *reinterpret_cast<const float4*>(P + (long)kc_ * ld + rc);
     }
-    return inb;
+    return cnt;
   };
-  auto lstore = [&](float* S, int ld, bool kc, float4 val, bool inb, int v) {
-    if (!KX && !inb) val = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto lstore = [&](float* S, int ld, bool kc, float4 val, int cnt, int v) {
+    if (!KX && cnt < 4) {
+      val.w = 0.f;
+      if (cnt < 3) val.z = 0.f;
+      if (cnt < 2) val.y = 0.f;
+      if (cnt < 1) val.x = 0.f;
+    }
     if (kc) *reinterpret_cast<float4*>(&S[(v / KV) * ld + ((v % KV) << 2)]) = val;
     else *reinterpret_cast<float4*>(&S[(v / RV) * ld + ((v % RV) << 2)]) = val;
   };
@@ -588,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
   // register sets of staged tiles (PDEPTH 2: tile kt+1 waits in one while tile kt+2 is in flight into the
   // other — a load then has two whole iterations to land; MALL/HBM latency exceeds one ~1 us iteration)
   float4 ra[PDEPTH][NV], rb[PDEPTH][NV];
-  bool ia[PDEPTH][NV], ib[PDEPTH][NV];
+  int ia[PDEPTH][NV], ib[PDEPTH][NV];          // valid elements of each staged vector (4 everywhere when KX)
   const int nk = (K - kbeg + BK - 1) / BK;
   const float* pa[NV];
   const float* pb[NV];
@@ -599,11 +608,11 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
     for (int i = 0; i < NV; ++i) {
       const int v = tid + i * NT;
       if (A_KC) pa[i] = A + (long)min(m0 + v / KV, M - 1) * a_ld + kbeg + ((v % KV) << 2);
-      else pa[i] = A + (long)(kbeg + v / RV) * a_ld + min(m0 + ((v % RV) << 2), M - 4);
+      else pa[i] = A + (long)(kbeg + v / RV) * a_ld + min(m0 + ((v % RV) << 2), ((M + 3) & ~3) - 4);
       if (B_KC) pb[i] = B + (long)min(n0 + v / KV, N - 1) * b_ld + kbeg + ((v % KV) << 2);
-      else pb[i] = B + (long)(kbeg + v / RV) * b_ld + min(n0 + ((v % RV) << 2), N - 4);
+      else pb[i] = B + (long)(kbeg + v / RV) * b_ld + min(n0 + ((v % RV) << 2), ((N + 3) & ~3) - 4);
 #pragma unroll
-      for (int st = 0; st < PDEPTH; ++st) ia[st][i] = ib[st][i] = true;
+      for (int st = 0; st < PDEPTH; ++st) ia[st][i] = ib[st][i] = 4;
     }
   }
   auto nextA = [&](int st, int i) {        // KX: load the thread's i-th A vector of the next unfetched tile
@@ -1135,9 +1144,12 @@ int launch_rr(const float* A, long a_rs, long a_ks, const float* B, long b_rs, l
     if (G == 1) a_vec = ok && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
     else b_vec = ok && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
   }
-  const bool k4 = (K % 4 == 0) && K >= 4;
-  const bool fast = a_vec && b_vec && ((!a_kc && !b_kc) || k4) && (a_kc || (M % 4 == 0 && M >= 4)) &&
-                    (b_kc || (N % 4 == 0 && N >= 4));
+  // every line of an operand must hold a whole number of 16-byte vectors: ld >= roundup4(extent along the line)
+  // (an extent that is itself a multiple of 4 always qualifies; 255 does with rows padded to 256)
+  const long K4 = ((long)K + 3) & ~3L, M4 = ((long)M + 3) & ~3L, N4 = ((long)N + 3) & ~3L;
+  const bool a_ok = G == 1 ? (K % 4 == 0) : (a_ld >= (a_kc ? K4 : M4));
+  const bool b_ok = G == 2 ? (N % 4 == 0) : (b_ld >= (b_kc ? K4 : N4));
+  const bool fast = a_vec && b_vec && a_ok && b_ok && K >= 4 && M >= 4 && N >= 4;
   if (!fast || (G == 1 && !(a_kc && b_kc)) || (G == 2 && (a_kc || b_kc))) return -1;
   constexpr int BT = 32 * WB, BKR = WB == 2 ? 64 : 32;
   const int tiles_m = cdiv(M, BT), tiles_n = cdiv(N, BT), ntiles = tiles_m * tiles_n;

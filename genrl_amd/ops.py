@@ -26,6 +26,14 @@ def _p(t):
     return t.data_ptr()
 
 
+def _prows(t):
+    """pointer of a 2-D operand whose rows are evenly spaced (unit column stride); the callee gets the spacing"""
+    if not t.is_cuda:
+        raise GenrlHipError('genrl_amd ops need tensors on the MI355X (no CPU fallback)')
+    assert t.dim() == 2 and (t.shape[1] == 1 or t.stride(1) == 1), 'rows must be unit-stride'
+    return t.data_ptr()
+
+
 def _f32(t):
     assert t.dtype == torch.float32, t.dtype
     return t
@@ -112,11 +120,11 @@ def sgemm_conv(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, which, img, 
         gemm_profile.append((M, N, K, e0, e1, ('k' if a_ks == 1 else 'r') + ('k' if b_ks == 1 else 'r') + f'/conv{which}'))
 
 
-def colsum(x2d, out=None, accumulate=False):
+def colsum(x2d, out=None, accumulate=False, ld=None):
     M, N = x2d.shape
     out = out if out is not None else torch.empty(N, device=x2d.device)
     ws = _ws(lib().genrl_colsum_ws_floats(M, N), x2d.device)
-    check(lib().genrl_colsum(_p(x2d), N, _p(out), _p(ws), M, N, int(accumulate), _stream()), 'colsum')
+    check(lib().genrl_colsum(_prows(x2d), ld or N, _p(out), _p(ws), M, N, int(accumulate), _stream()), 'colsum')
     return out
 
 
@@ -164,44 +172,60 @@ def transpose_last2_raw(x):
 
 # ------------------------------------------------------------------ Linear
 
+_NO_PAD = os.environ.get('GENRL_NO_PAD_HEADS') == '1'      # calibration only
+
+
+def _rows_ld(t2d):
+    """Row-major 2-D operand for the GEMMs without a copy: (tensor, leading dimension).  A column slice of a
+    wider buffer (rows 16-byte aligned, spaced by a multiple of 4 floats) is used in place."""
+    if t2d.stride(1) == 1 and t2d.stride(0) >= t2d.shape[1] and t2d.stride(0) % 4 == 0 and t2d.data_ptr() % 16 == 0:
+        return t2d, t2d.stride(0)
+    t2d = t2d.contiguous()
+    return t2d, t2d.shape[1]
+
+
 class _Linear(Function):
+    """y = x W^T + b.  For N % 4 != 0 (the 255-bin two-hot heads) y is a column slice of a buffer with rows padded
+    to a multiple of 4 floats, and a gradient arriving in such a slice is read in place: the vector-load GEMM
+    kernels need 16-byte aligned rows (a 255-wide operand falls back to the scalar-load kernel, ~3x slower)."""
     @staticmethod
     def forward(ctx, x, W, b):
         x2 = _f32(x).reshape(-1, x.shape[-1]).contiguous()
         M, K = x2.shape
         N = W.shape[0]
-        y = torch.empty(M, N, device=x.device)
-        sgemm(x2, K, 1, W, K, 1, y, N, b, M, N, K)
+        Np = (N + 3) // 4 * 4 if (N >= 128 and not _NO_PAD) else N   # (narrow heads take the thin-product paths anyway)
+        y = torch.empty(M, Np, device=x.device)
+        sgemm(x2, K, 1, W, K, 1, y, Np, b, M, N, K)
         ctx.save_for_backward(x2, W)
         ctx.has_bias = b is not None
         ctx.bias = b
         ctx.xshape = x.shape
-        return y.reshape(*x.shape[:-1], N)
+        return (y if Np == N else y[:, :N]).view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
         x2, W = ctx.saved_tensors
         M, K = x2.shape
         N = W.shape[0]
-        dy2 = dy.reshape(M, N).contiguous()
+        dy2, ldy = _rows_ld(dy.reshape(M, N))
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dy.device)
-            sgemm(dy2, N, 1, W, 1, K, dx, K, None, M, K, N)          # dx = dy W
+            sgemm(dy2, ldy, 1, W, 1, K, dx, K, None, M, K, N)          # dx = dy W
             dx = dx.reshape(ctx.xshape)
         if ctx.needs_input_grad[1]:
             tgt = _grad_buf(W)
             if tgt is not None:
-                wgrad_stream.run(lambda: sgemm(dy2, 1, N, x2, 1, K, tgt, K, None, N, K, M, accumulate=True), dy2, x2)
+                wgrad_stream.run(lambda: sgemm(dy2, 1, ldy, x2, 1, K, tgt, K, None, N, K, M, accumulate=True), dy2, x2)
             else:
                 dW = torch.empty(N, K, device=dy.device)
-                sgemm(dy2, 1, N, x2, 1, K, dW, K, None, N, K, M)     # dW = dy^T x
+                sgemm(dy2, 1, ldy, x2, 1, K, dW, K, None, N, K, M)     # dW = dy^T x
         if ctx.has_bias and ctx.needs_input_grad[2]:
             tgt = _grad_buf(ctx.bias)
             if tgt is not None:
-                colsum(dy2, out=tgt, accumulate=True)
+                colsum(dy2, out=tgt, accumulate=True, ld=ldy)
             else:
-                db = colsum(dy2)
+                db = colsum(dy2, ld=ldy)
         return dx, dW, db
 
 
@@ -365,27 +389,40 @@ def twohot_buckets(dev):
     return _buckets[k]
 
 
+def _rows255(t):
+    """(R x 255 view, row stride) of two-hot logits without copying when the rows are evenly spaced (the padded
+    rows _Linear hands out for N % 4 != 0); otherwise a contiguous copy."""
+    R = t.numel() // 255
+    try:
+        v = t.view(R, 255)
+    except RuntimeError:
+        v = None
+    if v is None or v.stride(1) != 1 or (R > 1 and v.stride(0) < 255):
+        v = t.reshape(R, 255).contiguous()
+    return v, (v.stride(0) if R > 1 else 255)
+
+
 class _TwoHot(Function):
     @staticmethod
     def forward(ctx, logits, x, mode):
-        lg = _f32(logits).contiguous()
-        R = lg.numel() // 255
+        lg, ld = _rows255(_f32(logits))
+        R = lg.shape[0]
         b = twohot_buckets(lg.device)
         xx = x.reshape(R).contiguous() if x is not None else None
         out = torch.empty(R, device=lg.device)
-        check(lib().genrl_twohot_fwd(_p(lg), _p(xx), _p(b), _p(out), R, mode, _stream()), 'twohot_fwd')
+        check(lib().genrl_twohot_fwd(_prows(lg), ld, _p(xx), _p(b), _p(out), R, mode, _stream()), 'twohot_fwd')
         ctx.save_for_backward(lg, xx if xx is not None else lg.new_empty(0))
-        ctx.mode = mode
-        return out.reshape(lg.shape[:-1])
+        ctx.mode, ctx.ld, ctx.lshape = mode, ld, logits.shape
+        return out.reshape(logits.shape[:-1])
 
     @staticmethod
     def backward(ctx, g):
         lg, xx = ctx.saved_tensors
-        R = lg.numel() // 255
-        d = torch.empty_like(lg)
-        check(lib().genrl_twohot_bwd(_p(lg), _p(xx) if ctx.mode == 0 else None, _p(twohot_buckets(lg.device)),
-                                     _p(g.reshape(R).contiguous()), _p(d), R, ctx.mode, _stream()), 'twohot_bwd')
-        return d, None, None
+        R = lg.shape[0]
+        d = torch.empty(R, 256, device=lg.device)          # padded rows: the head's dgrad/wgrad read them in place
+        check(lib().genrl_twohot_bwd(_prows(lg), ctx.ld, _p(xx) if ctx.mode == 0 else None, _p(twohot_buckets(lg.device)),
+                                     _p(g.reshape(R).contiguous()), _p(d), 256, R, ctx.mode, _stream()), 'twohot_bwd')
+        return d[:, :255].view(ctx.lshape), None, None
 
 
 def twohot_logprob(logits, x):

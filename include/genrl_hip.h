@@ -23,7 +23,11 @@ extern "C" {
  * one stride of each operand must be 1.  fp32 MFMA (v_mfma_f32_32x32x2_f32).
  * Shapes with few output tiles and a long reduction (the M=N=1024 GEMMs, the conv weight
  * gradients) are split over K into `ws` (>= genrl_sgemm_ws_floats(M,N,K) floats; pass NULL/0 to
- * disable) and reduced deterministically. */
+ * disable) and reduced deterministically.
+ * Padded lines: an operand whose lines (rows of a k-contiguous operand, k-lines of a row-contiguous one) are a
+ * multiple of 4 floats apart, 16-byte aligned and at least roundup4(extent) long is read with 16-byte loads
+ * up to the end of the padded line (extent = 255 in rows of 256: element 255 of every line is read and
+ * ignored), so the padding must be addressable; every other layout takes the scalar-load kernel. */
 long genrl_sgemm_ws_floats(int M, int N, int K);
 int genrl_sgemm(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks, float* C, long ldc,
                 const float* bias, int M, int N, int K, int accumulate, float* ws, long ws_floats, void* stream);
@@ -94,11 +98,13 @@ int genrl_cat_kl_fwd(const float* lp, const float* lq, float* kl, float* ent_p, 
 int genrl_cat_kl_bwd(const float* lp, const float* lq, const float* gp, const float* gq, float* dlp, float* dlq, long R,
                      int S, int K, float unimix, void* stream);
 
-/* ---- TwoHotDist (agent/dreamer_utils.py:120-171): mode 0 log_prob(x), mode 1 mean */
-int genrl_twohot_fwd(const float* logits, const float* x, const float* buckets, float* out, long R, int mode,
+/* ---- TwoHotDist (agent/dreamer_utils.py:120-171): mode 0 log_prob(x), mode 1 mean.  logits rows are `ld` floats
+ * apart (255, or 256 for the padded rows the head's GEMMs prefer), dlogits rows `ldd`; with ldd > 255 the
+ * backward also writes a zero into column 255. */
+int genrl_twohot_fwd(const float* logits, long ld, const float* x, const float* buckets, float* out, long R, int mode,
                      void* stream);
-int genrl_twohot_bwd(const float* logits, const float* x, const float* buckets, const float* gout, float* dlogits,
-                     long R, int mode, void* stream);
+int genrl_twohot_bwd(const float* logits, long ld, const float* x, const float* buckets, const float* gout,
+                     float* dlogits, long ldd, long R, int mode, void* stream);
 
 /* ---- lambda_return (agent/dreamer_utils.py:228-253): reward [H,N], value [H+1,N] */
 int genrl_lambda_return_fwd(const float* reward, const float* value, float* ret, int H, long N, float disc, float lam,

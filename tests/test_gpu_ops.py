@@ -66,6 +66,30 @@ def test_sgemm_exact_layout(ops):
     assert torch.equal(C.cpu(), 2 * (A @ B.T))
 
 
+@pytest.mark.parametrize('M,N,K', [(1024, 255, 512), (1024, 512, 255), (255, 512, 1024), (300, 255, 255), (2048, 130, 1030),
+                                   (16384, 255, 1024)])
+def test_sgemm_padded_lines(ops, M, N, K):
+    """Extents that are not a multiple of 4 in lines padded to one (the 255-bin two-hot heads in rows of 256): the
+    vector-load kernels read the padding, which holds NaN here, and must not let it reach the result.  All four
+    operand layouts, padded C, bias + accumulate; exact on small integers."""
+    r4 = lambda n: (n + 3) // 4 * 4
+    A = (torch.arange(M * K, dtype=torch.float32).reshape(M, K) % 5 - 2)
+    B = ((torch.arange(N * K, dtype=torch.float32).reshape(N, K) * 3) % 7 - 3)
+    bias = torch.arange(N, dtype=torch.float32) % 3
+    want = A.double() @ B.double().T
+
+    def padded(t):                       # rows of t in lines of roundup4(cols), padding = NaN
+        buf = torch.full((t.shape[0], r4(t.shape[1])), float('nan'))
+        buf[:, :t.shape[1]] = t
+        return buf.cuda()
+    for (a, ars, aks) in ((padded(A), r4(K), 1), (padded(A.T), 1, r4(M))):
+        for (b, brs, bks) in ((padded(B), r4(K), 1), (padded(B.T), 1, r4(N))):
+            C = torch.full((M, r4(N)), 1.0, device='cuda')
+            ops.sgemm(a, ars, aks, b, brs, bks, C, r4(N), bias.cuda(), M, N, K, accumulate=True)
+            assert torch.equal(C[:, :N].cpu().double(), want + bias.double() + 1.0), (ars, aks, brs, bks)
+            assert torch.equal(C[:, N:].cpu(), torch.ones(M, r4(N) - N))          # C's padding is not written
+
+
 @pytest.mark.parametrize('M', [1, 4, 16, 17, 32])
 @pytest.mark.parametrize('N,K', [(10, 8), (16, 520), (1000, 1034), (3072, 1024), (1024, 3073), (33, 5)])
 def test_sgemm_skinny(ops, M, N, K):
@@ -163,6 +187,21 @@ def test_twohot(ops):
     x = torch.tensor([-30., -20., -3.3, 0., 0.5, 19.999]).reshape(6, 1, 1) * torch.tensor([1., .5, 1.7, -1., 1e-3]).reshape(1, 5, 1)
     compare(lambda l: ops.twohot_logprob(l, x.cuda()), lambda l: O.twohot_logprob(l, x), [lg], rtol=1e-4, atol=1e-5)
     compare(ops.twohot_mean, O.twohot_mean, [lg], rtol=1e-4, atol=1e-5)
+
+
+def test_twohot_head_padded_rows(ops):
+    """The 255-bin head end to end: linear hands out logits as a column slice of rows padded to 256, the two-hot
+    kernels read them in place and return the gradient the same way, and linear's dgrad / wgrad / bias
+    gradient consume that slice without a copy — against plain torch on the host."""
+    B, T, K = 12, 32, 512
+    x = torch.randn(B, T, K, generator=g(1)); W = torch.randn(255, K, generator=g(2)) / K ** 0.5
+    b = torch.randn(255, generator=g(3)) * 0.1
+    tgt = torch.randn(B, T, 1, generator=g(4)) * 3
+    lg = ops.linear(x.cuda(), W.cuda(), b.cuda())
+    assert lg.shape == (B, T, 255) and lg.stride() == (T * 256, 256, 1)
+    hip = lambda x, W, b: (ops.twohot_logprob(ops.linear(x, W, b), tgt.cuda()), ops.twohot_mean(ops.linear(x, W, b)))
+    ref = lambda x, W, b: (O.twohot_logprob(F.linear(x, W, b), tgt), O.twohot_mean(F.linear(x, W, b)))
+    compare(hip, ref, [x, W, b], rtol=1e-4, atol=1e-4)
 
 
 def test_lambda_return(ops):
