@@ -549,24 +549,27 @@ class EnsembleRSSM(Module):  # ref :302-555
 class FlatGroup:
     """Parameters of one optimiser group re-homed into one flat fp32 buffer (params and grads are
     views), so clip-norm + decay + Adam is one pass and DP needs one all-reduce per group."""
+    ALIGN = 64          # floats: every parameter starts on a 256-byte boundary (the vector-load GEMMs need 16)
+
     def __init__(self, params):
         self.params = [p for p in params]
         dev = self.params[0].device
-        n = sum(p.numel() for p in self.params)
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.n = n
-        self.flat = torch.empty(n, device=dev)
+        self.flat = torch.zeros(n, device=dev)              # (the gaps stay zero: zero gradient, zero Adam moments)
         self.grad = torch.zeros(n, device=dev)
         self.m = torch.zeros(n, device=dev)
         self.v = torch.zeros(n, device=dev)
         self.step = 0
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)   # device-side Adam step (graph replay)
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             k = p.numel()
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view(p.shape)
             p.grad = self.grad[off:off + k].view(p.shape)
-            off += k
         self.norm = torch.zeros(1, device=dev)
 
     def owns(self, params):
@@ -574,15 +577,12 @@ class FlatGroup:
 
     def rebind(self):
         """re-attach .grad views (zero_grad(set_to_none) or external code may have dropped them)"""
-        off = 0
-        for p in self.params:
-            k = p.numel()
-            g = self.grad[off:off + k].view(p.shape)
+        for p, off in zip(self.params, self.offsets):
+            g = self.grad[off:off + p.numel()].view(p.shape)
             if p.grad is None:
                 p.grad = g
             elif p.grad.data_ptr() != g.data_ptr():
                 g.copy_(p.grad); p.grad = g
-            off += k
 
 
 class Optimizer:

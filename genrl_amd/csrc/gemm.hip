@@ -1202,6 +1202,14 @@ extern "C" long genrl_sgemm_ws_floats(int M, int N, int K) {
   return p.splits > 1 ? (long)p.splits * M * N : 0;
 }
 
+// GENRL_GEMM_TRACE=1: one stderr line per product that misses the vector-load kernels (operand layout audit)
+static void trace_fallback(int M, int N, int K, long a_rs, long a_ks, long b_rs, long b_ks, const void* A, const void* B) {
+  static const char* f = getenv("GENRL_GEMM_TRACE");
+  if (f && f[0] == '1')
+    fprintf(stderr, "[genrl gemm fallback] M=%d N=%d K=%d a=(%ld,%ld) b=(%ld,%ld) A%%16=%d B%%16=%d\n", M, N, K, a_rs, a_ks, b_rs,
+            b_ks, (int)(reinterpret_cast<uintptr_t>(A) & 15), (int)(reinterpret_cast<uintptr_t>(B) & 15));
+}
+
 static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks,
                       float* C, long ldc, const float* bias, int M, int N, int K,
                       int accumulate, float* ws, long ws_floats, void* stream, int G, const Gather* gp) {
@@ -1215,6 +1223,7 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
     const long b_ld = b_kc ? b_rs : b_ks;
     const int vec = ((a_rs & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
                     (!b_kc || (((b_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0)));
+    if (!vec) trace_fallback(M, N, K, a_rs, a_ks, b_rs, b_ks, A, B);
     dim3 grid(cdiv(N, 16), 1, M <= 32 ? 1 : cdiv(M, 64)), block(1024);
 #define GO(MB, BKC) \
   hipLaunchKernelGGL((skinny_kernel<MB, BKC>), grid, block, 0, s, A, a_rs, B, b_ld, C, ldc, bias, M, N, K, accumulate, vec, 0L)
@@ -1247,6 +1256,8 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
                                                             p.splits, p.k_per_split, wsp, s, G, gp);
   else if (use_rr(M, N, K, p.splits) && (rc = launch_rr<2>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, p.splits,
                                        (p.k_per_split + 63) / 64 * 64, wsp, s, G, gp)) >= 0)
+    ;
+  else if (trace_fallback(M, N, K, a_rs, a_ks, b_rs, b_ks, A, B), false)
     ;
   else if ((p.splits == 1 && (long)cdiv(M, 64) * cdiv(N, 64) >= GENRL_MID_TILES) || force_mid())
     // several 64x64 tiles per CU: 256-thread workgroups (one wave per SIMD each, 4+ resident per CU,

@@ -723,6 +723,7 @@ class _Rollout(Function):
         stoch = f(H + 1, N, SK); deter = f(H + 1, N, D); logit = f(H + 1, N, SK); action = torch.zeros(H + 1, N, AP, device=dev)
         wa = torch.zeros(sp.in_w.shape[0], AP, device=dev)
         wa[:, :A].copy_(sp.in_w[:, SK:SK + A])
+        ws_in = sp.in_w[:, :SK].contiguous()     # stoch slice with 16-byte aligned rows (the (U, SK + A) weight's are not)
         raws = f(H, N, 2 * A)
         stoch[0].copy_(stoch0.reshape(N, SK)); deter[0].copy_(deter0); logit[0].copy_(logit0.reshape(N, SK))
         x_pre, x = f(H, N, U), f(H, N, U)
@@ -739,7 +740,7 @@ class _Rollout(Function):
             check(lib().genrl_actor_head_fwd(pt(raws, h * N * 2 * A), pt(eps, h * N * A), pt(action, (h + 1) * N * AP), None, None,
                                              N, A, sp.min_std, sp.max_std, AP, _stream()), 'actor_head_fwd')
             # img_in: [stoch_h | action_{h+1}] -> hidden, LN + SiLU
-            sgemm(stoch, SK, 1, sp.in_w, Kin, 1, x_pre, U, sp.in_b, N, U, SK, a_off=sN, c_off=h * N * U)
+            sgemm(stoch, SK, 1, ws_in, SK, 1, x_pre, U, sp.in_b, N, U, SK, a_off=sN, c_off=h * N * U)
             sgemm(action, AP, 1, wa, AP, 1, x_pre, U, None, N, U, AP, accumulate=True, a_off=(h + 1) * N * AP, c_off=h * N * U)
             _ln_fwd_raw(pt(x_pre, h * N * U), sp.in_g, sp.in_be, pt(x, h * N * U), pt(st['xm'], h * N), pt(st['xr'], h * N),
                         N, U, sp.in_eps)
@@ -758,7 +759,7 @@ class _Rollout(Function):
                                          UNIMIX, _stream()), 'onehot_fwd')
         tape.inputs = (stoch, deter)
         ctx.sp = sp
-        ctx.bufs = (stoch, deter, logit, raws, eps, x_pre, g_pre, o_pre, st, wa)
+        ctx.bufs = (stoch, deter, logit, raws, eps, x_pre, g_pre, o_pre, st, wa, ws_in)
         ctx.nparams = len(actor_params)
         ctx.dims = (H, N, S, K, D, A, U)
         return stoch.reshape(H + 1, N, S, K), deter, logit.reshape(H + 1, N, S, K), action[:, :, :A], raws
@@ -766,7 +767,7 @@ class _Rollout(Function):
     @staticmethod
     def backward(ctx, d_stoch, d_deter, d_logit, d_action, d_raws):
         sp, tape = ctx.sp, ctx.sp.tape
-        stoch, deter, logit, raws, eps, x_pre, g_pre, o_pre, st, wa = ctx.bufs
+        stoch, deter, logit, raws, eps, x_pre, g_pre, o_pre, st, wa, ws_in = ctx.bufs
         H, N, S, K, D, A, U = ctx.dims
         SK = S * K
         dev = deter.device
@@ -800,7 +801,7 @@ class _Rollout(Function):
             sgemm(dg_pre, 3 * D, 1, sp.gru_w, 1, Kg, cur, D, None, N, D, 3 * D, accumulate=True, b_off=U)
             sgemm(dg_pre, 3 * D, 1, sp.gru_w, 1, Kg, dx, U, None, N, U, 3 * D)
             _ln_bwd_raw(_p(dx), pt(x_pre, h * N * U), sp.in_g, sp.in_be, pt(st['xm'], h * N), pt(st['xr'], h * N), _p(dx_pre), N, U)
-            sgemm(dx_pre, U, 1, sp.in_w, 1, Kin, ds, SK, None, N, SK, U, accumulate=True, c_off=sN)
+            sgemm(dx_pre, U, 1, ws_in, 1, SK, ds, SK, None, N, SK, U, accumulate=True, c_off=sN)
             if da_in is not None:
                 dact.zero_()
                 dact[:, :A].copy_(da_in[h + 1])
@@ -1031,6 +1032,16 @@ def scale_(p, s):
 
 # ------------------------------------------------------------------ fused multi-input layers
 
+def _aligned_block(W, K1, M):
+    """First column block W[:, :K1] of a two-input layer's weight for the GEMMs: (tensor, row spacing).  Rows of W
+    are K floats apart; with K % 4 != 0 (1024 latent + 10 action inputs) they are not 16-byte aligned and the big
+    block would take the scalar-load kernel, so it gets a compact copy (4 MB, once per call)."""
+    K = W.shape[1]
+    if K % 4 and K1 % 4 == 0 and K1 < K and M > 32:
+        return W[:, :K1].contiguous(), K1
+    return W, K
+
+
 class _Linear2(Function):
     """y = [x1, x2] W^T + b without materialising the concatenation: W = [W1 | W2] column blocks
     (torch.cat([stoch, action]) -> _img_in, agent/dreamer_utils.py:461-462; feat -> MLP dense0)."""
@@ -1043,8 +1054,10 @@ class _Linear2(Function):
         N, K = W.shape
         assert K == K1 + K2 and c.shape[0] == M
         y = torch.empty(M, N, device=a.device)
-        sgemm(a, K1, 1, W, K, 1, y, N, b, M, N, K1)
+        w1, ld1 = _aligned_block(W, K1, M)
+        sgemm(a, K1, 1, w1, ld1, 1, y, N, b, M, N, K1)
         sgemm(c, K2, 1, W, K, 1, y, N, None, M, N, K2, accumulate=True, b_off=K1)
+        ctx.w1 = (w1, ld1)
         ctx.save_for_backward(a, c, W)
         ctx.has_bias = b is not None
         ctx.shapes = (x1.shape, x2.shape)
@@ -1060,7 +1073,7 @@ class _Linear2(Function):
         d1 = d2 = dW = db = None
         if ctx.needs_input_grad[0]:
             d1 = torch.empty(M, K1, device=dy.device)
-            sgemm(dy2, N, 1, W, 1, K, d1, K1, None, M, K1, N)
+            sgemm(dy2, N, 1, ctx.w1[0], 1, ctx.w1[1], d1, K1, None, M, K1, N)
             d1 = d1.reshape(ctx.shapes[0])
         if ctx.needs_input_grad[1]:
             d2 = torch.empty(M, K2, device=dy.device)
@@ -1266,9 +1279,11 @@ class _DenseLNAct(Function):
         N, K = W.shape
         assert K == K1 + K2
         pre = torch.empty(M, N, device=a.device)
-        sgemm(a, K1, 1, W, K, 1, pre, N, b, M, N, K1)
+        w1, ld1 = _aligned_block(W, K1, M)
+        sgemm(a, K1, 1, w1, ld1, 1, pre, N, b, M, N, K1)
         if c is not None:
             sgemm(c, K2, 1, W, K, 1, pre, N, None, M, N, K2, accumulate=True, b_off=K1)
+        ctx.w1 = (w1, ld1)
         y = torch.empty_like(pre)
         mean = torch.empty(M, device=a.device); rstd = torch.empty(M, device=a.device)
         check(lib().genrl_ln_act_fwd(_p(pre), N, _p(gamma), _p(beta), _p(y), N, _p(mean), _p(rstd), M, N, eps, 1,
@@ -1305,7 +1320,7 @@ class _DenseLNAct(Function):
         d1 = d2 = dW = None
         if ctx.needs_input_grad[0]:
             d1 = torch.empty(M, K1, device=dev)
-            sgemm(dpre, N, 1, W, 1, K, d1, K1, None, M, K1, N)
+            sgemm(dpre, N, 1, ctx.w1[0], 1, ctx.w1[1], d1, K1, None, M, K1, N)
             d1 = d1.reshape(ctx.shapes[0])
         if ctx.has2 and ctx.needs_input_grad[1]:
             d2 = torch.empty(M, K2, device=dev)
