@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_blk_kernel(
     const float* __restrict__ dhout2_scale, const float* __restrict__ pre, const float* __restrict__ h, long ldh, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in, float* __restrict__ dpre,
     float* __restrict__ dh, long lddh, float* __restrict__ part, int R, int D,
-    const float* __restrict__ d2parts, int nparts, long part_stride) {
+    const float* __restrict__ d2parts, int nparts, long part_stride, int part_acc) {
   __shared__ float red[8];
   const int dv = D >> 2, N = 3 * D;
   float4 ag[3][DV], ab[3][DV];
@@ -734,8 +734,14 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_blk_kernel(
       if (j < dv) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          pg[c * dv + j] = ag[c][i];
-          pb[c * dv + j] = ab[c][i];
+          if (part_acc) {               // a scan's steps pile up in the block's own slot (fixed order: step by step)
+            const float4 g0 = pg[c * dv + j], b0 = pb[c * dv + j];
+            pg[c * dv + j] = make_float4(g0.x + ag[c][i].x, g0.y + ag[c][i].y, g0.z + ag[c][i].z, g0.w + ag[c][i].w);
+            pb[c * dv + j] = make_float4(b0.x + ab[c][i].x, b0.y + ab[c][i].y, b0.z + ab[c][i].z, b0.w + ab[c][i].w);
+          } else {
+            pg[c * dv + j] = ag[c][i];
+            pb[c * dv + j] = ab[c][i];
+          }
         }
       }
     }
@@ -898,7 +904,10 @@ long genrl_gru_ws_floats(int R, int D) { return (long)(blk_grid_for(R) + 16) * 2
 // gradient is dhout + dhout2 * dhout2_scale[row] (dhout2 / its scale may be NULL): the recurrent
 // term of a sequence scan; dhout2_parts (optional): nparts more slabs [R,D], part_stride floats apart,
 // added to dhout2 before scaling (genrl_sgemm_skinny_parts output).  `h` is the masked state used in
-// the forward (hm_out).
+// the forward (hm_out).  accumulate_params is a bit set: 1 = add to dgamma/dbeta instead of overwriting;
+// 2 = add this call's per-workgroup partial sums to the ones a previous call left in `ws` (same R, D);
+// 4 = leave the partials in `ws` and skip the reduction (dgamma/dbeta untouched) -- a T-step scan passes
+// 4, 2|4, ..., 2|4, 2 and pays for one parameter-gradient reduction instead of T.
 int genrl_gru_gates_bwd(const float* dhout, long lddo, const float* dhout2, const float* dhout2_scale,
                         const float* pre, const float* h, long ldh, const float* gamma, const float* beta,
                         const float* mean, const float* rstd, float* dpre, float* dh, long lddh, float* dgamma,
@@ -915,11 +924,13 @@ int genrl_gru_gates_bwd(const float* dhout, long lddo, const float* dhout2, cons
   hipStream_t s = (hipStream_t)stream;
   const int grid = blk_grid_for(R);
   const int dvn = cdiv(D, 1024);
-  float* part = dgamma ? ws : nullptr;
-#define GO(DV) hipLaunchKernelGGL((gru_gates_bwd_blk_kernel<DV>), dim3(grid), dim3(256), 0, s, dhout, lddo, dhout2, dhout2_scale, pre, h, ldh, gamma, beta, mean, rstd, dpre, dh, lddh, part, R, D, dhout2_parts, nparts, part_stride)
+  const int defer = accumulate_params & 4, part_acc = (accumulate_params & 2) ? 1 : 0;
+  if (defer && !ws) return GENRL_EINVAL;
+  float* part = (dgamma || defer) ? ws : nullptr;
+#define GO(DV) hipLaunchKernelGGL((gru_gates_bwd_blk_kernel<DV>), dim3(grid), dim3(256), 0, s, dhout, lddo, dhout2, dhout2_scale, pre, h, ldh, gamma, beta, mean, rstd, dpre, dh, lddh, part, R, D, dhout2_parts, nparts, part_stride, part_acc)
   if (dvn == 1) GO(1); else if (dvn == 2) GO(2); else if (dvn == 3) GO(3); else GO(4);
 #undef GO
-  if (dgamma) reduce_params(ws, ws + (long)grid * 6 * D, dgamma, dbeta, grid, 3 * D, accumulate_params, s);
+  if (dgamma && !defer) reduce_params(ws, ws + (long)grid * 6 * D, dgamma, dbeta, grid, 3 * D, accumulate_params & 1, s);
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }

@@ -1207,8 +1207,10 @@ class _GRUSeq(Function):
         dout = dout.contiguous()
         dpre = torch.empty_like(pre)
         dha = torch.empty(B, D, device=dev); dhb = torch.empty(B, D, device=dev)   # ping-pong d(hm_t)
-        gb = torch.zeros(2, 3 * D, device=dev)
-        ws = _ws(lib().genrl_gru_ws_floats(B, D), dev)
+        gb = torch.empty(2, 3 * D, device=dev)
+        # the LayerNorm parameter gradients pile up per workgroup in `ws` over the scan (accumulate_params bits
+        # 2|4) and are reduced once, by the last step (t = 0): a private buffer, not the shared scratch
+        ws = torch.empty(lib().genrl_gru_ws_floats(B, D), device=dev)
         BD, B3D = B * D, B * 3 * D
         # few sequences per GPU: the recurrent dgrad d(hm_t) += dpre_t W_h is a weight stream with only D/16
         # column blocks -> K-split into slabs that the next step's gate backward sums (no reduce launch)
@@ -1226,7 +1228,7 @@ class _GRUSeq(Function):
                          (mask.data_ptr() + 4 * (t + 1) * B) if (nxt is not None and ctx.has_mask) else None,
                          pre.data_ptr() + 4 * t * B3D, hprev.data_ptr() + 4 * hoff, gamma, beta,
                          mean.data_ptr() + 4 * t * B, rstd.data_ptr() + 4 * t * B, dpre.data_ptr() + 4 * t * B3D,
-                         cur.data_ptr(), gb[0], gb[1], ws, B, D, True,
+                         cur.data_ptr(), gb[0], gb[1], ws, B, D, (0 if t == T - 1 else 2) | (4 if t > 0 else 0),
                          pnxt.data_ptr() if (S and pnxt is not None) else None, S if pnxt is not None else 0, BD)
             if S:
                 check(lib().genrl_sgemm_skinny_parts(dpre.data_ptr() + 4 * t * B3D, 3 * D, W.data_ptr() + 4 * I, 1, K,

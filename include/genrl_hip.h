@@ -63,7 +63,10 @@ int genrl_colsum(const float* x, long ldx, float* out, float* ws, int M, int N, 
 
 /* ---- GRU gate block: GRUCell.forward after the projection (agent/dreamer_utils.py:778-785), with the
  * is_first reset of the next step's previous state (:433-434) fused as a scaled second output; the
- * backward includes the LayerNorm backward and the recurrent-gradient add of a sequence scan. */
+ * backward includes the LayerNorm backward and the recurrent-gradient add of a sequence scan.
+ * genrl_gru_gates_bwd's accumulate_params is a bit set: 1 = add to dgamma/dbeta; 2 = add this call's per-workgroup
+ * partial sums to those a previous call (same R, D) left in ws; 4 = leave the partials in ws, no reduction.  A T-step
+ * scan passes 4, 2|4, ..., 2|4, 2: one parameter-gradient reduction per scan instead of one per step. */
 int genrl_gru_gates_fwd(const float* pre, const float* h, long ldh, const float* gamma, const float* beta,
                         float* hout, long ldo, float* hout2, const float* hout2_scale, float* mean, float* rstd,
                         int R, int D, float eps, void* stream);
