@@ -825,6 +825,105 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tall products with a small resident operand: M ~ 10^6 rows, N <= 16*NB, K <= 16*KC (the 3-channel ends of the
+// image encoder / decoder: 921600x108x48, 921600x48x108, 984064x48x48).  They are streams -- 4(MK + MN) bytes
+// against a handful of MFMAs per row -- and a tiled kernel spends its time in per-tile prologues (1.5 K-steps per
+// tile).  Here every wave keeps ALL of B as MFMA fragments in registers (NB*KC*4 <= 84 VGPRs), and walks 16-row
+// blocks of A: the lane's float4 at A[row0 + lane%16][16 j + 4 (lane/16)] IS its A fragment for 4 MFMAs (same
+// k-pairing as sgemm_rr_kernel), so A goes global -> register -> MFMA with no LDS, the next block's loads are in
+// flight during the MFMAs, and C leaves as 16-byte stores (operand-swapped MFMA: a lane owns 4 consecutive
+// columns).  A k-contiguous with 16-byte aligned rows; K padding is masked in B (zero fragments), so the
+// A vector that straddles the end of a row multiplies zeros (A must be finite there: it is the next row).
+template <int NB, int KC, bool B_KC>
+__global__ __launch_bounds__(256) void sgemm_tall_kernel(const float* __restrict__ A, long a_ld,
+                                                         const float* __restrict__ B, long b_ld,
+                                                         float* __restrict__ C, long ldc,
+                                                         const float* __restrict__ bias, int M, int N, int K,
+                                                         int accumulate) {
+  const int lane = threadIdx.x & 63, l16 = lane & 15, q4 = lane >> 4;
+  const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  // ---- B fragments: fb[bj][j][e] = B(n = 16 bj + l16, k = 16 j + 4 q4 + e), zero outside N x K
+  float fb[NB][KC][4];
+#pragma unroll
+  for (int bj = 0; bj < NB; ++bj)
+#pragma unroll
+    for (int j = 0; j < KC; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = 16 * bj + l16, k = 16 * j + 4 * q4 + e;
+        const bool ok = n < N && k < K;
+        const long off = B_KC ? (long)min(n, N - 1) * b_ld + min(k, K - 1) : (long)min(k, K - 1) * b_ld + min(n, N - 1);
+        const float v = B[off];
+        fb[bj][j][e] = ok ? v : 0.f;
+      }
+  float4 bv[NB];
+#pragma unroll
+  for (int bj = 0; bj < NB; ++bj) {
+    const int col = 16 * bj + 4 * q4;
+    bv[bj].x = (bias && col + 0 < N) ? bias[col + 0] : 0.f;
+    bv[bj].y = (bias && col + 1 < N) ? bias[col + 1] : 0.f;
+    bv[bj].z = (bias && col + 2 < N) ? bias[col + 2] : 0.f;
+    bv[bj].w = (bias && col + 3 < N) ? bias[col + 3] : 0.f;
+  }
+  const long nblk = ((long)M + 15) >> 4;
+  // the last vector of the last row may start past the end of A: clamp every lane's k offset so that the 16 bytes
+  // stay inside the row when the row itself is the matrix's last (the values only meet zero B fragments)
+  const long a_last = (long)(M - 1) * a_ld + K - 4;         // last float4 start that is certainly addressable
+  auto load_a = [&](long blk, float4 (&fa)[KC]) {
+    const long row = min(blk * 16 + l16, (long)M - 1);
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      const long off = min(row * a_ld + 16 * j + 4 * q4, a_last);
+      fa[j] = *reinterpret_cast<const float4*>(A + off);
+    }
+  };
+  float4 cur[KC], nxt[KC];
+  long blk = wave_id;
+  if (blk < nblk) load_a(blk, cur);
+  for (; blk < nblk; blk += nwaves) {
+    const bool more = blk + nwaves < nblk;
+    if (more) load_a(blk + nwaves, nxt);
+    f32x4 acc[NB];
+#pragma unroll
+    for (int bj = 0; bj < NB; ++bj) acc[bj] = f32x4{bv[bj].x, bv[bj].y, bv[bj].z, bv[bj].w};
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      const float a4[4] = {cur[j].x, cur[j].y, cur[j].z, cur[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int bj = 0; bj < NB; ++bj)
+          acc[bj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[bj][j][e], a4[e], acc[bj], 0, 0, 0);
+    }
+    const long row = blk * 16 + l16;
+    if (row < M) {
+      float* crow = C + row * ldc;
+#pragma unroll
+      for (int bj = 0; bj < NB; ++bj) {
+        const int col = 16 * bj + 4 * q4;
+        if (col >= N) continue;
+        float o[4] = {acc[bj][0], acc[bj][1], acc[bj][2], acc[bj][3]};
+        if (col + 3 < N) {
+          if (accumulate) {
+            const float4 cv = *reinterpret_cast<const float4*>(crow + col);
+            o[0] += cv.x; o[1] += cv.y; o[2] += cv.z; o[3] += cv.w;
+          }
+          *reinterpret_cast<float4*>(crow + col) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            if (col + v < N) crow[col + v] = accumulate ? crow[col + v] + o[v] : o[v];
+        }
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < KC; ++j) cur[j] = nxt[j];
+    }
+  }
+}
+
 // C[m,n] = sum_s ws[s][m][n] (+bias[n]) (+C[m,n])
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, long ldc,
                                      const float* __restrict__ bias, int M, int N, int splits, int accumulate) {
@@ -987,6 +1086,10 @@ inline bool use_rr(int M, int N, int K, int splits) {
 }
 inline bool use_rr_big() {       // 128x128 products through sgemm_rr_kernel<4> (5-8 % faster than sgemm_kernel<128,128,..>);
   static const char* f = getenv("GENRL_GEMM_RR128");      // GENRL_GEMM_RR128=0 disables (calibration)
+  return !(f && f[0] == '0');
+}
+inline bool use_tall() {          // GENRL_GEMM_TALL=0 disables sgemm_tall_kernel (calibration)
+  static const char* f = getenv("GENRL_GEMM_TALL");
   return !(f && f[0] == '0');
 }
 inline bool force_mid() {       // calibration only: GENRL_GEMM_FORCE=m,<splits>
@@ -1235,6 +1338,26 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
     return GENRL_OK;
   }
 #endif
+  // tall stream with a register-resident B (see sgemm_tall_kernel)
+  if (G == 0 && a_ks == 1 && M >= 16384 && N <= 112 && K <= 112 && K >= 4 && (K & 3) == 0 && (a_rs & 3) == 0 && (ldc & 3) == 0 &&
+      ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(C)) & 15) == 0 && use_tall()) {
+    const bool b_kc = (b_ks == 1);
+    const long b_ld = b_kc ? b_rs : b_ks;
+    const int nb = cdiv(N, 16), kc = cdiv(K, 16);
+    const long nblk = cdiv(M, 16);
+    dim3 grid((unsigned)std::min<long>(cdiv(nblk, 4), 256 * 8)), block(256);
+#define GO(NBV, KCV)                                                                                                   \
+  do {                                                                                                                 \
+    if (b_kc) hipLaunchKernelGGL((sgemm_tall_kernel<NBV, KCV, true>), grid, block, 0, s, A, a_rs, B, b_ld, C, ldc, bias, M, N, K, accumulate); \
+    else hipLaunchKernelGGL((sgemm_tall_kernel<NBV, KCV, false>), grid, block, 0, s, A, a_rs, B, b_ld, C, ldc, bias, M, N, K, accumulate);    \
+    GENRL_CHECK_LAUNCH();                                                                                              \
+    return GENRL_OK;                                                                                                   \
+  } while (0)
+    if (nb <= 3 && kc <= 3) GO(3, 3);
+    else if (nb <= 7 && kc <= 3) GO(7, 3);
+    else if (nb <= 3 && kc <= 7) GO(3, 7);
+#undef GO
+  }
   SplitPlan p = plan_split(M, N, K);
   if (G == 0)
     if (const int m1 = tail_split_rows(M, N, K, p)) {

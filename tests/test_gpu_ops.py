@@ -90,6 +90,30 @@ def test_sgemm_padded_lines(ops, M, N, K):
             assert torch.equal(C[:, N:].cpu(), torch.ones(M, r4(N) - N))          # C's padding is not written
 
 
+@pytest.mark.parametrize('M,N,K', [(20000, 108, 48), (16391, 48, 108), (17000, 48, 48), (16384, 3, 48), (30001, 100, 20)])
+def test_sgemm_tall_stream(ops, M, N, K):
+    """M >= 16384 rows against a small B held in registers (sgemm_tall_kernel: the 3-channel ends of the image
+    encoder / decoder): both B layouts, ragged M and N, bias + accumulate, exact on small integers; the same
+    shapes must agree with the tiled kernels' answer on random data."""
+    A = (torch.arange(M * K, dtype=torch.float32).reshape(M, K) % 5 - 2)
+    B = ((torch.arange(N * K, dtype=torch.float32).reshape(N, K) * 3) % 7 - 3)
+    bias = torch.arange(N, dtype=torch.float32) % 3
+    want = A.double() @ B.double().T
+    ldc = (N + 3) // 4 * 4
+    for (b, brs, bks) in ((B.cuda(), K, 1), (B.T.contiguous().cuda(), 1, N)):
+        C = torch.full((M, ldc), 1.0, device='cuda')
+        ops.sgemm(A.cuda(), K, 1, b, brs, bks, C, ldc, bias.cuda(), M, N, K, accumulate=True)
+        assert torch.equal(C[:, :N].cpu().double(), want + bias.double() + 1.0), (brs, bks)
+        assert torch.equal(C[:, N:].cpu(), torch.ones(M, ldc - N))
+        C2 = torch.empty(M, ldc, device='cuda')
+        ops.sgemm(A.cuda(), K, 1, b, brs, bks, C2, ldc, None, M, N, K)
+        assert torch.equal(C2[:, :N].cpu().double(), want)
+    Ar = torch.randn(M, K, generator=g(1)); Br = torch.randn(N, K, generator=g(2))
+    C3 = torch.empty(M, ldc, device='cuda')
+    ops.sgemm(Ar.cuda(), K, 1, Br.cuda(), K, 1, C3, ldc, None, M, N, K)
+    np.testing.assert_allclose(C3[:, :N].cpu().numpy(), (Ar.double() @ Br.double().T).numpy(), rtol=1e-4, atol=1e-4 * K ** 0.5)
+
+
 @pytest.mark.parametrize('M', [1, 4, 16, 17, 32])
 @pytest.mark.parametrize('N,K', [(10, 8), (16, 520), (1000, 1034), (3072, 1024), (1024, 3073), (33, 5)])
 def test_sgemm_skinny(ops, M, N, K):
