@@ -833,16 +833,23 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
 // blocks of A: the lane's float4 at A[row0 + lane%16][16 j + 4 (lane/16)] IS its A fragment for 4 MFMAs (same
 // k-pairing as sgemm_rr_kernel), so A goes global -> register -> MFMA with no LDS, the next block's loads are in
 // flight during the MFMAs, and C leaves as 16-byte stores (operand-swapped MFMA: a lane owns 4 consecutive
-// columns).  A k-contiguous with 16-byte aligned rows; K padding is masked in B (zero fragments), so the
-// A vector that straddles the end of a row multiplies zeros (A must be finite there: it is the next row).
+// columns).  A k-contiguous with 16-byte aligned rows, K % 4 == 0; K padding is masked in B (zero fragments).
+// One workgroup per CU-resident slot (grid = 256 x waves-per-SIMD): the B fragments are loaded once per wave.
 template <int NB, int KC, bool B_KC>
 __global__ __launch_bounds__(256) void sgemm_tall_kernel(const float* __restrict__ A, long a_ld,
                                                          const float* __restrict__ B, long b_ld,
                                                          float* __restrict__ C, long ldc,
-                                                         const float* __restrict__ bias, int M, int N, int K,
-                                                         int accumulate) {
+                                                         const float* __restrict__ bias, int M, int Ntot, int K,
+                                                         int accumulate, int nslabs) {
   const int lane = threadIdx.x & 63, l16 = lane & 15, q4 = lane >> 4;
-  const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  // wider N: column slabs of 16*NB, the slab index fastest over the workgroups so that the slabs of one row range
+  // run together and share its A rows in L2
+  const int slab = blockIdx.x % nslabs;
+  const long wave_id = (long)(blockIdx.x / nslabs) * 4 + (threadIdx.x >> 6), nwaves = (long)(gridDim.x / nslabs) * 4;
+  const int N = min(16 * NB, Ntot - slab * 16 * NB);
+  B += B_KC ? (long)slab * 16 * NB * b_ld : (long)slab * 16 * NB;
+  C += slab * 16 * NB;
+  if (bias) bias += slab * 16 * NB;
   // ---- B fragments: fb[bj][j][e] = B(n = 16 bj + l16, k = 16 j + 4 q4 + e), zero outside N x K
   float fb[NB][KC][4];
 #pragma unroll
@@ -867,16 +874,15 @@ __global__ __launch_bounds__(256) void sgemm_tall_kernel(const float* __restrict
     bv[bj].w = (bias && col + 3 < N) ? bias[col + 3] : 0.f;
   }
   const long nblk = ((long)M + 15) >> 4;
-  // the last vector of the last row may start past the end of A: clamp every lane's k offset so that the 16 bytes
-  // stay inside the row when the row itself is the matrix's last (the values only meet zero B fragments)
-  const long a_last = (long)(M - 1) * a_ld + K - 4;         // last float4 start that is certainly addressable
-  auto load_a = [&](long blk, float4 (&fa)[KC]) {
-    const long row = min(blk * 16 + l16, (long)M - 1);
+  // K % 4 == 0: a lane's vector is wholly inside the row or wholly past K; the latter is pulled back to the row's
+  // last vector (addressable, finite) and only ever meets the zero B fragments above
+  int koff[KC];
 #pragma unroll
-    for (int j = 0; j < KC; ++j) {
-      const long off = min(row * a_ld + 16 * j + 4 * q4, a_last);
-      fa[j] = *reinterpret_cast<const float4*>(A + off);
-    }
+  for (int j = 0; j < KC; ++j) koff[j] = min(16 * j + 4 * q4, K - 4);
+  auto load_a = [&](long blk, float4 (&fa)[KC]) {
+    const float* ap = A + min(blk * 16 + l16, (long)M - 1) * a_ld;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) fa[j] = *reinterpret_cast<const float4*>(ap + koff[j]);
   };
   float4 cur[KC], nxt[KC];
   long blk = wave_id;
@@ -895,6 +901,20 @@ __global__ __launch_bounds__(256) void sgemm_tall_kernel(const float* __restrict
 #pragma unroll
         for (int bj = 0; bj < NB; ++bj)
           acc[bj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[bj][j][e], a4[e], acc[bj], 0, 0, 0);
+    }
+    // The next block's A fragments are claimed HERE, before this block's stores are issued: the wait then covers
+    // loads that had the whole MFMA phase to land (and the previous block's stores, a full iteration old).  Left
+    // to the first use in the next iteration, the wait sits behind the (conditional) stores and, counted
+    // conservatively, drains them: the store latency of every block was exposed (173056x1728x96: 630 -> 608 us).
+    // (Only for the MFMA-heavy shapes: with few MFMAs per block the loads have not landed yet and the early wait
+    // costs more than it saves -- 163 -> 202 us on 921600x108x48.)
+    constexpr bool CLAIM = NB * KC >= 30;
+    if (CLAIM && more) {
+#pragma unroll
+      for (int j = 0; j < KC; ++j) {
+        cur[j] = nxt[j];
+        asm volatile("" : "+v"(cur[j].x), "+v"(cur[j].y), "+v"(cur[j].z), "+v"(cur[j].w));
+      }
     }
     const long row = blk * 16 + l16;
     if (row < M) {
@@ -917,7 +937,7 @@ __global__ __launch_bounds__(256) void sgemm_tall_kernel(const float* __restrict
         }
       }
     }
-    if (more) {
+    if (!CLAIM && more) {
 #pragma unroll
       for (int j = 0; j < KC; ++j) cur[j] = nxt[j];
     }
@@ -1090,6 +1110,10 @@ inline bool use_rr_big() {       // 128x128 products through sgemm_rr_kernel<4> 
 }
 inline bool use_tall() {          // GENRL_GEMM_TALL=0 disables sgemm_tall_kernel (calibration)
   static const char* f = getenv("GENRL_GEMM_TALL");
+  return !(f && f[0] == '0');
+}
+inline bool tall_wide() {         // GENRL_GEMM_TALLW=0: no column slabs (calibration)
+  static const char* f = getenv("GENRL_GEMM_TALLW");
   return !(f && f[0] == '0');
 }
 inline bool force_mid() {       // calibration only: GENRL_GEMM_FORCE=m,<splits>
@@ -1339,23 +1363,26 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
   }
 #endif
   // tall stream with a register-resident B (see sgemm_tall_kernel)
-  if (G == 0 && a_ks == 1 && M >= 16384 && N <= 112 && K <= 112 && K >= 4 && (K & 3) == 0 && (a_rs & 3) == 0 && (ldc & 3) == 0 &&
+  if (G == 0 && a_ks == 1 && M >= 16384 && K <= 112 && K >= 4 && (K & 3) == 0 && (a_rs & 3) == 0 && (ldc & 3) == 0 &&
       ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(C)) & 15) == 0 && use_tall()) {
     const bool b_kc = (b_ks == 1);
     const long b_ld = b_kc ? b_rs : b_ks;
     const int nb = cdiv(N, 16), kc = cdiv(K, 16);
     const long nblk = cdiv(M, 16);
-    dim3 grid((unsigned)std::min<long>(cdiv(nblk, 4), 256 * 8)), block(256);
 #define GO(NBV, KCV)                                                                                                   \
   do {                                                                                                                 \
-    if (b_kc) hipLaunchKernelGGL((sgemm_tall_kernel<NBV, KCV, true>), grid, block, 0, s, A, a_rs, B, b_ld, C, ldc, bias, M, N, K, accumulate); \
-    else hipLaunchKernelGGL((sgemm_tall_kernel<NBV, KCV, false>), grid, block, 0, s, A, a_rs, B, b_ld, C, ldc, bias, M, N, K, accumulate);    \
+    const int nslabs = cdiv(N, 16 * NBV);                                                                              \
+    const long slots = 256L * (NBV * KCV <= 9 ? 3 : (NBV * KCV <= 21 ? 2 : 1));      /* resident workgroups */         \
+    dim3 grid((unsigned)(std::max<long>(std::min<long>(cdiv(nblk, 4), slots) / nslabs, 1) * nslabs)), block(256);     \
+    if (b_kc) hipLaunchKernelGGL((sgemm_tall_kernel<NBV, KCV, true>), grid, block, 0, s, A, a_rs, B, b_ld, C, ldc, bias, M, N, K, accumulate, nslabs); \
+    else hipLaunchKernelGGL((sgemm_tall_kernel<NBV, KCV, false>), grid, block, 0, s, A, a_rs, B, b_ld, C, ldc, bias, M, N, K, accumulate, nslabs);    \
     GENRL_CHECK_LAUNCH();                                                                                              \
     return GENRL_OK;                                                                                                   \
   } while (0)
     if (nb <= 3 && kc <= 3) GO(3, 3);
     else if (nb <= 7 && kc <= 3) GO(7, 3);
     else if (nb <= 3 && kc <= 7) GO(3, 7);
+    else if (kc <= 6 && !b_kc && tall_wide()) GO(7, 6);      // any N in slabs of 112 columns (K <= 96)
 #undef GO
   }
   SplitPlan p = plan_split(M, N, K);

@@ -90,7 +90,8 @@ def test_sgemm_padded_lines(ops, M, N, K):
             assert torch.equal(C[:, N:].cpu(), torch.ones(M, r4(N) - N))          # C's padding is not written
 
 
-@pytest.mark.parametrize('M,N,K', [(20000, 108, 48), (16391, 48, 108), (17000, 48, 48), (16384, 3, 48), (30001, 100, 20)])
+@pytest.mark.parametrize('M,N,K', [(20000, 108, 48), (16391, 48, 108), (17000, 48, 48), (16384, 3, 48), (30001, 100, 20),
+                                   (20000, 300, 64), (16500, 1000, 96), (16384, 113, 92)])
 def test_sgemm_tall_stream(ops, M, N, K):
     """M >= 16384 rows against a small B held in registers (sgemm_tall_kernel: the 3-channel ends of the image
     encoder / decoder): both B layouts, ragged M and N, bias + accumulate, exact on small integers; the same
