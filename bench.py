@@ -122,7 +122,9 @@ def main():
     B, T = args.batch, args.length
     torch.manual_seed(0)                         # identical random-init weights on every rank
     cfg = config.default_cfg(B // world, T, device=dev, overlap_detached=(world == 1 and not args.no_overlap))
-    ag = config.make_agent(cfg)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):   # (the agent announces its parameter counts like the reference does;
+        ag = config.make_agent(cfg)                #  stdout carries the ONE JSON line only)
     ag.wm.viclip_model = TextStub()
     full = synth_batch(B, T)
     batch = {k: v.to(dev) for k, v in dp.shard_batch({k: torch.from_numpy(v) for k, v in full.items()}, rank, world).items()}
@@ -239,7 +241,7 @@ def main():
                            'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
                            'traffic_note': 'HBM bytes per launch (read+write) from profiles/r01_pmc.json; algorithmic '
                                            f'operand bytes per launch {sum(4.0 * (p_[0] * p_[2] + p_[1] * p_[2] + p_[0] * p_[1]) for p_ in prof) / max(len(prof), 1):.3g}',
-                           'kernel': 'sgemm_rr_kernel<2|4> (+ sgemm_kernel fallback) — gemm.hip, v_mfma_f32_16x16x4_f32 / 32x32x2_f32, all instantiations',
+                           'kernel': 'sgemm_rr_kernel<2|4> + sgemm_tall_kernel (sgemm_kernel = fallback for unaligned operands) — gemm.hip, v_mfma_f32_16x16x4_f32, all instantiations',
                            'launches_per_step': len(prof), 'avg_launch_us': 1e3 * tot_ms / len(prof),
                            'gemm_gflop_per_step': tot_fl / 1e9, 'gemm_ms_per_step': tot_ms,
                            'skinny_kernel': {'launches_per_step': len(skinny), 'ms_per_step': sk_ms,
