@@ -44,7 +44,7 @@ def _grad_buf(p):
     gradient, agent/dreamer_utils.FlatGroup) — weight-gradient GEMMs accumulate straight into it
     (`accumulate=True` epilogue) instead of returning a fresh tensor for autograd to add: no extra
     allocation, no elementwise add per use of a shared weight (16 uses per imagination rollout)."""
-    if p is None or not p.is_leaf:
+    if p is None or not p.is_leaf or not p.requires_grad:      # (a frozen parameter's buffer must stay untouched)
         return None
     g = p.grad
     if g is not None and g.is_cuda and g.is_contiguous() and g.shape == p.shape:
@@ -624,9 +624,18 @@ class ActorTape:
         A2, U = self.head_w.shape
         d = self.d_raw.reshape(M, A2)
         x_last = self.y[-1]
-        dWh = torch.empty(A2, U, device=dev)
-        sgemm(d, 1, A2, x_last, 1, U, dWh, U, None, A2, U, M)
-        dbh = colsum(d)
+        # parameter gradients go straight into the optimiser's flat gradient buffers (GEMM / reduction epilogues
+        # with accumulate) when the parameters have them -- autograd then has nothing to add (one elementwise
+        # launch per parameter otherwise); the returned gradient is None for those
+        tgt = _grad_buf(self.head_w)
+        dWh = None if tgt is not None else torch.empty(A2, U, device=dev)
+        sgemm(d, 1, A2, x_last, 1, U, tgt if tgt is not None else dWh, U, None, A2, U, M, accumulate=tgt is not None)
+        tb = _grad_buf(self.head_b)
+        dbh = None
+        if tb is not None:
+            colsum(d, out=tb, accumulate=True)
+        else:
+            dbh = colsum(d)
         dy = torch.empty(M, U, device=dev)
         sgemm(d, A2, 1, self.head_w, 1, U, dy, U, None, M, U, A2)
         grads = [None] * len(self.layers)
@@ -634,24 +643,33 @@ class ActorTape:
             W, b, gamma, beta, eps = self.layers[l]
             U, K = W.shape
             dpre = torch.empty(M, U, device=dev)
-            gb = torch.empty(3, U, device=dev)
+            tg, tbe, tc = _grad_buf(gamma), _grad_buf(beta), (_grad_buf(b) if b is not None else None)
+            direct = tg is not None and tbe is not None and (b is None or tc is not None)
+            if direct:
+                g0, g1, g2, acc_p = tg, tbe, tc, 1
+            else:
+                gb = torch.empty(3, U, device=dev)
+                g0, g1, g2, acc_p = gb[0], gb[1], gb[2], 0
             ws = _ws(lib().genrl_ln_ws_floats(M, U), dev)
             check(lib().genrl_ln_act_bwd(_p(dy), U, _p(self.pre[l]), U, _p(gamma), _p(beta), _p(self.mean[l]),
-                                         _p(self.rstd[l]), _p(dpre), U, _p(gb[0]), _p(gb[1]), _p(gb[2]), _p(ws), M, U, 1, 0,
+                                         _p(self.rstd[l]), _p(dpre), U, _p(g0), _p(g1), _p(g2), _p(ws), M, U, 1, acc_p,
                                          _stream()), 'ln_act_bwd')
-            dW = torch.empty(U, K, device=dev)
+            tw = _grad_buf(W)
+            acc = tw is not None
+            dW = tw if acc else torch.empty(U, K, device=dev)
             if l > 0:
                 x = self.y[l - 1]
-                sgemm(dpre, 1, U, x, 1, K, dW, K, None, U, K, M)
+                sgemm(dpre, 1, U, x, 1, K, dW, K, None, U, K, M, accumulate=acc)
                 dy = torch.empty(M, K, device=dev)
                 sgemm(dpre, U, 1, W, 1, K, dy, K, None, M, K, U)
             else:
                 x1, x2 = self.inputs
                 K1, K2 = x1.shape[-1], x2.shape[-1]
                 assert x1.is_contiguous() and x2.is_contiguous() and x1.shape[0] >= H and K1 + K2 == K
-                sgemm(dpre, 1, U, x1, 1, K1, dW, K, None, U, K1, M)
-                sgemm(dpre, 1, U, x2, 1, K2, dW, K, None, U, K2, M, c_off=K1)
-            grads[l] = (dW, gb[2] if b is not None else None, gb[0], gb[1])
+                sgemm(dpre, 1, U, x1, 1, K1, dW, K, None, U, K1, M, accumulate=acc)
+                sgemm(dpre, 1, U, x2, 1, K2, dW, K, None, U, K2, M, c_off=K1, accumulate=acc)
+            grads[l] = (None if acc else dW, None if (direct or b is None) else g2, None if direct else g0,
+                        None if direct else g1)
         return dWh, dbh, grads
 
 
@@ -849,15 +867,23 @@ def _ln_fwd_rows(pre2d, gamma, beta, eps):
     return y, mean, rstd
 
 
-def _ln_bwd_rows(dy2d, pre2d, gamma, beta, mean, rstd):
-    """-> dpre, dgamma, dbeta, column sums of dpre (= the producing layer's bias gradient), one pass"""
+def _ln_bwd_rows(dy2d, pre2d, gamma, beta, mean, rstd, bias=None):
+    """-> dpre, dgamma, dbeta, column sums of dpre (= the producing layer's bias gradient), one pass.  When gamma,
+    beta (and the layer's `bias`) have flat gradient buffers the three sums are accumulated straight into them and
+    returned as None (nothing left for autograd to add)."""
     M, N = pre2d.shape
     dpre = torch.empty_like(pre2d)
-    gb = torch.empty(3, N, device=pre2d.device)
+    tg, tb, tc = _grad_buf(gamma), _grad_buf(beta), _grad_buf(bias)
+    direct = tg is not None and tb is not None and tc is not None
+    if direct:
+        g0, g1, g2 = tg, tb, tc
+    else:
+        gb = torch.empty(3, N, device=pre2d.device)
+        g0, g1, g2 = gb[0], gb[1], gb[2]
     ws = _ws(lib().genrl_ln_ws_floats(M, N), pre2d.device)
     check(lib().genrl_ln_act_bwd(_p(dy2d), N, _p(pre2d), N, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dpre), N,
-                                 _p(gb[0]), _p(gb[1]), _p(gb[2]), _p(ws), M, N, 1, 0, _stream()), 'ln_act_bwd')
-    return dpre, gb[0], gb[1], gb[2]
+                                 _p(g0), _p(g1), _p(g2), _p(ws), M, N, 1, int(direct), _stream()), 'ln_act_bwd')
+    return (dpre, None, None, None) if direct else (dpre, g0, g1, g2)
 
 
 def _implicit_conv(img, C):
@@ -887,6 +913,7 @@ class _Conv2dS2(Function):
             sgemm(cols, K, 1, Wp, K, 1, y, Co, b, M, Co, K)
         ctx.dims = (Nimg, Hi, Wi, C, k, u8)
         ctx.fused_ln = gamma is not None
+        ctx.bias = b
         if ctx.fused_ln:           # channel-LayerNorm + SiLU of the layer (ImgChLayerNorm + act)
             out, mean, rstd = _ln_fwd_rows(y, gamma, beta, eps)
             ctx.save_for_backward(x, Wp, y, mean, rstd, gamma, beta)
@@ -906,7 +933,7 @@ class _Conv2dS2(Function):
         dx = dW = db = dg = dbe = None
         if ctx.fused_ln:
             pre, mean, rstd, gamma, beta = ctx.saved_tensors[2:]
-            dy2, dg, dbe, db_ln = _ln_bwd_rows(dy2, pre, gamma, beta, mean, rstd)
+            dy2, dg, dbe, db_ln = _ln_bwd_rows(dy2, pre, gamma, beta, mean, rstd, ctx.bias)
         if ctx.needs_input_grad[1]:
             dW = torch.empty(Co, K, device=dy.device)
             if _implicit_conv(x, C) and Co % 4 == 0:
@@ -949,6 +976,7 @@ class _ConvT2dS2(Function):
         y = _col2im(cols, b, Nimg, Hi, Wi, Co, k)
         ctx.dims = (Nimg, Hi, Wi, Ci, Co, k)
         ctx.fused_ln = gamma is not None
+        ctx.bias = b
         if ctx.fused_ln:
             out, mean, rstd = _ln_fwd_rows(y.reshape(-1, Co), gamma, beta, eps)
             ctx.save_for_backward(x, Wp, y, mean, rstd, gamma, beta)
@@ -966,7 +994,7 @@ class _ConvT2dS2(Function):
         dg = dbe = db_ln = None
         if ctx.fused_ln:
             pre, mean, rstd, gamma, beta = ctx.saved_tensors[2:]
-            dy, dg, dbe, db_ln = _ln_bwd_rows(dy.reshape(-1, Co), pre.reshape(-1, Co), gamma, beta, mean, rstd)
+            dy, dg, dbe, db_ln = _ln_bwd_rows(dy.reshape(-1, Co), pre.reshape(-1, Co), gamma, beta, mean, rstd, ctx.bias)
             dy = dy.reshape(Nimg, Ho, Wo, Co)
         implicit = _implicit_conv(dy, Co) and Ci % 4 == 0
         dcols = None if implicit else _im2col(dy, Nimg, Ho, Wo, Co, k, 0)       # (M, Nw) patch matrix of dy
@@ -1207,9 +1235,12 @@ class _GRUSeq(Function):
         dout = dout.contiguous()
         dpre = torch.empty_like(pre)
         dha = torch.empty(B, D, device=dev); dhb = torch.empty(B, D, device=dev)   # ping-pong d(hm_t)
-        gb = torch.empty(2, 3 * D, device=dev)
         # the LayerNorm parameter gradients pile up per workgroup in `ws` over the scan (accumulate_params bits
-        # 2|4) and are reduced once, by the last step (t = 0): a private buffer, not the shared scratch
+        # 2|4) and are reduced once, by the last step (t = 0) -- straight into the flat gradient buffers when
+        # gamma / beta have them
+        tg, tb = _grad_buf(gamma), _grad_buf(beta)
+        direct = tg is not None and tb is not None
+        gb = (tg, tb) if direct else torch.empty(2, 3 * D, device=dev)
         ws = torch.empty(lib().genrl_gru_ws_floats(B, D), device=dev)
         BD, B3D = B * D, B * 3 * D
         # few sequences per GPU: the recurrent dgrad d(hm_t) += dpre_t W_h is a weight stream with only D/16
@@ -1228,7 +1259,8 @@ class _GRUSeq(Function):
                          (mask.data_ptr() + 4 * (t + 1) * B) if (nxt is not None and ctx.has_mask) else None,
                          pre.data_ptr() + 4 * t * B3D, hprev.data_ptr() + 4 * hoff, gamma, beta,
                          mean.data_ptr() + 4 * t * B, rstd.data_ptr() + 4 * t * B, dpre.data_ptr() + 4 * t * B3D,
-                         cur.data_ptr(), gb[0], gb[1], ws, B, D, (0 if t == T - 1 else 2) | (4 if t > 0 else 0),
+                         cur.data_ptr(), gb[0], gb[1], ws, B, D,
+                         (0 if t == T - 1 else 2) | (4 if t > 0 else 0) | (1 if (direct and t == 0) else 0),
                          pnxt.data_ptr() if (S and pnxt is not None) else None, S if pnxt is not None else 0, BD)
             if S:
                 check(lib().genrl_sgemm_skinny_parts(dpre.data_ptr() + 4 * t * B3D, 3 * D, W.data_ptr() + 4 * I, 1, K,
@@ -1245,12 +1277,14 @@ class _GRUSeq(Function):
             dx = torch.empty_like(x)
             sgemm(dpre, 3 * D, 1, W, 1, K, dx, I, None, T * B, I, 3 * D)
         if ctx.needs_input_grad[3]:
-            dW = torch.empty(3 * D, K, device=dev)
-            sgemm(dpre, 1, 3 * D, x, 1, I, dW, K, None, 3 * D, I, T * B)
+            tw = _grad_buf(W)
+            acc = tw is not None
+            dW = tw if acc else torch.empty(3 * D, K, device=dev)
+            sgemm(dpre, 1, 3 * D, x, 1, I, dW, K, None, 3 * D, I, T * B, accumulate=acc)
             if ctx.has_mask:
-                sgemm(dpre, 1, 3 * D, hm, 1, D, dW, K, None, 3 * D, D, T * B, c_off=I)
+                sgemm(dpre, 1, 3 * D, hm, 1, D, dW, K, None, 3 * D, D, T * B, c_off=I, accumulate=acc)
             else:   # h_{t-1} = [h0, out[:-1]]
-                sgemm(dpre, 1, 3 * D, h0, 1, D, dW, K, None, 3 * D, D, B, c_off=I)
+                sgemm(dpre, 1, 3 * D, h0, 1, D, dW, K, None, 3 * D, D, B, c_off=I, accumulate=acc)
                 if T > 1:
                     ws2 = dW.new_empty(0)
                     nws = lib().genrl_sgemm_ws_floats(3 * D, D, (T - 1) * B)
@@ -1258,9 +1292,11 @@ class _GRUSeq(Function):
                     check(lib().genrl_sgemm(dpre.data_ptr() + 4 * B3D, 1, 3 * D, out.data_ptr(), 1, D,
                                             dW.data_ptr() + 4 * I, K, None, 3 * D, D, (T - 1) * B, 1, _p(ws2), nws,
                                             _stream()), 'sgemm')
+            if acc:
+                dW = None
         if ctx.needs_input_grad[2]:
             dh0 = nxt * mask[0].unsqueeze(-1) if ctx.has_mask else nxt.clone()
-        return dx, None, dh0, dW, gb[0], gb[1]
+        return (dx, None, dh0, dW, None, None) if direct else (dx, None, dh0, dW, gb[0], gb[1])
 
 
 def gru_seq(x, mask, h0, W, gamma, beta):
