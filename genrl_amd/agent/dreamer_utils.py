@@ -537,11 +537,8 @@ class EnsembleRSSM(Module):  # ref :302-555
         lhs, rhs = (prior, post) if forward else (post, prior)
         mix = balance if forward else (1 - balance)
         l, r = lhs['logit'], rhs['logit']
-        value = value_lhs = ops.cat_kl(l, r.detach())
-        value_rhs = ops.cat_kl(l.detach(), r)
-        # max(value, free) without materialising a device scalar (no H2D copy on the hot path)
-        loss = mix * torch.clamp_min(value_lhs, free).mean() + (1 - mix) * torch.clamp_min(value_rhs, free).mean()
-        return loss, value
+        # mix * max(KL(l || sg r), free).mean() + (1 - mix) * max(KL(sg l || r), free).mean() as one autograd node
+        return ops.kl_balance(l, r, mix, free)
 
 
 # ----------------------------------------------------------------------------- optimiser

@@ -249,6 +249,31 @@ __global__ __launch_bounds__(256) void twohot_bwd_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------ balanced, free-nats KL loss
+// loss = mix * mean(max(kl, free)) + (1 - mix) * mean(max(kl, free))  (EnsembleRSSM.kl_loss, agent/dreamer_utils.py:
+// 534-555 with balance != 0.5, free_avg False: the two means are the same number, they differ in which side receives
+// the gradient).  One workgroup, fixed summation order.
+__global__ __launch_bounds__(256) void kl_balance_fwd_kernel(const float* __restrict__ kl, long R, float mix, float free_,
+                                                            float* __restrict__ loss) {
+  __shared__ float red[8];
+  float a = 0.f;
+  for (long i = threadIdx.x; i < R; i += 256) a += fmaxf(kl[i], free_);
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) {
+    const float m = a / (float)R;
+    *loss = mix * m + (1.0f - mix) * m;
+  }
+}
+// per-row upstream gradients of the two KL sides: clamp_min passes the gradient where kl >= free
+__global__ void kl_balance_bwd_kernel(const float* __restrict__ kl, const float* __restrict__ gloss, long R, float mix,
+                                      float free_, float* __restrict__ gp, float* __restrict__ gq) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  const float g = (kl[i] >= free_) ? gloss[0] / (float)R : 0.f;
+  gp[i] = mix * g;
+  gq[i] = (1.0f - mix) * g;
+}
+
 // ------------------------------------------------------------------ lambda-return scan
 // R_t = r_t + g_t*((1-lam)*v_{t+1} + lam*R_{t+1}), R_H = v_H.  reward [H,N], value [H+1,N].
 // ref: lambda_return, agent/dreamer_utils.py:228-253.  One thread per column; coalesced over N.
@@ -526,6 +551,24 @@ int genrl_cat_kl_bwd(const float* lp, const float* lq, const float* gp, const fl
     GENRL_CHECK_LAUNCH();
     return GENRL_OK;
   });
+}
+
+int genrl_kl_balance_fwd(const float* kl, long R, float mix, float free_nats, float* loss, void* stream) {
+  GENRL_ENTER();
+  if (R <= 0) return GENRL_EINVAL;
+  hipLaunchKernelGGL(kl_balance_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, kl, R, mix, free_nats, loss);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}
+
+int genrl_kl_balance_bwd(const float* kl, const float* gloss, long R, float mix, float free_nats, float* gp, float* gq,
+                         void* stream) {
+  GENRL_ENTER();
+  if (R <= 0) return GENRL_OK;
+  hipLaunchKernelGGL(kl_balance_bwd_kernel, dim3(cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, kl, gloss, R, mix,
+                     free_nats, gp, gq);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
 }
 
 int genrl_twohot_fwd(const float* logits, long ld, const float* x, const float* buckets, float* out, long R, int mode,

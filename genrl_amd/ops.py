@@ -368,6 +368,45 @@ def cat_kl(lp, lq):
     return _CatKL.apply(lp, lq)
 
 
+class _KLBalance(Function):
+    """EnsembleRSSM.kl_loss's arithmetic as one node (agent/dreamer_utils.py:534-555, balance != 0.5, free_avg False):
+    loss = mix * mean(max(KL(l || sg r), free)) + (1 - mix) * mean(max(KL(sg l || r), free)), plus the per-row KL.
+    Forward: the KL kernel + a one-workgroup clamp-mean; backward: the per-row upstream gradients of both sides
+    and ONE KL-backward launch (gp scales dl, gq scales dr) -- the elementwise formulation was ~25 launches."""
+    @staticmethod
+    def forward(ctx, l, r, mix, free):
+        l = _f32(l).contiguous(); r = _f32(r).contiguous()
+        S, K = l.shape[-2:]
+        R = l.numel() // (S * K)
+        kl = torch.empty(R, device=l.device)
+        check(lib().genrl_cat_kl_fwd(_p(l), _p(r), _p(kl), None, None, R, S, K, UNIMIX, _stream()), 'cat_kl_fwd')
+        loss = torch.empty((), device=l.device)
+        check(lib().genrl_kl_balance_fwd(_p(kl), R, mix, free, _p(loss), _stream()), 'kl_balance_fwd')
+        ctx.save_for_backward(l, r, kl)
+        ctx.mix, ctx.free = mix, free
+        value = kl.reshape(l.shape[:-2])
+        ctx.mark_non_differentiable(value)
+        return loss, value
+
+    @staticmethod
+    def backward(ctx, gloss, _gvalue):
+        l, r, kl = ctx.saved_tensors
+        S, K = l.shape[-2:]
+        R = kl.numel()
+        gp = torch.empty(R, device=l.device); gq = torch.empty(R, device=l.device)
+        check(lib().genrl_kl_balance_bwd(_p(kl), _p(gloss.contiguous()), R, ctx.mix, ctx.free, _p(gp), _p(gq), _stream()),
+              'kl_balance_bwd')
+        dl = torch.empty_like(l) if ctx.needs_input_grad[0] else None
+        dr = torch.empty_like(r) if ctx.needs_input_grad[1] else None
+        check(lib().genrl_cat_kl_bwd(_p(l), _p(r), _p(gp), _p(gq), _p(dl), _p(dr), R, S, K, UNIMIX, _stream()), 'cat_kl_bwd')
+        return dl, dr, None, None
+
+
+def kl_balance(l, r, mix, free):
+    """-> (scalar loss, per-row KL value [detached])"""
+    return _KLBalance.apply(l, r, float(mix), float(free))
+
+
 def cat_entropy(logits):
     lg = logits.detach().contiguous()
     S, K = lg.shape[-2:]

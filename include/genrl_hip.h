@@ -101,6 +101,14 @@ int genrl_cat_kl_fwd(const float* lp, const float* lq, float* kl, float* ent_p, 
 int genrl_cat_kl_bwd(const float* lp, const float* lq, const float* gp, const float* gq, float* dlp, float* dlq, long R,
                      int S, int K, float unimix, void* stream);
 
+/* The balanced free-nats loss on top of the per-row KL (EnsembleRSSM.kl_loss, agent/dreamer_utils.py:534-555, balance != 0.5,
+ * free_avg False): loss = mix*mean(max(kl,free)) + (1-mix)*mean(max(kl,free)) as one device scalar, and the per-row
+ * upstream gradients of the two sides (gp -> genrl_cat_kl_bwd's gp: the side scaled by mix; gq: by 1-mix) from the
+ * scalar gradient gloss[0]; rows with kl < free get zero. */
+int genrl_kl_balance_fwd(const float* kl, long R, float mix, float free_nats, float* loss, void* stream);
+int genrl_kl_balance_bwd(const float* kl, const float* gloss, long R, float mix, float free_nats, float* gp, float* gq,
+                         void* stream);
+
 /* ---- TwoHotDist (agent/dreamer_utils.py:120-171): mode 0 log_prob(x), mode 1 mean.  logits rows are `ld` floats
  * apart (255, or 256 for the padded rows the head's GEMMs prefer), dlogits rows `ldd`; with ldd > 255 the
  * backward also writes a zero into column 255. */

@@ -207,6 +207,24 @@ def test_onehot_and_kl(ops, R, S, K):
     np.testing.assert_allclose(ops.cat_entropy(lg.cuda()).cpu().numpy(), O.cat_entropy(lg).numpy(), rtol=1e-5)
 
 
+@pytest.mark.parametrize('forward,balance', [(False, 0.8), (True, 0.3)])
+def test_kl_balance(ops, forward, balance):
+    """The balanced free-nats KL loss as one node vs the oracle's elementwise restatement of EnsembleRSSM.kl_loss:
+    loss, per-row value and both logits' gradients, with about half the rows under the free-nats floor."""
+    R, S, K = 96, 32, 32
+    post = torch.randn(R, S, K, generator=g(1)); prior = post + 0.3 * torch.randn(R, S, K, generator=g(2))
+    kls = O.cat_kl(post, prior).sort().values
+    free = float(0.5 * (kls[R // 2 - 1] + kls[R // 2]))          # between two rows: no row sits on the clamp's kink
+    lhs, rhs = (prior, post) if forward else (post, prior)
+    mix = balance if forward else 1 - balance
+    hip = lambda a, b: ops.kl_balance(a, b, mix, free)
+    ref = lambda a, b: O.kl_loss(b, a, forward, balance, free) if forward else O.kl_loss(a, b, forward, balance, free)
+    compare(lambda a, b: hip(a, b)[0], lambda a, b: ref(a, b)[0], [lhs, rhs], rtol=1e-4, atol=1e-6)
+    v = hip(lhs.cuda(), rhs.cuda())[1]
+    assert not v.requires_grad
+    np.testing.assert_allclose(v.cpu().numpy(), O.cat_kl(lhs, rhs).numpy(), rtol=1e-4, atol=1e-5)
+
+
 def test_twohot(ops):
     lg = torch.randn(6, 5, 255, generator=g(1))
     x = torch.tensor([-30., -20., -3.3, 0., 0.5, 19.999]).reshape(6, 1, 1) * torch.tensor([1., .5, 1.7, -1., 1e-3]).reshape(1, 5, 1)
