@@ -500,16 +500,20 @@ __global__ __launch_bounds__(64 * (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1) * KG, 
 // CU and their barriers are independent.  Same operand conventions / loaders / epilogue as
 // sgemm_kernel (vector-load preconditions required).  KX: every split's K range is a whole number of
 // BK steps and no gather -> per-thread pointers that just advance, no clamps/flags/selects in the loop.
-template <int WB, bool A_KC, bool B_KC, int G, bool KX>
+template <int WB, bool A_KC, bool B_KC, int G, bool KX, int WBM = WB, int WBN = WB>
 __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
     const float* __restrict__ A, long a_ld, const float* __restrict__ B, long b_ld,
     float* __restrict__ C, long ldc, const float* __restrict__ bias, int M, int N, int Ktot,
     int accumulate, int tiles_n, int ntiles, int k_per_split, float* __restrict__ ws, int tiles_m, int xcd_m, Gather g) {
-  constexpr int BM = 32 * WB, BN = 32 * WB, BK = WB == 2 ? 64 : 32, NT = 256;
-  constexpr int NV = BM * BK / 4 / NT;                              // float4 per thread per operand (= 4)
-  constexpr int NJ = BK / 16, KV = BK / 4, RV = BM / 4;             // k-groups of 16; vectors per k-row / per tile row
+  // WB names the tile class (2: BK 64, 4: BK 32); the wave tile is 16 WBM x 16 WBN, normally WB x WB blocks.  The
+  // rectangular 96-row / 96-column variants (WBM or WBN = 3 with WB = 4) serve the conv products whose M or N is
+  // 96 or 192 channels: a 128-wide tile would waste a quarter of its MFMAs on padding there.
+  constexpr int BM = 32 * WBM, BN = 32 * WBN, BK = WB == 2 ? 64 : 32, NT = 256;
+  constexpr int NVA = BM * BK / 4 / NT, NVB = BN * BK / 4 / NT;     // float4 per thread per operand (3 or 4)
+  constexpr int NJ = BK / 16, KV = BK / 4, RVA = BM / 4, RVB = BN / 4;   // k-groups of 16; vectors per k-row / per tile row
   constexpr int PDEPTH = GENRL_RR_PD4(WB);
-  constexpr int WT = 16 * WB;                                       // wave tile edge
+  constexpr int WTM = 16 * WBM, WTN = 16 * WBN;                     // wave tile
+  static_assert(BM * BK / 4 % NT == 0 && BN * BK / 4 % NT == 0, "tile operands must split evenly over the threads");
   constexpr int LDA = A_KC ? BK + 4 : BM + 4, LDB = B_KC ? BK + 4 : BN + 4;
   constexpr int A_SZ = A_KC ? BM * LDA : BK * LDA, B_SZ = B_KC ? BN * LDB : BK * LDB;
   constexpr int T_SZ = A_SZ + B_SZ;                                 // one tile image; two of them (ping-pong)
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
     accumulate = 0;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave >> 1) * WT, wn0 = (wave & 1) * WT;
+  const int wm0 = (wave >> 1) * WTM, wn0 = (wave & 1) * WTN;
   const int l16 = lane & 15, q4 = lane >> 4;
 
   auto gbase = [&](int m) -> long {
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
   // multiple of 4 floats (launch_rr checks ld >= roundup4(extent)): the clamp keeps the address aligned, and
   // the elements past the end are masked (k-contiguous) or feed rows/columns that are never stored.
   auto gload = [&](const float* __restrict__ P, long ld, int rows_total, int r0, int k0, bool kc, float4& out, int v,
-                   bool gath) -> int {
+                   bool gath, int RV) -> int {
     int cnt;
     if (kc) {
       const int row = r0 + v / KV, k = k0 + ((v % KV) << 2);
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
     }
     return cnt;
   };
-  auto lstore = [&](float* S, int ld, bool kc, float4 val, int cnt, int v) {
+  auto lstore = [&](float* S, int ld, bool kc, float4 val, int cnt, int v, int RV) {
     if (!KX && cnt < 4) {
       val.w = 0.f;
       if (cnt < 3) val.z = 0.f;
@@ -589,30 +593,36 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
     else *reinterpret_cast<float4*>(&S[(v / RV) * ld + ((v % RV) << 2)]) = val;
   };
 
-  f32x4 acc[WB][WB];
+  f32x4 acc[WBM][WBN];
 #pragma unroll
-  for (int i = 0; i < WB; ++i)
+  for (int i = 0; i < WBM; ++i)
 #pragma unroll
-    for (int j = 0; j < WB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < WBN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // register sets of staged tiles (PDEPTH 2: tile kt+1 waits in one while tile kt+2 is in flight into the
   // other — a load then has two whole iterations to land; MALL/HBM latency exceeds one ~1 us iteration)
-  float4 ra[PDEPTH][NV], rb[PDEPTH][NV];
-  int ia[PDEPTH][NV], ib[PDEPTH][NV];          // valid elements of each staged vector (4 everywhere when KX)
+  float4 ra[PDEPTH][NVA], rb[PDEPTH][NVB];
+  int ia[PDEPTH][NVA], ib[PDEPTH][NVB];          // valid elements of each staged vector (4 everywhere when KX)
   const int nk = (K - kbeg + BK - 1) / BK;
-  const float* pa[NV];
-  const float* pb[NV];
+  const float* pa[NVA];
+  const float* pb[NVB];
   const long stepA = A_KC ? BK : (long)BK * a_ld, stepB = B_KC ? BK : (long)BK * b_ld;
   int lefta = nk, leftb = nk;              // tiles still to be fetched (scalar)
   if (KX) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
+    for (int i = 0; i < NVA; ++i) {
       const int v = tid + i * NT;
       if (A_KC) pa[i] = A + (long)min(m0 + v / KV, M - 1) * a_ld + kbeg + ((v % KV) << 2);
-      else pa[i] = A + (long)(kbeg + v / RV) * a_ld + min(m0 + ((v % RV) << 2), ((M + 3) & ~3) - 4);
-      if (B_KC) pb[i] = B + (long)min(n0 + v / KV, N - 1) * b_ld + kbeg + ((v % KV) << 2);
-      else pb[i] = B + (long)(kbeg + v / RV) * b_ld + min(n0 + ((v % RV) << 2), ((N + 3) & ~3) - 4);
+      else pa[i] = A + (long)(kbeg + v / RVA) * a_ld + min(m0 + ((v % RVA) << 2), ((M + 3) & ~3) - 4);
 #pragma unroll
-      for (int st = 0; st < PDEPTH; ++st) ia[st][i] = ib[st][i] = 4;
+      for (int st = 0; st < PDEPTH; ++st) ia[st][i] = 4;
+    }
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) {
+      const int v = tid + i * NT;
+      if (B_KC) pb[i] = B + (long)min(n0 + v / KV, N - 1) * b_ld + kbeg + ((v % KV) << 2);
+      else pb[i] = B + (long)(kbeg + v / RVB) * b_ld + min(n0 + ((v % RVB) << 2), ((N + 3) & ~3) - 4);
+#pragma unroll
+      for (int st = 0; st < PDEPTH; ++st) ib[st][i] = 4;
     }
   }
   auto nextA = [&](int st, int i) {        // KX: load the thread's i-th A vector of the next unfetched tile
@@ -626,29 +636,29 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
   auto fetch_all = [&](int st, int kt) {
     if (KX) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) nextA(st, i);
+      for (int i = 0; i < NVA; ++i) nextA(st, i);
 #pragma unroll
-      for (int i = 0; i < NV; ++i) nextB(st, i);
+      for (int i = 0; i < NVB; ++i) nextB(st, i);
       --lefta; --leftb;
       return;
     }
 #pragma unroll
-    for (int i = 0; i < NV; ++i) ia[st][i] = gload(A, a_ld, M, m0, kbeg + kt * BK, A_KC, ra[st][i], tid + i * NT, G == 1);
+    for (int i = 0; i < NVA; ++i) ia[st][i] = gload(A, a_ld, M, m0, kbeg + kt * BK, A_KC, ra[st][i], tid + i * NT, G == 1, RVA);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) ib[st][i] = gload(B, b_ld, N, n0, kbeg + kt * BK, B_KC, rb[st][i], tid + i * NT, G == 2);
+    for (int i = 0; i < NVB; ++i) ib[st][i] = gload(B, b_ld, N, n0, kbeg + kt * BK, B_KC, rb[st][i], tid + i * NT, G == 2, RVB);
   };
   // prologue: tile 0 -> LDS; tile 1 (-> set PDEPTH-1) and, with two sets, tile 2 (-> set 0) -> registers
   fetch_all(0, 0);
 #pragma unroll
-  for (int i = 0; i < NV; ++i) lstore(lds, LDA, A_KC, ra[0][i], ia[0][i], tid + i * NT);
+  for (int i = 0; i < NVA; ++i) lstore(lds, LDA, A_KC, ra[0][i], ia[0][i], tid + i * NT, RVA);
 #pragma unroll
-  for (int i = 0; i < NV; ++i) lstore(lds + A_SZ, LDB, B_KC, rb[0][i], ib[0][i], tid + i * NT);
+  for (int i = 0; i < NVB; ++i) lstore(lds + A_SZ, LDB, B_KC, rb[0][i], ib[0][i], tid + i * NT, RVB);
   fetch_all(PDEPTH - 1, 1);
   if (PDEPTH == 2) fetch_all(0, 2);
   __syncthreads();
 
   // fragments: fa[j][bi][e] = A(row = wm0 + 16 bi + lane%16, k = 16 j + 4 (lane/16) + e), same for B
-  float fa[NJ][WB][4], fb[NJ][WB][4];
+  float fa[NJ][WBM][4], fb[NJ][WBN][4];
   auto read_frag = [&](const float* S, int ld, bool kc, int w0, int j, int bi, float (&out)[4]) {
     if (kc) {
       const float4 v = *reinterpret_cast<const float4*>(&S[(w0 + 16 * bi + l16) * ld + 16 * j + 4 * q4]);
@@ -660,24 +670,24 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
   };
   auto read_frags = [&](const float* T, int j) {      // T: tile image (A part, then B part)
 #pragma unroll
-    for (int bi = 0; bi < WB; ++bi) {
-      read_frag(T, LDA, A_KC, wm0, j, bi, fa[j][bi]);
-      read_frag(T + A_SZ, LDB, B_KC, wn0, j, bi, fb[j][bi]);
-    }
-  };
-  // one "step" = the WB MFMAs of (j, e, bi) over bj; NJ*4*WB steps per iteration
-  auto step = [&](int sidx) {
-    const int bi = sidx % WB, e = (sidx / WB) % 4, j = sidx / (4 * WB);
+    for (int bi = 0; bi < WBM; ++bi) read_frag(T, LDA, A_KC, wm0, j, bi, fa[j][bi]);
 #pragma unroll
-    for (int bj = 0; bj < WB; ++bj)
+    for (int bj = 0; bj < WBN; ++bj) read_frag(T + A_SZ, LDB, B_KC, wn0, j, bj, fb[j][bj]);
+  };
+  // one "step" = the WBN MFMAs of (j, e, bi) over bj; NJ*4*WBM steps per iteration
+  auto step = [&](int sidx) {
+    const int bi = sidx % WBM, e = (sidx / WBM) % 4, j = sidx / (4 * WBM);
+#pragma unroll
+    for (int bj = 0; bj < WBN; ++bj)
 #if RR_VEC_EPI
       acc[bi][bj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][bj][e], fa[j][bi][e], acc[bi][bj], 0, 0, 0);
 #else
       acc[bi][bj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j][bi][e], fb[j][bj][e], acc[bi][bj], 0, 0, 0);
 #endif
   };
-  constexpr int NSTEP = NJ * 4 * WB, PRE = 4 * WB, LAST = RR_LAST(WB), UEVERY = WB == 2 ? 2 : 1;
-  static_assert((NSTEP - PRE - LAST) >= 2 * NV * UEVERY, "not enough MFMA steps to interleave the staging");
+  constexpr int NSTEP = NJ * 4 * WBM, PRE = 4 * WBM, UEVERY = WB == 2 ? 2 : 1, NVT = NVA + NVB;
+  constexpr int LAST = RR_LAST(WB) < NSTEP - PRE - NVT * UEVERY ? RR_LAST(WB) : NSTEP - PRE - NVT * UEVERY;
+  static_assert(LAST >= 1 && (NSTEP - PRE - LAST) >= NVT * UEVERY, "not enough MFMA steps to interleave the staging");
   read_frags(lds, 0);
   auto iteration = [&](int kt, auto ST, auto CUR) {
     constexpr int st = decltype(ST)::value;     // register set holding tile kt+1; refilled with tile kt+1+PDEPTH
@@ -688,13 +698,14 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
 #if RR_SPREAD_READS
     // (requested one (j, bi) pair at a time between the MFMA steps, so that the LDS never sees the four waves'
     // whole fragment sets at once and the wait in front of the barrier below is already satisfied)
-    constexpr int NU = (NJ - 1) * WB;
+    constexpr int WBX = WBM > WBN ? WBM : WBN, NU = (NJ - 1) * WBX;
+    static_assert(NU <= PRE, "more fragment units than MFMA steps in the first k-group");
 #pragma unroll
     for (int sidx = 0; sidx < PRE; ++sidx) {
       if (sidx < NU) {
-        const int j = 1 + sidx / WB, bi = sidx % WB;
-        read_frag(Tc, LDA, A_KC, wm0, j, bi, fa[j][bi]);
-        read_frag(Tc + A_SZ, LDB, B_KC, wn0, j, bi, fb[j][bi]);
+        const int j = 1 + sidx / WBX, bi = sidx % WBX;
+        if (bi < WBM) read_frag(Tc, LDA, A_KC, wm0, j, bi, fa[j][bi]);
+        if (bi < WBN) read_frag(Tc + A_SZ, LDB, B_KC, wn0, j, bi, fb[j][bi]);
       }
       step(sidx);
       __builtin_amdgcn_sched_barrier(0);
@@ -706,48 +717,47 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
     for (int sidx = 0; sidx < PRE; ++sidx) step(sidx);
 #endif
     if (RR_LDS_BUFS == 1) __syncthreads(); // 2. (single buffer) the LDS tile is dead: refill it behind the following MFMAs
-    // one staged vector goes to LDS after each of the first 2*NV (every UEVERY-th) steps and its registers are
+    // one staged vector goes to LDS after each of the first NVA+NVB (every UEVERY-th) steps and its registers are
     // re-armed with the load for a later tile.  Everything is unconditional (clamped addresses are always
     // valid; the final iterations stage data nobody reads): one basic block, counted waits.
     const int k2 = kbeg + (kt + 1 + PDEPTH) * BK;
 #pragma unroll
     for (int m = 0; m < NSTEP - PRE - LAST; ++m) {
       step(PRE + m);
-      if (m % UEVERY == 0 && m / UEVERY < 2 * NV) {
+      if (m % UEVERY == 0 && m / UEVERY < NVT) {
         const int u = m / UEVERY;
-        if (u < NV) {
-          lstore(Tn, LDA, A_KC, ra[st][u], ia[st][u], tid + u * NT);
+        if (u < NVA) {
+          lstore(Tn, LDA, A_KC, ra[st][u], ia[st][u], tid + u * NT, RVA);
           __builtin_amdgcn_sched_barrier(0);   // (a load hoisted over the store lands in fresh registers -> copies)
           if (KX) nextA(st, u);
-          else ia[st][u] = gload(A, a_ld, M, m0, k2, A_KC, ra[st][u], tid + u * NT, G == 1);
+          else ia[st][u] = gload(A, a_ld, M, m0, k2, A_KC, ra[st][u], tid + u * NT, G == 1, RVA);
         } else {
-          lstore(Tn + A_SZ, LDB, B_KC, rb[st][u - NV], ib[st][u - NV], tid + (u - NV) * NT);
+          lstore(Tn + A_SZ, LDB, B_KC, rb[st][u - NVA], ib[st][u - NVA], tid + (u - NVA) * NT, RVB);
           __builtin_amdgcn_sched_barrier(0);
-          if (KX) nextB(st, u - NV);
-          else ib[st][u - NV] = gload(B, b_ld, N, n0, k2, B_KC, rb[st][u - NV], tid + (u - NV) * NT, G == 2);
+          if (KX) nextB(st, u - NVA);
+          else ib[st][u - NVA] = gload(B, b_ld, N, n0, k2, B_KC, rb[st][u - NVA], tid + (u - NVA) * NT, G == 2, RVB);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (KX) { --lefta; --leftb; }
     __syncthreads();                       // 3. next tile visible: its k-group-0 fragments are requested behind
-    float na[WB][4], nb[WB][4];            //    the last MFMAs of this one
+    float na[WBM][4], nb[WBN][4];          //    the last MFMAs of this one
 #pragma unroll
-    for (int bi = 0; bi < WB; ++bi) {
-      read_frag(Tn, LDA, A_KC, wm0, 0, bi, na[bi]);
-      read_frag(Tn + A_SZ, LDB, B_KC, wn0, 0, bi, nb[bi]);
-    }
+    for (int bi = 0; bi < WBM; ++bi) read_frag(Tn, LDA, A_KC, wm0, 0, bi, na[bi]);
+#pragma unroll
+    for (int bj = 0; bj < WBN; ++bj) read_frag(Tn + A_SZ, LDB, B_KC, wn0, 0, bj, nb[bj]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int sidx = NSTEP - LAST; sidx < NSTEP; ++sidx) step(sidx);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int bi = 0; bi < WB; ++bi)
+    for (int e = 0; e < 4; ++e) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        fa[0][bi][e] = na[bi][e];
-        fb[0][bi][e] = nb[bi][e];
-      }
+      for (int bi = 0; bi < WBM; ++bi) fa[0][bi][e] = na[bi][e];
+#pragma unroll
+      for (int bj = 0; bj < WBN; ++bj) fb[0][bj][e] = nb[bj][e];
+    }
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -774,11 +784,11 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
   // 4 consecutive columns of one row and stores them with one 16-byte instruction.
   const bool vec_c = ((ldc & 3) == 0) && (((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0);
 #pragma unroll
-  for (int bi = 0; bi < WB; ++bi) {
+  for (int bi = 0; bi < WBM; ++bi) {
     const int row = m0 + wm0 + 16 * bi + l16;
     if (row >= M) continue;
 #pragma unroll
-    for (int bj = 0; bj < WB; ++bj) {
+    for (int bj = 0; bj < WBN; ++bj) {
       const int col = n0 + wn0 + 16 * bj + 4 * q4;
       if (col >= N) continue;
       float* c = C + (long)row * ldc + col;
@@ -806,9 +816,9 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
   }
 #else
 #pragma unroll
-  for (int bi = 0; bi < WB; ++bi)
+  for (int bi = 0; bi < WBM; ++bi)
 #pragma unroll
-    for (int bj = 0; bj < WB; ++bj) {
+    for (int bj = 0; bj < WBN; ++bj) {
       const int col = n0 + wn0 + 16 * bj + l16;
       if (col >= N) continue;
       const float bv = bias ? bias[col] : 0.f;
@@ -1279,14 +1289,22 @@ int launch_rr(const float* A, long a_rs, long a_ks, const float* B, long b_rs, l
   const bool fast = a_vec && b_vec && a_ok && b_ok && K >= 4 && M >= 4 && N >= 4;
   if (!fast || (G == 1 && !(a_kc && b_kc)) || (G == 2 && (a_kc || b_kc))) return -1;
   constexpr int BT = 32 * WB, BKR = WB == 2 ? 64 : 32;
-  const int tiles_m = cdiv(M, BT), tiles_n = cdiv(N, BT), ntiles = tiles_m * tiles_n;
+  // 96-wide tiles for the gathered conv products whose channel dimension is 96 / 192 (a quarter of a 128-wide
+  // tile would be padding): N side for the patch-matrix-times-weights product (G == 1), M side for the weight
+  // gradient (G == 2).  GENRL_RR_RECT=0 disables (calibration).
+  static const char* rect_env = getenv("GENRL_RR_RECT");
+  const bool rect_ok = WB == 4 && !(rect_env && rect_env[0] == '0');
+  const bool rect_n = rect_ok && G == 1 && cdiv(N, 96) * 96 < cdiv(N, 128) * 128;
+  const bool rect_m = rect_ok && G == 2 && cdiv(M, 96) * 96 < cdiv(M, 128) * 128;
+  const int BTM = rect_m ? 96 : BT, BTN = rect_n ? 96 : BT;
+  const int tiles_m = cdiv(M, BTM), tiles_n = cdiv(N, BTN), ntiles = tiles_m * tiles_n;
   int xcd_m = 0;
   {
     double best = 1e30;
     for (int xm = 1; xm <= 8; xm *= 2) {
       const int xn = 8 / xm;
       if (tiles_m % xm || tiles_n % xn) continue;
-      const double fp = (double)(tiles_m / xm) * BT + (double)(tiles_n / xn) * BT;
+      const double fp = (double)(tiles_m / xm) * BTM + (double)(tiles_n / xn) * BTN;
       if (fp < best) {
         best = fp;
         xcd_m = xm;
@@ -1300,13 +1318,19 @@ int launch_rr(const float* A, long a_rs, long a_ks, const float* B, long b_rs, l
                      accumulate, tiles_n, ntiles, kps, ws, tiles_m, xcd_m, g)
 #define GO2(AK, BKC) \
   if (kx) GO(AK, BKC, 0, true); else GO(AK, BKC, 0, false)
-  if (G == 1) GO(true, true, 1, false);
+#define GOR(AK, BKC, GG, WM, WN)                                                                                      \
+  hipLaunchKernelGGL((sgemm_rr_kernel<4, AK, BKC, GG, false, WM, WN>), grid, block, 0, s, A, a_ld, B, b_ld, C, ldc, bias, M, N, \
+                     K, accumulate, tiles_n, ntiles, kps, ws, tiles_m, xcd_m, g)
+  if (G == 1 && rect_n) GOR(true, true, 1, 4, 3);
+  else if (G == 2 && rect_m) GOR(false, false, 2, 3, 4);
+  else if (G == 1) GO(true, true, 1, false);
   else if (G == 2) GO(false, false, 2, false);
   else if (a_kc && b_kc) { GO2(true, true); }
   else if (a_kc && !b_kc) { GO2(true, false); }
   else if (!a_kc && b_kc) { GO2(false, true); }
   else { GO2(false, false); }
 #undef GO2
+#undef GOR
 #undef GO
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;

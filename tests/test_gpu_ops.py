@@ -275,7 +275,8 @@ def test_mse_maxcos_actor(ops):
 
 
 @pytest.mark.parametrize('N,Hi,C,Co,k', [(2, 16, 3, 8, 4), (3, 31, 8, 16, 4), (2, 6, 16, 32, 4), (1, 63, 4, 4, 4),
-                                         (8, 31, 48, 96, 4), (64, 14, 96, 192, 4), (2, 33, 12, 20, 5)])
+                                         (8, 31, 48, 96, 4), (64, 14, 96, 192, 4), (2, 33, 12, 20, 5),
+                                         (512, 31, 48, 96, 4)])      # (the last: 96-wide rectangular GEMM tiles, both gather sides)
 def test_conv2d_s2(ops, N, Hi, C, Co, k):
     x = torch.randn(N, C, Hi, Hi, generator=g(1)); W = torch.randn(Co, C, k, k, generator=g(2)) / (C * k * k) ** .5
     b = torch.randn(Co, generator=g(3))
@@ -304,7 +305,7 @@ def test_conv2d_s2_u8(ops):
 
 
 @pytest.mark.parametrize('N,Hi,Ci,Co,k', [(2, 1, 32, 8, 5), (2, 5, 8, 4, 5), (3, 13, 4, 6, 6), (1, 30, 6, 3, 6),
-                                          (8, 13, 96, 48, 6), (16, 5, 192, 96, 5), (3, 7, 8, 12, 6)])
+                                          (8, 13, 96, 48, 6), (16, 5, 192, 96, 5), (3, 7, 8, 12, 6), (128, 13, 96, 48, 6)])
 def test_convT2d_s2(ops, N, Hi, Ci, Co, k):
     x = torch.randn(N, Ci, Hi, Hi, generator=g(1)); W = torch.randn(Ci, Co, k, k, generator=g(2)) / (Ci * k) ** .5
     b = torch.randn(Co, generator=g(3))
