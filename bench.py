@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 (--precision 16)
 
 
 def synth_batch(B, T, A=10, img=64, seed=0):
@@ -102,9 +103,15 @@ def main():
     ap.add_argument('--input', default='replay', choices=['replay', 'fixed'],
                     help="replay: every step draws a fresh batch from the device-resident replay store "
                          "(genrl_amd/replay.py, on-GPU window gather); fixed: one batch reused")
+    ap.add_argument('--precision', type=int, default=32, choices=[32, 16],
+                    help='32 (default, the parity-pinned path) or 16: bf16 MFMA operands, fp32 accumulation/storage '
+                         '(SURVEY 8f.4; reported as its own dtype, never mixed into the fp32 headline)')
     ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
                     help='replay the iteration as captured hipGraphs (collectives stay eager between graphs)')
     args = ap.parse_args()
+    global PEAK_F32_MFMA_TFLOPS
+    if args.precision == 16:
+        PEAK_F32_MFMA_TFLOPS = PEAK_BF16_MFMA_TFLOPS   # the roofline of the bf16 mode is priced against the bf16 peak
 
     from genrl_amd import build, config, dp, ops, flops_model
     build.build(verbose=False)
@@ -121,7 +128,8 @@ def main():
 
     B, T = args.batch, args.length
     torch.manual_seed(0)                         # identical random-init weights on every rank
-    cfg = config.default_cfg(B // world, T, device=dev, overlap_detached=(world == 1 and not args.no_overlap))
+    cfg = config.default_cfg(B // world, T, device=dev, overlap_detached=(world == 1 and not args.no_overlap),
+                             precision=args.precision)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):   # (the agent announces its parameter counts like the reference does;
         ag = config.make_agent(cfg)                #  stdout carries the ONE JSON line only)
@@ -183,7 +191,8 @@ def main():
         fl = flops_model.iteration_gflop(B * T)
         out = {'metric': 'world-model+imag update steps/sec (B32xL32x64x64x3)', 'value': sps, 'unit': 'steps/s',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * dt / args.steps,
-               'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
+               'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+               'dtype': 'f32' if args.precision == 32 else 'bf16 MFMA operands, f32 accumulate and storage',
                'data': 'synthetic (seeded uint8 64x64 RGB replay, random-init weights, stub text embedding); '
                        + ('fresh batch per step gathered on-GPU from a device-resident replay store' if replay is not None
                           else 'one fixed batch'),

@@ -593,7 +593,7 @@ class Optimizer:
         assert 0 <= wd < 1
         assert not clip or 1 <= clip
         assert opt == 'adam' and wd_pattern == r'.*'
-        assert not use_amp, 'precision 16 (autocast) is a "next" row (SURVEY §8f.4); run with precision: 32'
+        self._use_amp = use_amp   # precision 16 = bf16 MFMA operands (ops.set_gemm_precision): no GradScaler, nothing to do here
         self._name, self._clip, self._wd, self._lr, self._eps = name, clip, wd, lr, eps
         self._params = list(parameters)
         self._groups = []

@@ -484,6 +484,17 @@ __global__ __launch_bounds__(64 * (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1) * KG, 
 #endif
 }
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// 4 floats -> 4 bf16 (round to nearest even; two v_cvt_pk_bf16_f32)
+__device__ __forceinline__ s16x4 bf16_pack(float a, float b, float c, float d) {
+  const bf16x2_t lo = __builtin_convertvector(f32x2_t{a, b}, bf16x2_t), hi = __builtin_convertvector(f32x2_t{c, d}, bf16x2_t);
+  const unsigned ul = __builtin_bit_cast(unsigned, lo), uh = __builtin_bit_cast(unsigned, hi);
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(s16x4, u32x2{ul, uh});
+}
+
 // ---------------------------------------------------------------------------------------------
 // Register-resident-operand kernels: 256 threads = 2x2 waves, ONE LDS buffer, MFMA 16x16x4 with
 // WB x WB independent 16x16 accumulators per wave (no dependent-issue stalls).
@@ -500,7 +511,7 @@ __global__ __launch_bounds__(64 * (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1) * KG, 
 // CU and their barriers are independent.  Same operand conventions / loaders / epilogue as
 // sgemm_kernel (vector-load preconditions required).  KX: every split's K range is a whole number of
 // BK steps and no gather -> per-thread pointers that just advance, no clamps/flags/selects in the loop.
-template <int WB, bool A_KC, bool B_KC, int G, bool KX, int WBM = WB, int WBN = WB>
+template <int WB, bool A_KC, bool B_KC, int G, bool KX, int WBM = WB, int WBN = WB, bool BF = false>
 __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
     const float* __restrict__ A, long a_ld, const float* __restrict__ B, long b_ld,
     float* __restrict__ C, long ldc, const float* __restrict__ bias, int M, int N, int Ktot,
@@ -677,6 +688,22 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
   // one "step" = the WBN MFMAs of (j, e, bi) over bj; NJ*4*WBM steps per iteration
   auto step = [&](int sidx) {
     const int bi = sidx % WBM, e = (sidx / WBM) % 4, j = sidx / (4 * WBM);
+    if (BF) {
+      // bf16 mode (precision 16): the lane's 4 consecutive k of each operand, rounded to bf16 (RNE), are ONE
+      // v_mfma_f32_16x16x16_bf16 (fp32 accumulate) in place of the four fp32 16x16x4 MFMAs of e = 0..3
+      if (e != 0) return;
+      const s16x4 ah = bf16_pack(fa[j][bi][0], fa[j][bi][1], fa[j][bi][2], fa[j][bi][3]);
+#pragma unroll
+      for (int bj = 0; bj < WBN; ++bj) {
+        const s16x4 bh = bf16_pack(fb[j][bj][0], fb[j][bj][1], fb[j][bj][2], fb[j][bj][3]);
+#if RR_VEC_EPI
+        acc[bi][bj] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh, ah, acc[bi][bj], 0, 0, 0);
+#else
+        acc[bi][bj] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, acc[bi][bj], 0, 0, 0);
+#endif
+      }
+      return;
+    }
 #pragma unroll
     for (int bj = 0; bj < WBN; ++bj)
 #if RR_VEC_EPI
@@ -1266,6 +1293,10 @@ int launch_cfg(const float* A, long a_rs, long a_ks, const float* B, long b_rs, 
 }
 
 // launch the register-resident-operand 64x64 kernel (FAST preconditions hold; returns -1 if they do not)
+// 0 = fp32 MFMA (default), 1 = bf16 MFMA inputs with fp32 accumulation for the sgemm_rr_kernel products
+// (genrl_set_gemm_precision; the reference's precision-16 autocast mode)
+static int g_gemm_bf16 = 0;
+
 template <int WB>
 int launch_rr(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks, float* C, long ldc,
               const float* bias, int M, int N, int K, int accumulate, int splits, int kps, float* ws, hipStream_t s,
@@ -1314,13 +1345,25 @@ int launch_rr(const float* A, long a_rs, long a_ks, const float* B, long b_rs, l
   dim3 grid(ntiles, splits), block(256);
   const bool kx = !G && (K % BKR == 0) && (kps % BKR == 0) && M >= 4 && N >= 4;
 #define GO(AK, BKC, GG, KXV)                                                                                        \
-  hipLaunchKernelGGL((sgemm_rr_kernel<WB, AK, BKC, GG, KXV>), grid, block, 0, s, A, a_ld, B, b_ld, C, ldc, bias, M, N, K, \
-                     accumulate, tiles_n, ntiles, kps, ws, tiles_m, xcd_m, g)
+  do {                                                                                                              \
+    if (g_gemm_bf16)                                                                                                \
+      hipLaunchKernelGGL((sgemm_rr_kernel<WB, AK, BKC, GG, KXV, WB, WB, true>), grid, block, 0, s, A, a_ld, B, b_ld, C, ldc, bias, \
+                         M, N, K, accumulate, tiles_n, ntiles, kps, ws, tiles_m, xcd_m, g);                         \
+    else                                                                                                            \
+      hipLaunchKernelGGL((sgemm_rr_kernel<WB, AK, BKC, GG, KXV>), grid, block, 0, s, A, a_ld, B, b_ld, C, ldc, bias, M, N, K, \
+                         accumulate, tiles_n, ntiles, kps, ws, tiles_m, xcd_m, g);                                  \
+  } while (0)
 #define GO2(AK, BKC) \
-  if (kx) GO(AK, BKC, 0, true); else GO(AK, BKC, 0, false)
+  do { if (kx) GO(AK, BKC, 0, true); else GO(AK, BKC, 0, false); } while (0)
 #define GOR(AK, BKC, GG, WM, WN)                                                                                      \
-  hipLaunchKernelGGL((sgemm_rr_kernel<4, AK, BKC, GG, false, WM, WN>), grid, block, 0, s, A, a_ld, B, b_ld, C, ldc, bias, M, N, \
-                     K, accumulate, tiles_n, ntiles, kps, ws, tiles_m, xcd_m, g)
+  do {                                                                                                              \
+    if (g_gemm_bf16)                                                                                                \
+      hipLaunchKernelGGL((sgemm_rr_kernel<4, AK, BKC, GG, false, WM, WN, true>), grid, block, 0, s, A, a_ld, B, b_ld, C, ldc, bias, \
+                         M, N, K, accumulate, tiles_n, ntiles, kps, ws, tiles_m, xcd_m, g);                         \
+    else                                                                                                            \
+      hipLaunchKernelGGL((sgemm_rr_kernel<4, AK, BKC, GG, false, WM, WN>), grid, block, 0, s, A, a_ld, B, b_ld, C, ldc, bias, M, N, \
+                         K, accumulate, tiles_n, ntiles, kps, ws, tiles_m, xcd_m, g);                               \
+  } while (0)
   if (G == 1 && rect_n) GOR(true, true, 1, 4, 3);
   else if (G == 2 && rect_m) GOR(false, false, 2, 3, 4);
   else if (G == 1) GO(true, true, 1, false);
@@ -1446,6 +1489,12 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(MN, 256)), dim3(256), 0, s, ws, C, ldc, bias, M, N, p.splits, accumulate);
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
+}
+
+extern "C" int genrl_set_gemm_precision(int bf16) {
+  const int prev = g_gemm_bf16;
+  g_gemm_bf16 = bf16 ? 1 : 0;
+  return prev;
 }
 
 extern "C" int genrl_sgemm(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks,

@@ -26,6 +26,13 @@ def _p(t):
     return t.data_ptr()
 
 
+def set_gemm_precision(mode):
+    """'f32' (default) or 'bf16': MFMA operands rounded to bf16, fp32 accumulation, fp32 tensors (the reference's
+    `precision: 16` mode).  Process-wide; returns the previous mode."""
+    assert mode in ('f32', 'bf16'), mode
+    return 'bf16' if lib().genrl_set_gemm_precision(int(mode == 'bf16')) else 'f32'
+
+
 def _prows(t):
     """pointer of a 2-D operand whose rows are evenly spaced (unit column stride); the callee gets the spacing"""
     if not t.is_cuda:

@@ -246,3 +246,24 @@ def test_c2_full_size_vs_oracle_and_determinism():
         np.testing.assert_allclose(a, b, rtol=1e-3, err_msg=ph)
     _, _, _, _, _, _, _, mets_wm2, mets2, _ = run_product(meta, True, {}, {})
     assert mets_wm2 == mets_wm and mets2 == mets, 'HIP path is not run-to-run deterministic'
+
+
+def test_precision16_bf16_mode_tracks_fp32():
+    """cfg.precision = 16 (the reference's autocast mode; here: bf16 MFMA operands, fp32 accumulation and storage,
+    SURVEY 8f.4): one full-size-layer iteration at B4xT16 on the same weights / batch / injected noise must stay
+    within a few 1e-2 relative of the fp32 path's losses -- and must not be bit-identical to it (the mode is on).
+    Parity of this mode against the reference is NOT pinned: the reference's fp16 autocast only exists on CUDA."""
+    from genrl_amd import ops
+    meta = {'meta': (4, 16, 10, 32, 32, 16, 5), 'img': 64}
+    try:
+        _, _, _, _, _, _, _, w32, m32, _ = run_product(meta, True, {}, {})
+        _, _, _, _, _, _, _, w16, m16, _ = run_product(meta, True, dict(precision=16), {})
+    finally:
+        ops.set_gemm_precision('f32')
+    assert w16['model_loss'] != w32['model_loss']
+    for k in ('model_loss', 'observation_loss', 'reward_loss', 'kl_loss', 'model_kl'):
+        np.testing.assert_allclose(w16[k], w32[k], rtol=3e-2, err_msg=k)
+    later = [k for k in m32 if k.endswith(('critic_loss', 'connector_kl', 'aligner_loss')) and np.isfinite(m32[k])]
+    assert later, sorted(m32)
+    for k in later:          # phases downstream of the (sampled) world-model state: looser
+        np.testing.assert_allclose(m16[k], m32[k], rtol=1e-1, atol=1e-3, err_msg=k)

@@ -90,6 +90,28 @@ def test_sgemm_padded_lines(ops, M, N, K):
             assert torch.equal(C[:, N:].cpu(), torch.ones(M, r4(N) - N))          # C's padding is not written
 
 
+@pytest.mark.parametrize('M,N,K,lay', [(1024, 1024, 1024, 'kk'), (1024, 768, 2048, 'kr'), (4096, 1024, 512, 'rr'),
+                                       (16384, 1024, 1024, 'kk'), (300, 200, 260, 'kk'), (96, 1728, 40000, 'rr')])
+def test_sgemm_bf16_mode(ops, M, N, K, lay):
+    """precision 16: the MFMA operands are rounded to bf16 (nearest even), products and sums stay fp32 -- so the
+    result must equal the fp32 product of the bf16-rounded operands up to summation order, and differ from the
+    fp32-mode result by bf16 rounding (~1e-2 relative of the operand scale)."""
+    A = torch.randn(M, K, generator=g(1)); B = torch.randn(N, K, generator=g(2))
+    a, ars, aks = (A.cuda(), K, 1) if lay[0] == 'k' else (A.T.contiguous().cuda(), 1, M)
+    b, brs, bks = (B.cuda(), K, 1) if lay[1] == 'k' else (B.T.contiguous().cuda(), 1, N)
+    C32 = torch.empty(M, N, device='cuda'); C16 = torch.empty(M, N, device='cuda')
+    ops.sgemm(a, ars, aks, b, brs, bks, C32, N, None, M, N, K)
+    prev = ops.set_gemm_precision('bf16')
+    try:
+        ops.sgemm(a, ars, aks, b, brs, bks, C16, N, None, M, N, K)
+    finally:
+        ops.set_gemm_precision(prev)
+    want = (A.bfloat16().double() @ B.bfloat16().double().T)
+    np.testing.assert_allclose(C16.cpu().double().numpy(), want.numpy(), rtol=1e-4, atol=2e-5 * K ** 0.5)
+    err = (C16 - C32).abs().max().item()
+    assert 1e-4 * K ** 0.5 < err < 3e-2 * K ** 0.5, err           # really a different (bf16) rounding, of the expected size
+
+
 @pytest.mark.parametrize('M,N,K', [(20000, 108, 48), (16391, 48, 108), (17000, 48, 48), (16384, 3, 48), (30001, 100, 20),
                                    (20000, 300, 64), (16500, 1000, 96), (16384, 113, 92)])
 def test_sgemm_tall_stream(ops, M, N, K):
