@@ -39,7 +39,7 @@ class DreamerAgent(Module):
         # precision 16 (the reference wraps its forward passes in fp16 autocast + GradScaler, agent/dreamer.py:38,
         # dreamer_utils.py:889-932): here the MFMA GEMMs round their operands to bf16 and accumulate in fp32, every
         # tensor stays fp32, and no scaler is needed (bf16 keeps fp32's exponent range).  Process-wide switch.
-        ops.set_gemm_precision('bf16' if self._use_amp else 'f32')
+        ops.set_gemm_precision('bf16' if self._use_amp else ops.F32_MODE)
         self.wm = WorldModel(cfg, obs_space, self.act_dim)
         self.instantiate_acting_behavior()
         self.to(self.device)

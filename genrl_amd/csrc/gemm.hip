@@ -484,6 +484,7 @@ __global__ __launch_bounds__(64 * (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1) * KG, 
 #endif
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -493,6 +494,32 @@ __device__ __forceinline__ s16x4 bf16_pack(float a, float b, float c, float d) {
   const unsigned ul = __builtin_bit_cast(unsigned, lo), uh = __builtin_bit_cast(unsigned, hi);
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   return __builtin_bit_cast(s16x4, u32x2{ul, uh});
+}
+
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+// The 8-element bf16 MFMA operand(s) of two 4-float fragments x (elements 0..3) and y (4..7).  NT = 1: rounded to
+// bf16; NT = 3: out[0..2] = h, m, l with x = h + m + l exactly (nearest-even at each level, exact fp32 residuals).
+template <int NT>
+__device__ __forceinline__ void bf16_terms(const float (&x)[4], const float (&y)[4], s16x8 (&out)[NT]) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  float r[8] = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const s16x4 p = bf16_pack(r[0], r[1], r[2], r[3]), q = bf16_pack(r[4], r[5], r[6], r[7]);
+    out[t] = __builtin_shufflevector(p, q, 0, 1, 2, 3, 4, 5, 6, 7);
+    if (t + 1 < NT) {
+      const u32x2 u = __builtin_bit_cast(u32x2, p), v = __builtin_bit_cast(u32x2, q);
+      r[0] -= __builtin_bit_cast(float, u[0] << 16);
+      r[1] -= __builtin_bit_cast(float, u[0] & 0xFFFF0000u);
+      r[2] -= __builtin_bit_cast(float, u[1] << 16);
+      r[3] -= __builtin_bit_cast(float, u[1] & 0xFFFF0000u);
+      r[4] -= __builtin_bit_cast(float, v[0] << 16);
+      r[5] -= __builtin_bit_cast(float, v[0] & 0xFFFF0000u);
+      r[6] -= __builtin_bit_cast(float, v[1] << 16);
+      r[7] -= __builtin_bit_cast(float, v[1] & 0xFFFF0000u);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -511,7 +538,7 @@ __device__ __forceinline__ s16x4 bf16_pack(float a, float b, float c, float d) {
 // CU and their barriers are independent.  Same operand conventions / loaders / epilogue as
 // sgemm_kernel (vector-load preconditions required).  KX: every split's K range is a whole number of
 // BK steps and no gather -> per-thread pointers that just advance, no clamps/flags/selects in the loop.
-template <int WB, bool A_KC, bool B_KC, int G, bool KX, int WBM = WB, int WBN = WB, bool BF = false>
+template <int WB, bool A_KC, bool B_KC, int G, bool KX, int WBM = WB, int WBN = WB, int BF = 0>
 __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
     const float* __restrict__ A, long a_ld, const float* __restrict__ B, long b_ld,
     float* __restrict__ C, long ldc, const float* __restrict__ bias, int M, int N, int Ktot,
@@ -609,6 +636,18 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
   for (int i = 0; i < WBM; ++i)
 #pragma unroll
     for (int j = 0; j < WBN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // (BF == 3) 32x32 blocks; with a single block per wave three accumulators take the products in turn, so that
+  // consecutive MFMAs do not form one dependent chain
+  constexpr int MB32 = BF == 3 ? WBM / 2 : 1, NB32 = BF == 3 ? WBN / 2 : 1, NACC = (BF == 3 && MB32 * NB32 == 1) ? 3 : 1;
+  f32x16 acc32[NACC][MB32][NB32];
+#pragma unroll
+  for (int c = 0; c < NACC; ++c)
+#pragma unroll
+    for (int i = 0; i < MB32; ++i)
+#pragma unroll
+      for (int j = 0; j < NB32; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc32[c][i][j][r] = 0.f;
   // register sets of staged tiles (PDEPTH 2: tile kt+1 waits in one while tile kt+2 is in flight into the
   // other — a load then has two whole iterations to land; MALL/HBM latency exceeds one ~1 us iteration)
   float4 ra[PDEPTH][NVA], rb[PDEPTH][NVB];
@@ -668,9 +707,25 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
   if (PDEPTH == 2) fetch_all(0, 2);
   __syncthreads();
 
-  // fragments: fa[j][bi][e] = A(row = wm0 + 16 bi + lane%16, k = 16 j + 4 (lane/16) + e), same for B
+  // fragments: fa[j][bi][e] = A(row = wm0 + 16 bi + lane%16, k = 16 j + 4 (lane/16) + e), same for B.
+  // B32 (BF == 3, 32x32x16 MFMA blocks): the SAME slots hold the lane's 8 k-values of a 32-row block in two halves:
+  // slot bi = 2 mb + half  ->  A(row = wm0 + 32 mb + lane%32, k = 16 j + 8 (lane/32) + 4 half + e)
+  constexpr bool B32 = BF == 3;
+  static_assert(!B32 || (WBM % 2 == 0 && WBN % 2 == 0), "32x32 blocks need even 16-block counts");
+  const int l32 = lane & 31, h32 = lane >> 5;
   float fa[NJ][WBM][4], fb[NJ][WBN][4];
   auto read_frag = [&](const float* S, int ld, bool kc, int w0, int j, int bi, float (&out)[4]) {
+    if (B32) {
+      const int row = w0 + 32 * (bi >> 1) + l32, kk = 16 * j + 8 * h32 + 4 * (bi & 1);
+      if (kc) {
+        const float4 v = *reinterpret_cast<const float4*>(&S[row * ld + kk]);
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = S[(kk + e) * ld + row];
+      }
+      return;
+    }
     if (kc) {
       const float4 v = *reinterpret_cast<const float4*>(&S[(w0 + 16 * bi + l16) * ld + 16 * j + 4 * q4]);
       out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
@@ -685,23 +740,69 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
 #pragma unroll
     for (int bj = 0; bj < WBN; ++bj) read_frag(T + A_SZ, LDB, B_KC, wn0, j, bj, fb[j][bj]);
   };
+  s16x8 b3c[BF != 0 ? WBN : 1][BF == 3 ? 3 : 1];   // (bf16 modes) converted B fragments of the current k-pair
   // one "step" = the WBN MFMAs of (j, e, bi) over bj; NJ*4*WBM steps per iteration
   auto step = [&](int sidx) {
     const int bi = sidx % WBM, e = (sidx / WBM) % 4, j = sidx / (4 * WBM);
-    if (BF) {
-      // bf16 mode (precision 16): the lane's 4 consecutive k of each operand, rounded to bf16 (RNE), are ONE
-      // v_mfma_f32_16x16x16_bf16 (fp32 accumulate) in place of the four fp32 16x16x4 MFMAs of e = 0..3
-      if (e != 0) return;
-      const s16x4 ah = bf16_pack(fa[j][bi][0], fa[j][bi][1], fa[j][bi][2], fa[j][bi][3]);
+    if constexpr (BF == 3) {
+      // fp32 through the bf16 matrix cores at their full rate (v_mfma_f32_32x32x16_bf16: 2.1 PFLOP/s measured against
+      // 1.3 for the 16x16x32 shape, scripts/micro).  Every operand element is split EXACTLY into three bf16 terms
+      // a = h + m + l (8 + 8 + 8 mantissa bits; the residuals a - h and a - h - m are exact in fp32) and the product
+      // is the six largest of the nine cross terms (hh, hm, mh, hl, lh, mm; the dropped ones are <= 2^-24 |a||b|, one
+      // fp32 rounding), small terms first, each an MFMA with fp32 accumulation: 6 x 32 cycles per 32x32x16 block
+      // product where the fp32 MFMAs take 512.
+      if (e != 0 || bi != 0) return;       // the whole k-group at its first slot
+      s16x8 a3[MB32][3];
 #pragma unroll
-      for (int bj = 0; bj < WBN; ++bj) {
-        const s16x4 bh = bf16_pack(fb[j][bj][0], fb[j][bj][1], fb[j][bj][2], fb[j][bj][3]);
-#if RR_VEC_EPI
-        acc[bi][bj] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh, ah, acc[bi][bj], 0, 0, 0);
-#else
-        acc[bi][bj] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, acc[bi][bj], 0, 0, 0);
-#endif
+      for (int nb = 0; nb < NB32; ++nb) bf16_terms<3>(fb[j][2 * nb], fb[j][2 * nb + 1], b3c[nb]);
+#pragma unroll
+      for (int mb = 0; mb < MB32; ++mb) bf16_terms<3>(fa[j][2 * mb], fa[j][2 * mb + 1], a3[mb]);
+      // term-major round robin over the MB32 x NB32 (x NACC) accumulators: consecutive MFMAs never share one, and
+      // the order is pinned (left alone, the scheduler regroups them into one dependent chain per accumulator)
+      constexpr int TX[6] = {2, 0, 1, 1, 0, 0}, TY[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+#pragma unroll
+        for (int mb = 0; mb < MB32; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB32; ++nb) {
+            f32x16& c = acc32[t % NACC][mb][nb];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, b3c[nb][TY[t]]),
+                                                        __builtin_bit_cast(bf16x8_t, a3[mb][TX[t]]), c, 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
+      return;
+    }
+    if constexpr (BF != 0) {
+      // bf16 matrix cores, v_mfma_f32_16x16x32_bf16 (the full-rate bf16 shape of gfx950): the lane's 4 consecutive k
+      // of TWO k-groups (j-1, j) of each operand form its 8-element operand -- any k permutation is fine as long as
+      // both operands use the same one -- so the MFMAs of a pair of k-groups are issued at the odd group's e = 0 steps.
+      //  BF == 1 (precision 16): operands rounded to bf16 (RNE), fp32 accumulate: one MFMA per block and k-pair.
+      //  BF == 3: fp32 through the bf16 cores.  Every element is split EXACTLY into three bf16 terms
+      //    a = h + m + l (8 + 8 + 8 mantissa bits; the residuals a - h and a - h - m are exact in fp32) and the
+      //    product is the six largest of the nine cross terms (hh, hm, mh, hl, lh, mm; the dropped ones are
+      //    <= 2^-24 |a||b|, one fp32 rounding), small terms first, term-major over the WBN independent accumulators.
+      if (e != 0 || (j & 1) == 0) return;
+      constexpr int NT3 = BF == 3 ? 3 : 1;
+      if (bi == 0) {                       // the B fragments of this k-pair are converted once, for all bi
+#pragma unroll
+        for (int bj = 0; bj < WBN; ++bj) bf16_terms<NT3>(fb[j - 1][bj], fb[j][bj], b3c[bj]);
+      }
+      s16x8 a3[NT3];
+      bf16_terms<NT3>(fa[j - 1][bi], fa[j][bi], a3);
+      constexpr int TX[6] = {2, 0, 1, 1, 0, 0}, TY[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int t = (BF == 3 ? 0 : 5); t < 6; ++t)
+#pragma unroll
+        for (int bj = 0; bj < WBN; ++bj)
+#if RR_VEC_EPI
+          acc[bi][bj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b3c[bj][TY[t]]),
+                                                                __builtin_bit_cast(bf16x8_t, a3[TX[t]]), acc[bi][bj], 0, 0, 0);
+#else
+          acc[bi][bj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a3[TX[t]]),
+                                                                __builtin_bit_cast(bf16x8_t, b3c[bj][TY[t]]), acc[bi][bj], 0, 0, 0);
+#endif
       return;
     }
 #pragma unroll
@@ -805,6 +906,50 @@ __global__ __launch_bounds__(256, 2) void sgemm_rr_kernel(
   }
 #endif
 
+  if constexpr (BF == 3) {
+    // 32x32 blocks, operands swapped: lane (l32, h32), register v = C[row = l32][col = 8 (v/4) + 4 h32 + v%4]
+    const bool vec_c32 = ((ldc & 3) == 0) && (((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0);
+#pragma unroll
+    for (int mb = 0; mb < MB32; ++mb) {
+      const int row = m0 + wm0 + 32 * mb + l32;
+      if (row >= M) continue;
+#pragma unroll
+      for (int nb = 0; nb < NB32; ++nb)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int col = n0 + wn0 + 32 * nb + 8 * gq + 4 * h32;
+          if (col >= N) continue;
+          float o[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            o[v] = acc32[0][mb][nb][4 * gq + v];
+#pragma unroll
+            for (int c2 = 1; c2 < NACC; ++c2) o[v] += acc32[c2][mb][nb][4 * gq + v];
+          }
+          float* c = C + (long)row * ldc + col;
+          if (vec_c32 && col + 3 < N) {
+            if (bias) {
+              const float4 bv = *reinterpret_cast<const float4*>(bias + col);
+              o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+            }
+            if (accumulate) {
+              const float4 cv = *reinterpret_cast<const float4*>(c);
+              o[0] += cv.x; o[1] += cv.y; o[2] += cv.z; o[3] += cv.w;
+            }
+            *reinterpret_cast<float4*>(c) = make_float4(o[0], o[1], o[2], o[3]);
+          } else {
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+              if (col + v < N) {
+                float val = o[v] + (bias ? bias[col + v] : 0.f);
+                if (accumulate) val += c[v];
+                c[v] = val;
+              }
+          }
+        }
+    }
+    return;
+  }
 #if RR_VEC_EPI
   // ---- epilogue.  The MFMAs are issued with the operands swapped (B fragment first), so a 16x16 block holds
   // its TRANSPOSE in the D layout: lane (l16, q4), register v = C[row = l16][col = 4*q4 + v] -> every lane owns
@@ -1295,7 +1440,13 @@ int launch_cfg(const float* A, long a_rs, long a_ks, const float* B, long b_rs, 
 // launch the register-resident-operand 64x64 kernel (FAST preconditions hold; returns -1 if they do not)
 // 0 = fp32 MFMA (default), 1 = bf16 MFMA inputs with fp32 accumulation for the sgemm_rr_kernel products
 // (genrl_set_gemm_precision; the reference's precision-16 autocast mode)
-static int g_gemm_bf16 = 0;
+static int initial_gemm_mode() {
+  // 0 fp32 MFMA everywhere, 1 bf16 operands (precision 16), 2 (default) fp32 with the bf16x3 split on the 128x128 tile,
+  // 3 split on every tile
+  const char* f = getenv("GENRL_GEMM_MODE");
+  return (f && f[0] >= '0' && f[0] <= '3') ? f[0] - '0' : 2;
+}
+static int g_gemm_bf16 = initial_gemm_mode();
 
 template <int WB>
 int launch_rr(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks, float* C, long ldc,
@@ -1324,7 +1475,10 @@ int launch_rr(const float* A, long a_rs, long a_ks, const float* B, long b_rs, l
   // tile would be padding): N side for the patch-matrix-times-weights product (G == 1), M side for the weight
   // gradient (G == 2).  GENRL_RR_RECT=0 disables (calibration).
   static const char* rect_env = getenv("GENRL_RR_RECT");
-  const bool rect_ok = WB == 4 && !(rect_env && rect_env[0] == '0');
+  // mode 2 ("split on the big tile"): bf16x3 for the 128x128 tile only, fp32 MFMA for the 64x64 tile (where the
+  // operand split costs more VALU time than the bf16 cores save)
+  const int mode = g_gemm_bf16 == 2 ? (WB == 4 ? 3 : 0) : g_gemm_bf16;
+  const bool rect_ok = WB == 4 && g_gemm_bf16 != 3 && !(rect_env && rect_env[0] == '0');   // (32x32 blocks need even counts; in mode 2 the 96-wide tiles stay fp32 MFMA)
   const bool rect_n = rect_ok && G == 1 && cdiv(N, 96) * 96 < cdiv(N, 128) * 128;
   const bool rect_m = rect_ok && G == 2 && cdiv(M, 96) * 96 < cdiv(M, 128) * 128;
   const int BTM = rect_m ? 96 : BT, BTN = rect_n ? 96 : BT;
@@ -1346,8 +1500,11 @@ int launch_rr(const float* A, long a_rs, long a_ks, const float* B, long b_rs, l
   const bool kx = !G && (K % BKR == 0) && (kps % BKR == 0) && M >= 4 && N >= 4;
 #define GO(AK, BKC, GG, KXV)                                                                                        \
   do {                                                                                                              \
-    if (g_gemm_bf16)                                                                                                \
-      hipLaunchKernelGGL((sgemm_rr_kernel<WB, AK, BKC, GG, KXV, WB, WB, true>), grid, block, 0, s, A, a_ld, B, b_ld, C, ldc, bias, \
+    if (mode == 1)                                                                                                  \
+      hipLaunchKernelGGL((sgemm_rr_kernel<WB, AK, BKC, GG, KXV, WB, WB, 1>), grid, block, 0, s, A, a_ld, B, b_ld, C, ldc, bias, \
+                         M, N, K, accumulate, tiles_n, ntiles, kps, ws, tiles_m, xcd_m, g);                         \
+    else if (mode == 3)                                                                                             \
+      hipLaunchKernelGGL((sgemm_rr_kernel<WB, AK, BKC, GG, KXV, WB, WB, 3>), grid, block, 0, s, A, a_ld, B, b_ld, C, ldc, bias, \
                          M, N, K, accumulate, tiles_n, ntiles, kps, ws, tiles_m, xcd_m, g);                         \
     else                                                                                                            \
       hipLaunchKernelGGL((sgemm_rr_kernel<WB, AK, BKC, GG, KXV>), grid, block, 0, s, A, a_ld, B, b_ld, C, ldc, bias, M, N, K, \
@@ -1357,8 +1514,8 @@ int launch_rr(const float* A, long a_rs, long a_ks, const float* B, long b_rs, l
   do { if (kx) GO(AK, BKC, 0, true); else GO(AK, BKC, 0, false); } while (0)
 #define GOR(AK, BKC, GG, WM, WN)                                                                                      \
   do {                                                                                                              \
-    if (g_gemm_bf16)                                                                                                \
-      hipLaunchKernelGGL((sgemm_rr_kernel<4, AK, BKC, GG, false, WM, WN, true>), grid, block, 0, s, A, a_ld, B, b_ld, C, ldc, bias, \
+    if (mode == 1)                                                                                                  \
+      hipLaunchKernelGGL((sgemm_rr_kernel<4, AK, BKC, GG, false, WM, WN, 1>), grid, block, 0, s, A, a_ld, B, b_ld, C, ldc, bias, \
                          M, N, K, accumulate, tiles_n, ntiles, kps, ws, tiles_m, xcd_m, g);                         \
     else                                                                                                            \
       hipLaunchKernelGGL((sgemm_rr_kernel<4, AK, BKC, GG, false, WM, WN>), grid, block, 0, s, A, a_ld, B, b_ld, C, ldc, bias, M, N, \
@@ -1493,7 +1650,7 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
 
 extern "C" int genrl_set_gemm_precision(int bf16) {
   const int prev = g_gemm_bf16;
-  g_gemm_bf16 = bf16 ? 1 : 0;
+  g_gemm_bf16 = (bf16 >= 1 && bf16 <= 3) ? bf16 : 0;
   return prev;
 }
 

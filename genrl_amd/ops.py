@@ -26,11 +26,18 @@ def _p(t):
     return t.data_ptr()
 
 
+# how `precision: 32` runs its big-tile GEMMs: 'f32' = fp32 MFMA; 'bf16x3-big' / 'bf16x3' = fp32 operands split exactly into
+# three bf16 terms, six bf16 MFMA products, fp32 accumulation (fp32-equivalent error; GENRL_GEMM_MODE=0|2|3 overrides)
+F32_MODE = {'0': 'f32', '2': 'bf16x3-big', '3': 'bf16x3'}.get(os.environ.get('GENRL_GEMM_MODE', ''), 'bf16x3-big')
+
+
 def set_gemm_precision(mode):
     """'f32' (default) or 'bf16': MFMA operands rounded to bf16, fp32 accumulation, fp32 tensors (the reference's
     `precision: 16` mode).  Process-wide; returns the previous mode."""
-    assert mode in ('f32', 'bf16'), mode
-    return 'bf16' if lib().genrl_set_gemm_precision(int(mode == 'bf16')) else 'f32'
+    codes = {'f32': 0, 'bf16': 1, 'bf16x3-big': 2, 'bf16x3': 3}
+    assert mode in codes, mode
+    prev = lib().genrl_set_gemm_precision(codes[mode])
+    return {v: k for k, v in codes.items()}[prev]
 
 
 def _prows(t):

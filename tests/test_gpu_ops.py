@@ -99,13 +99,19 @@ def test_sgemm_bf16_mode(ops, M, N, K, lay):
     A = torch.randn(M, K, generator=g(1)); B = torch.randn(N, K, generator=g(2))
     a, ars, aks = (A.cuda(), K, 1) if lay[0] == 'k' else (A.T.contiguous().cuda(), 1, M)
     b, brs, bks = (B.cuda(), K, 1) if lay[1] == 'k' else (B.T.contiguous().cuda(), 1, N)
-    C32 = torch.empty(M, N, device='cuda'); C16 = torch.empty(M, N, device='cuda')
-    ops.sgemm(a, ars, aks, b, brs, bks, C32, N, None, M, N, K)
-    prev = ops.set_gemm_precision('bf16')
+    C32 = torch.empty(M, N, device='cuda'); C16 = torch.empty(M, N, device='cuda'); C3 = torch.empty(M, N, device='cuda')
+    prev = ops.set_gemm_precision('f32')
     try:
+        ops.sgemm(a, ars, aks, b, brs, bks, C32, N, None, M, N, K)
+        ops.set_gemm_precision('bf16')
         ops.sgemm(a, ars, aks, b, brs, bks, C16, N, None, M, N, K)
+        ops.set_gemm_precision('bf16x3')         # fp32 through three exact bf16 terms per operand: fp32-sized error
+        ops.sgemm(a, ars, aks, b, brs, bks, C3, N, None, M, N, K)
     finally:
         ops.set_gemm_precision(prev)
+    exact = A.double() @ B.double().T
+    e32 = (C32.cpu().double() - exact).abs().max().item(); e3 = (C3.cpu().double() - exact).abs().max().item()
+    assert e3 <= 2.0 * e32 + 1e-6, (e3, e32)        # the split product is as accurate as the fp32 MFMAs
     want = (A.bfloat16().double() @ B.bfloat16().double().T)
     np.testing.assert_allclose(C16.cpu().double().numpy(), want.numpy(), rtol=1e-4, atol=2e-5 * K ** 0.5)
     err = (C16 - C32).abs().max().item()
