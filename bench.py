@@ -192,7 +192,11 @@ def main():
         out = {'metric': 'world-model+imag update steps/sec (B32xL32x64x64x3)', 'value': sps, 'unit': 'steps/s',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * dt / args.steps,
                'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
-               'dtype': 'f32' if args.precision == 32 else 'bf16 MFMA operands, f32 accumulate and storage',
+               'dtype': ('f32' if ops.F32_MODE == 'f32' else
+                         'f32 (storage, accumulation, every non-GEMM kernel and the 64x64-tile GEMMs; the 128x128-tile GEMMs '
+                         'split each fp32 operand exactly into 3 bf16 terms and sum 6 bf16-MFMA products in fp32: '
+                         'fp32-sized error, GENRL_GEMM_MODE=0 for fp32 MFMAs throughout)') if args.precision == 32
+               else 'bf16 MFMA operands, f32 accumulate and storage',
                'data': 'synthetic (seeded uint8 64x64 RGB replay, random-init weights, stub text embedding); '
                        + ('fresh batch per step gathered on-GPU from a device-resident replay store' if replay is not None
                           else 'one fixed batch'),
@@ -250,7 +254,7 @@ def main():
                            'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
                            'traffic_note': 'HBM bytes per launch (read+write) from profiles/r01_pmc.json; algorithmic '
                                            f'operand bytes per launch {sum(4.0 * (p_[0] * p_[2] + p_[1] * p_[2] + p_[0] * p_[1]) for p_ in prof) / max(len(prof), 1):.3g}',
-                           'kernel': 'sgemm_rr_kernel<2|4> + sgemm_tall_kernel (sgemm_kernel = fallback for unaligned operands) — gemm.hip, v_mfma_f32_16x16x4_f32, all instantiations',
+                           'kernel': 'sgemm_rr_kernel<2|4> + sgemm_tall_kernel (sgemm_kernel = fallback for unaligned operands) — gemm.hip, v_mfma_f32_16x16x4_f32 (64x64 tile) / 6 x v_mfma_f32_32x32x16_bf16 on exactly split fp32 operands (128x128 tile), all instantiations; priced against the fp32 MFMA peak',
                            'launches_per_step': len(prof), 'avg_launch_us': 1e3 * tot_ms / len(prof),
                            'gemm_gflop_per_step': tot_fl / 1e9, 'gemm_ms_per_step': tot_ms,
                            'skinny_kernel': {'launches_per_step': len(skinny), 'ms_per_step': sk_ms,

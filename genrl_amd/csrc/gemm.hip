@@ -1648,7 +1648,7 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
   return GENRL_OK;
 }
 
-extern "C" int genrl_set_gemm_precision(int bf16) {
+extern "C" int genrl_set_gemm_precision(int bf16 /* mode 0..3, see the header */) {
   const int prev = g_gemm_bf16;
   g_gemm_bf16 = (bf16 >= 1 && bf16 <= 3) ? bf16 : 0;
   return prev;

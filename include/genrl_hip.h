@@ -29,11 +29,15 @@ extern "C" {
  * up to the end of the padded line (extent = 255 in rows of 256: element 255 of every line is read and
  * ignored), so the padding must be addressable; every other layout takes the scalar-load kernel. */
 long genrl_sgemm_ws_floats(int M, int N, int K);
-/* Precision of the MFMA GEMMs (process-wide; returns the previous setting): 0 = fp32 MFMA (default), 1 = the operands
- * are rounded to bf16 (nearest even) on their way into the matrix cores, products accumulate in fp32 and every tensor
- * stays fp32 in memory -- the reference's `precision: 16` autocast mode (agent/dreamer_utils.py:889-932) without a
- * gradient scaler, which bf16's fp32 exponent range makes unnecessary. */
-int genrl_set_gemm_precision(int bf16);
+/* Arithmetic of the MFMA GEMMs (process-wide; returns the previous setting; initial value from GENRL_GEMM_MODE, default 2):
+ *   0  fp32 MFMAs everywhere.
+ *   2  fp32 (default): as 0, except that the 128x128-tile kernels split every fp32 operand element exactly into three
+ *      bf16 terms and sum the six largest bf16-MFMA cross products in fp32 -- error of the size of fp32 rounding.
+ *   3  the same split on every tile (slower on the 64x64 tile; for experiments).
+ *   1  precision 16: the operands are rounded to bf16 (nearest even) on their way into the matrix cores, products
+ *      accumulate in fp32 and every tensor stays fp32 in memory -- the reference's `precision: 16` autocast mode
+ *      (agent/dreamer_utils.py:889-932) without a gradient scaler, which bf16's fp32 exponent range makes unnecessary. */
+int genrl_set_gemm_precision(int mode);
 int genrl_sgemm(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks, float* C, long ldc,
                 const float* bias, int M, int N, int K, int accumulate, float* ws, long ws_floats, void* stream);
 
