@@ -9,30 +9,38 @@
 //   dgrad    dx = dy W        : A = dy (k-contig),   B = W  (row-contig)
 //   wgrad    dW = dy^T x      : A = dy (row-contig), B = x  (row-contig)
 //
-// Arithmetic: v_mfma_f32_32x32x2_f32 — exact fp32 (bitwise an fmaf chain), 64 FLOP/clk/SIMD.
-// gfx950 has no TF32/xf32 path, so this is the roofline the dense part of the GenRL hot path
-// is measured against (157.3 TFLOP/s).
+// Arithmetic (genrl_set_gemm_precision / GENRL_GEMM_MODE): fp32 MFMAs (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s peak, the
+// roofline everything is priced against; gfx950 has no TF32/xf32 path).  Default for the 128x128 tile: fp32 THROUGH THE
+// BF16 CORES -- every fp32 operand element split exactly into three bf16 terms, six v_mfma_f32_32x32x16_bf16 cross
+// products, fp32 accumulation: the error of an fp32 product, 19-23 % faster (VALU-bound by the split).  Precision 16:
+// operands rounded to bf16, fp32 accumulation.
 //
 // Kernels in this file:
-//   sgemm_rr_kernel<WB>  - the default.  256 threads (2x2 waves), ONE LDS buffer, every LDS fragment of a
-//       K tile pulled into registers (ds_read_b128 for k-contiguous operands), v_mfma_f32_16x16x4_f32 with
-//       WB x WB independent accumulators per wave, global loads two tiles ahead in two register sets, the
-//       register->LDS staging interleaved one 16-byte store at a time between the MFMAs, two barriers per
-//       iteration.  WB = 2: 64x64 tile (BK 64); WB = 4: 128x128 tile (BK 32, >= 512 such tiles or long-K
-//       split-K plans).  Several workgroups per CU with independent barriers.
-//   sgemm_kernel<BM,BN,BK,KG,..> - fallback for operands that miss the vector-load preconditions (odd
-//       leading dimensions / K), k-groups of 4 waves sharing a double-buffered LDS tile.
+//   sgemm_rr_kernel<WB, .., WBM, WBN, BF> - the default.  256 threads (2x2 waves), ONE LDS buffer, every LDS fragment
+//       of a K tile pulled into registers (ds_read_b128 for k-contiguous operands), WBM x WBN independent accumulators
+//       per wave, global loads two tiles ahead in two register sets, the register->LDS staging interleaved one 16-byte
+//       store at a time between the MFMAs, two barriers per iteration, iterations in pairs (one basic block), C stored
+//       16 bytes per lane (operand-swapped MFMAs).  WB = 2: 64x64 tile (BK 64); WB = 4: 128x128 tile (BK 32, >= 512 such
+//       tiles or long-K split-K plans); WBM / WBN = 3: 96-row / 96-column tiles for the 96/192-channel conv products.
+//       Several workgroups per CU with independent barriers.
+//   sgemm_tall_kernel<NB,KC> - M >= 16384, K <= 112: B as MFMA fragments in registers, A global -> register -> MFMA,
+//       no LDS, no barrier (the 3-channel ends of the image encoder / decoder; column slabs for wider N).
+//   sgemm_kernel<BM,BN,BK,KG,..> - fallback for operands that miss the vector-load preconditions (lines not padded to
+//       a multiple of 4 floats); none is left on the training step (GENRL_GEMM_TRACE=1 audits).
 //   skinny_kernel        - M <= 32 rows: weight stream, MFMA 16x16x4 straight from global memory.
 //   splitk_reduce_kernel - second pass of the deterministic split-K.
 // Operand conventions shared by all: one of the two strides of each operand is 1; LDS images are k-major
 // [k][rows+4] for row-contiguous and row-major [row][BK+4] for k-contiguous operands, with a k-pairing
-// shared by both MFMA operands; optional implicit stride-2 convolution operand (Gather).
-// Launch plan (tile shape x deterministic split-K through a caller workspace): plan_split().
+// shared by both MFMA operands; optional implicit stride-2 convolution operand (Gather); lines padded to a
+// multiple of 4 floats may hold any extent (255-bin heads in rows of 256).
+// Launch plan (tile shape x deterministic split-K through a caller workspace, row split of products that end just
+// above a full round): plan_split(), tail_split_rows().
 // Workgroup -> tile mapping is XCD-aware: the dispatcher places block b on XCD b%8, so blocks are
 // remapped such that each XCD owns a compact 2-D sub-block of the tile grid (operand panels stay
 // in that XCD's private L2).
 // Yardstick (scripts/blas_ref.py): the vendor's asm-scheduled fp32 kernels reach 98 / 105 / 131 TF/s on
-// 1024^3 / 1024x3072x1024 / 16384x1024x1024; this file reaches 78 / 88 / 124 (and wins on M <= 128).
+// 1024^3 / 1024x3072x1024 / 16384x1024x1024; this file reaches 94-98 / 107 / 118-133 with fp32 MFMAs and 146-155
+// (fp32-equivalent) on the last with the split operands.
 #include "common.h"
 #include <type_traits>
 
