@@ -119,6 +119,23 @@ class DreamerAgent(Module):
         return meta
 
 
+class _ImaginedSeq(dict):
+    """WorldModel.imagine's result.  The reference stores seq['feat'] = cat(stoch, deter) eagerly (agent/dreamer.py:272);
+    on the GenRL path nothing reads it (the heads take stoch and deter as two operands, video_text_reward goes
+    through the connector), and at 17 x 1024 rows the concatenation is a 140 MB copy per update -- so it is built
+    the first time somebody asks for it (env_reward does)."""
+    def __init__(self, rssm, items):
+        super().__init__(items)
+        self._rssm = rssm
+
+    def __missing__(self, key):
+        if key != 'feat':
+            raise KeyError(key)
+        value = self._rssm.get_feat(self)
+        self[key] = value
+        return value
+
+
 class WorldModel(Module):  # ref :120-321
     def __init__(self, config, obs_space, act_dim):
         super().__init__()
@@ -313,7 +330,7 @@ class WorldModel(Module):  # ref :120-321
             # policy outputs at states 0..H-1 — exactly what ActorCritic.actor_loss re-evaluates for its
             # entropy metric (agent/dreamer.py:397: actor(sg(feat[:-2]))): kept to avoid a second forward
             self._last_actor_raw = torch.stack(raws, 0)          # (H, N, 2A), attached to the actor's graph
-        seq['feat'] = rssm.get_feat(seq)
+        seq = _ImaginedSeq(rssm, seq)                  # 'feat' = cat(stoch, deter) (ref :272) on first access
         disc = torch.ones(list(seq['deter'].shape[:-1]) + [1], device=dev)       # no discount head
         seq['discount'] = disc * self.cfg.discount
         seq['weight'] = torch.cumprod(torch.cat([torch.ones_like(disc[:1]), disc[:-1]], 0), 0)
