@@ -335,6 +335,28 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   }
 }
 
+// narrow matrices (N <= 16 columns, contiguous rows: the 3-channel bias gradient of the last decoder layer sums 4.2 M
+// rows x 3 columns): the 64-column kernel above would keep 3 of 64 lanes busy.  Here a block walks its row chunk as a
+// flat stream with a stride that is a multiple of N, so a thread stays on one column; per-column sums through LDS.
+__global__ __launch_bounds__(256) void colsum_narrow_kernel(const float* __restrict__ x, float* __restrict__ part, long M,
+                                                           int N, long rows_per_chunk) {
+  __shared__ float sm[256];
+  const int bs = 256 - (256 % N);                      // active threads: a multiple of N
+  const long r0 = (long)blockIdx.x * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+  const long n = (r1 - r0) * N;
+  const float* p = x + r0 * N;
+  float a = 0.f;
+  if ((int)threadIdx.x < bs)
+    for (long i = threadIdx.x; i < n; i += bs) a += p[i];
+  sm[threadIdx.x] = a;
+  __syncthreads();
+  if ((int)threadIdx.x < N) {
+    float t = 0.f;
+    for (int i = threadIdx.x; i < bs; i += N) t += sm[i];
+    part[(long)blockIdx.x * N + threadIdx.x] = t;
+  }
+}
+
 // ------------------------------------------------------------------ actor Normal head
 // raw[R,2A] = [out | std_raw]; mean = tanh(out); std = (max-min)*sigmoid(std_raw+2)+min;
 // action = mean + std*eps.   ref: DistLayer 'normal', agent/dreamer_utils.py:814-819
@@ -871,7 +893,10 @@ int genrl_colsum(const float* x, long ldx, float* out, float* ws, int M, int N, 
   hipStream_t s = (hipStream_t)stream;
   const int nchunk = chunks_for(M);
   const int rpc = cdiv(M, nchunk);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), nchunk), dim3(256), 0, s, x, ldx, ws, M, N, rpc);
+  if (N <= 16 && ldx == N && M >= 4096)
+    hipLaunchKernelGGL(colsum_narrow_kernel, dim3(nchunk), dim3(256), 0, s, x, ws, (long)M, N, (long)rpc);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), nchunk), dim3(256), 0, s, x, ldx, ws, M, N, rpc);
   reduce_cols(ws, ws + (long)nchunk * N, out, nchunk, N, accumulate, s);
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;

@@ -341,6 +341,19 @@ def test_convT2d_s2(ops, N, Hi, Ci, Co, k):
     compare(lambda x, W, b: ops.convT2d_s2(x.permute(0, 2, 3, 1).contiguous(), W, b), ref, [x, W, b], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('M,N', [(5000, 3), (4194304, 3), (100000, 10), (70000, 16), (300, 3), (9000, 48), (100000, 255)])
+def test_colsum(ops, M, N):
+    """bias-gradient column sums: the wide kernel, the narrow-matrix kernel (3-channel image rows) and the accumulate
+    form; exact on small integers (fixed summation order, sums below 2^24)."""
+    x = ((torch.arange(M * N, dtype=torch.int64) * 7919) % 7 - 3).to(torch.float32).reshape(M, N)
+    want = x.double().sum(0)
+    out = ops.colsum(x.cuda())
+    assert torch.equal(out.cpu().double(), want)
+    acc = torch.full((N,), 2.0, device='cuda')
+    ops.colsum(x.cuda(), out=acc, accumulate=True)
+    assert torch.equal(acc.cpu().double(), want + 2.0)
+
+
 def test_transpose_and_cat(ops):
     x = torch.randn(3, 4, 6, generator=g(1))
     compare(ops.transpose_last2, lambda x: x.transpose(1, 2).contiguous(), [x])
