@@ -373,10 +373,8 @@ class Decoder(Module):  # ref :631-715
                 ln = self._conv_model[3 * i + 1]
                 x = ops.convT2d_s2(x, conv.weight, conv.bias, ln=(ln.norm.weight, ln.norm.bias, ln.norm.eps))
             else:
-                x = ops.convT2d_s2(x, conv.weight, conv.bias)
-        N, H, W, C = x.shape
-        x = ops.transpose_last2(x.reshape(N, H * W, C)).reshape(tuple(lead) + (C, H, W))   # -> NCHW
-        return {key: MSEDist(x) for key in self.channels}
+                x = ops.convT2d_s2(x, conv.weight, conv.bias, out_nchw=True)     # frames leave in the reference's NCHW
+        return {key: MSEDist(x.reshape(tuple(lead) + tuple(x.shape[1:]))) for key in self.channels}
 
 
 # ----------------------------------------------------------------------------- RSSM

@@ -1018,7 +1018,7 @@ class _ConvT2dS2(Function):
     """nn.ConvTranspose2d(k, stride 2) as GEMM + gather-form col2im.  x NHWC (N,Hi,Wi,Ci);
     Wp (Ci, k*k*Co) = weight permuted to (ci, kh, kw, co); returns NHWC."""
     @staticmethod
-    def forward(ctx, x, Wp, b, k, gamma=None, beta=None, eps=0.0):
+    def forward(ctx, x, Wp, b, k, gamma=None, beta=None, eps=0.0, out_nchw=False):
         x = _f32(x).contiguous()
         Nimg, Hi, Wi, Ci = x.shape
         Nw = Wp.shape[1]
@@ -1026,7 +1026,9 @@ class _ConvT2dS2(Function):
         M = Nimg * Hi * Wi
         cols = torch.empty(M, Nw, device=x.device)
         sgemm(x, Ci, 1, Wp, 1, Nw, cols, Nw, None, M, Nw, Ci)         # cols = x W
-        y = _col2im(cols, b, Nimg, Hi, Wi, Co, k)
+        assert not (out_nchw and gamma is not None)
+        y = _col2im(cols, b, Nimg, Hi, Wi, Co, k, nchw=out_nchw)       # (the last decoder layer hands out NCHW frames)
+        ctx.out_nchw = out_nchw
         ctx.dims = (Nimg, Hi, Wi, Ci, Co, k)
         ctx.fused_ln = gamma is not None
         ctx.bias = b
@@ -1049,8 +1051,8 @@ class _ConvT2dS2(Function):
             pre, mean, rstd, gamma, beta = ctx.saved_tensors[2:]
             dy, dg, dbe, db_ln = _ln_bwd_rows(dy.reshape(-1, Co), pre.reshape(-1, Co), gamma, beta, mean, rstd, ctx.bias)
             dy = dy.reshape(Nimg, Ho, Wo, Co)
-        implicit = _implicit_conv(dy, Co) and Ci % 4 == 0
-        dcols = None if implicit else _im2col(dy, Nimg, Ho, Wo, Co, k, 0)       # (M, Nw) patch matrix of dy
+        implicit = _implicit_conv(dy, Co) and Ci % 4 == 0 and not ctx.out_nchw
+        dcols = None if implicit else _im2col(dy, Nimg, Ho, Wo, Co, k, 1 if ctx.out_nchw else 0)   # (M, Nw) patch matrix of dy
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, Ci, device=dy.device)
@@ -1066,16 +1068,22 @@ class _ConvT2dS2(Function):
             else:
                 sgemm(x, 1, Ci, dcols, 1, Nw, dW, Nw, None, Ci, Nw, M)    # dW = x^T dcols
         if ctx.needs_input_grad[2]:
-            db = db_ln if ctx.fused_ln else colsum(dy.reshape(-1, Co))
-        return dx, dW, db, None, dg, dbe, None
+            if ctx.fused_ln:
+                db = db_ln
+            elif ctx.out_nchw:
+                db = dy.sum((0, 2, 3))
+            else:
+                db = colsum(dy.reshape(-1, Co))
+        return dx, dW, db, None, dg, dbe, None, None
 
 
-def convT2d_s2(x, W, b, ln=None):
-    """W (Ci,Co,k,k) in the reference layout; permuted per call to (Ci, kh*kw*Co)."""
+def convT2d_s2(x, W, b, ln=None, out_nchw=False):
+    """W (Ci,Co,k,k) in the reference layout; permuted per call to (Ci, kh*kw*Co).  out_nchw: (N,Co,Ho,Wo) output
+    (written that way by the overlap-add kernel; no LayerNorm fusion then)."""
     Ci, Co, k, _ = W.shape
     Wp = transpose_last2(W.reshape(Ci, Co, k * k)).reshape(Ci, k * k * Co)
     if ln is None:
-        return _ConvT2dS2.apply(x, Wp, b, k)
+        return _ConvT2dS2.apply(x, Wp, b, k, None, None, 0.0, out_nchw)
     return _ConvT2dS2.apply(x, Wp, b, k, ln[0], ln[1], float(ln[2]))
 
 

@@ -339,6 +339,9 @@ def test_convT2d_s2(ops, N, Hi, Ci, Co, k):
     b = torch.randn(Co, generator=g(3))
     ref = lambda x, W, b: F.conv_transpose2d(x, W, b, stride=2).permute(0, 2, 3, 1)
     compare(lambda x, W, b: ops.convT2d_s2(x.permute(0, 2, 3, 1).contiguous(), W, b), ref, [x, W, b], rtol=1e-4, atol=1e-4)
+    if N <= 16:       # the NCHW-output form of the last decoder layer (overlap-add writes planes, dY patches read from planes)
+        compare(lambda x, W, b: ops.convT2d_s2(x.permute(0, 2, 3, 1).contiguous(), W, b, out_nchw=True),
+                lambda x, W, b: F.conv_transpose2d(x, W, b, stride=2), [x, W, b], rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize('M,N', [(5000, 3), (4194304, 3), (100000, 10), (70000, 16), (300, 3), (9000, 48), (100000, 255)])
