@@ -639,7 +639,7 @@ class Optimizer:
         group.step += 1
         group.step_dev.add_(1)
         ops.adam_step(group.flat, group.grad, group.m, group.v, group.norm, gscale, float(self._clip or 0.0),
-                      self._lr, self._eps, float(self._wd or 0.0), group.step, step_dev=group.step_dev)
+                      self._lr, self._eps, float(self._wd or 0.0), group.step, step_dev=group.step_dev, zero_grad=True)
         if self._wd:
             live_ids = {id(p) for p in live}
             for p in params:
@@ -649,8 +649,7 @@ class Optimizer:
                         ops.scale_(p.data, 1.0 - self._wd) if p.data.is_contiguous() else p.data.mul_(1.0 - self._wd)
             for g in self._decay_groups(params, live_ids):
                 ops.scale_(g.flat, 1.0 - self._wd)
-        group.grad.zero_()
-        return metrics
+        return metrics                                   # (the gradient buffer was cleared by the Adam pass)
 
     def _flat_owner(self, p):
         for g in self._groups:

@@ -34,11 +34,11 @@ __global__ __launch_bounds__(256) void sqnorm_final_kernel(const float* __restri
   if (threadIdx.x == 0) norm_out[0] = sqrtf(a) * scale;
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n,
                                                    const float* __restrict__ norm, float gscale, float clip, float lr,
                                                    float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2,
-                                                   const int* __restrict__ step_dev) {
+                                                   const int* __restrict__ step_dev, int zero_grad) {
   if (step_dev) {   // step counter lives on the device (hipGraph replay: host scalars would be frozen)
     const float st = (float)step_dev[0];
     bc1 = 1.0f - powf(b1, st);
@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     p[i] = (1.0f - wd) * p[i] - (lr / bc1) * (mi / denom);
     m[i] = mi;
     v[i] = vi;
+    if (zero_grad) g[i] = 0.f;           // Optimizer's zero_grad() in the same pass (the gradient is read exactly here)
   }
 }
 
@@ -88,14 +89,15 @@ int genrl_grad_norm(const float* g, long n, float* norm_out, float* ws, float sc
 // genrl_grad_norm (already including gscale); gscale multiplies g before use (1/world_size).
 // `step` is the 1-based Adam step; if step_dev != NULL the (already incremented) count is read from
 // device memory instead, so that a captured hipGraph replays with the right bias correction.
-int genrl_adam_step(float* p, const float* g, float* m, float* v, long n, const float* norm, float gscale, float clip,
-                    float lr, float b1, float b2, float eps, float wd, int step, const int* step_dev, void* stream) {
+int genrl_adam_step(float* p, float* g, float* m, float* v, long n, const float* norm, float gscale, float clip,
+                    float lr, float b1, float b2, float eps, float wd, int step, const int* step_dev, int zero_grad,
+                    void* stream) {
   GENRL_ENTER();
   if (n <= 0) return GENRL_OK;
   const float bc1 = 1.0f - powf(b1, (float)step);
   const float sqrt_bc2 = sqrtf(1.0f - powf(b2, (float)step));
   hipLaunchKernelGGL(adam_kernel, dim3(cdiv(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, norm, gscale,
-                     clip, lr, b1, b2, eps, wd, bc1, sqrt_bc2, step_dev);
+                     clip, lr, b1, b2, eps, wd, bc1, sqrt_bc2, step_dev, zero_grad);
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }

@@ -1110,9 +1110,9 @@ def grad_norm(g_flat, out, scale=1.0):
     return out
 
 
-def adam_step(p, g, m, v, norm, gscale, clip, lr, eps, wd, step, b1=0.9, b2=0.999, step_dev=None):
+def adam_step(p, g, m, v, norm, gscale, clip, lr, eps, wd, step, b1=0.9, b2=0.999, step_dev=None, zero_grad=False):
     check(lib().genrl_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(norm), gscale, clip, lr, b1, b2, eps, wd,
-                                step, _p(step_dev), _stream()), 'adam_step')
+                                step, _p(step_dev), int(zero_grad), _stream()), 'adam_step')
 
 
 def scale_(p, s):

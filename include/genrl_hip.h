@@ -158,8 +158,10 @@ int genrl_gather_windows(const void* src, long row_bytes, long ring_rows, const 
 /* ---- Optimizer.__call__ (agent/dreamer_utils.py:892-932) on flat buffers */
 long genrl_sqnorm_ws_floats(long n);
 int genrl_grad_norm(const float* g, long n, float* norm_out, float* ws, float scale, void* stream);
-int genrl_adam_step(float* p, const float* g, float* m, float* v, long n, const float* norm, float gscale, float clip,
-                    float lr, float b1, float b2, float eps, float wd, int step, const int* step_dev, void* stream);
+/* zero_grad != 0: g is cleared in the same pass (the optimiser's zero_grad()) */
+int genrl_adam_step(float* p, float* g, float* m, float* v, long n, const float* norm, float gscale, float clip,
+                    float lr, float b1, float b2, float eps, float wd, int step, const int* step_dev, int zero_grad,
+                    void* stream);
 int genrl_scale(float* p, long n, float s, void* stream);
 
 #ifdef __cplusplus
