@@ -854,6 +854,10 @@ class _Rollout(Function):
         dha, dhb = f(N, D), f(N, D)
         cur, nxt = dha, None                              # ping-pong: recurrent gradient into deter_h from step h's GRU
         pt = lambda t, off: t.data_ptr() + 4 * off
+        dact_all = None
+        if da_in is not None:                 # upstream action gradients, once, in rows padded like the forward's actions
+            dact_all = torch.zeros(H + 1, N, AP, device=dev)
+            dact_all[:, :, :A].copy_(da_in)
         for h in range(H - 1, -1, -1):
             sN, dN = h * N * SK, h * N * D
             # grad wrt stoch_{h+1} (complete in ds[h+1]) -> logits (straight-through), plus any direct logit gradient
@@ -873,11 +877,14 @@ class _Rollout(Function):
             sgemm(dg_pre, 3 * D, 1, sp.gru_w, 1, Kg, dx, U, None, N, U, 3 * D)
             _ln_bwd_raw(_p(dx), pt(x_pre, h * N * U), sp.in_g, sp.in_be, pt(st['xm'], h * N), pt(st['xr'], h * N), _p(dx_pre), N, U)
             sgemm(dx_pre, U, 1, ws_in, 1, SK, ds, SK, None, N, SK, U, accumulate=True, c_off=sN)
-            if da_in is not None:
-                dact.zero_()
-                dact[:, :A].copy_(da_in[h + 1])
-            sgemm(dx_pre, U, 1, wa, 1, AP, dact, AP, None, N, AP, U, accumulate=da_in is not None)
-            check(lib().genrl_actor_head_bwd(_p(dact), pt(raws, h * N * 2 * A), pt(eps, h * N * A), pt(tape.d_raw, h * N * 2 * A),
+            # d action_{h+1} = upstream (already sitting in its padded row of dact_all) + dx_pre W_a: accumulate epilogue
+            if dact_all is not None:
+                sgemm(dx_pre, U, 1, wa, 1, AP, dact_all, AP, None, N, AP, U, accumulate=True, c_off=(h + 1) * N * AP)
+                dptr = pt(dact_all, (h + 1) * N * AP)
+            else:
+                sgemm(dx_pre, U, 1, wa, 1, AP, dact, AP, None, N, AP, U)
+                dptr = dact.data_ptr()
+            check(lib().genrl_actor_head_bwd(dptr, pt(raws, h * N * 2 * A), pt(eps, h * N * A), pt(tape.d_raw, h * N * 2 * A),
                                              N, A, sp.min_std, sp.max_std, AP, _stream()), 'actor_head_bwd')
             nxt, cur = cur, (dhb if cur is dha else dha)
         if d_raws is not None:
