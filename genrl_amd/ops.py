@@ -646,7 +646,7 @@ class ActorTape:
         flat = [q for l in self.layers for q in l[:4]]
         return _ActorStep.apply(x1, x2, self.head_w, self.head_b, self, t, *flat)
 
-    def _forward(self, t, x1, x2):
+    def _forward(self, t, x1, x2, out=None):
         N = self.N
         a, c = _f32(x1).contiguous(), _f32(x2).contiguous()
         K1, K2 = a.shape[1], c.shape[1]
@@ -665,7 +665,7 @@ class ActorTape:
                                          N, U, eps, 1, _stream()), 'ln_act_fwd')
             x, Kx = y, U
         A2 = self.head_w.shape[0]
-        raw = torch.empty(N, A2, device=a.device)
+        raw = out if out is not None else torch.empty(N, A2, device=a.device)     # (out: the rollout's own (N, 2A) row)
         sgemm(x, Kx, 1, self.head_w, Kx, 1, raw, A2, self.head_b, N, A2, Kx, a_off=t * N * Kx)
         return raw
 
@@ -806,8 +806,7 @@ class _Rollout(Function):
         pt = lambda t, off: t.data_ptr() + 4 * off
         for h in range(H):
             sN, dN = h * N * SK, h * N * D
-            raw = tape._forward(h, stoch[h], deter[h])
-            raws[h].copy_(raw)
+            tape._forward(h, stoch[h], deter[h], out=raws[h])
             check(lib().genrl_actor_head_fwd(pt(raws, h * N * 2 * A), pt(eps, h * N * A), pt(action, (h + 1) * N * AP), None, None,
                                              N, A, sp.min_std, sp.max_std, AP, _stream()), 'actor_head_fwd')
             # img_in: [stoch_h | action_{h+1}] -> hidden, LN + SiLU
