@@ -304,7 +304,8 @@ def test_mse_maxcos_actor(ops):
 
 @pytest.mark.parametrize('N,Hi,C,Co,k', [(2, 16, 3, 8, 4), (3, 31, 8, 16, 4), (2, 6, 16, 32, 4), (1, 63, 4, 4, 4),
                                          (8, 31, 48, 96, 4), (64, 14, 96, 192, 4), (2, 33, 12, 20, 5),
-                                         (512, 31, 48, 96, 4)])      # (the last: 96-wide rectangular GEMM tiles, both gather sides)
+                                         (512, 31, 48, 96, 4),       # 96-wide rectangular GEMM tiles, both gather sides
+                                         (1024, 14, 48, 256, 4)])    # 128x128 gather tiles (split-operand bf16 MFMAs by default)
 def test_conv2d_s2(ops, N, Hi, C, Co, k):
     x = torch.randn(N, C, Hi, Hi, generator=g(1)); W = torch.randn(Co, C, k, k, generator=g(2)) / (C * k * k) ** .5
     b = torch.randn(Co, generator=g(3))
