@@ -262,7 +262,10 @@ __global__ void reduce_chunks2_kernel(const float* __restrict__ part, float* __r
   float* o = j < N ? out0 + j : (j < 2 * N ? out1 + (j - N) : out2 + (j - 2 * N));
   *o = accumulate ? *o + s : s;
 }
-// one-launch version for a moderate number of partial rows (17..256): 64 columns x 4 interleaved row
+#ifndef REDUCE2M_MAX
+#define REDUCE2M_MAX 512   /* partial rows summed by ONE launch of reduce_chunks2m (512 = every block-per-row backward) */
+#endif
+// one-launch version for a moderate number of partial rows (17..REDUCE2M_MAX): 64 columns x 4 interleaved row
 // subsets per block, summed through LDS (fixed order)
 __global__ __launch_bounds__(256) void reduce_chunks2m_kernel(const float* __restrict__ part, float* __restrict__ out0,
                                                               float* __restrict__ out1, float* __restrict__ out2,
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256) void reduce_chunks2m_kernel(const float* __res
 // helper: part[nchunk][N] -> out[N]; `tmp` must hold 16*N floats when nchunk > 256
 static inline void reduce_cols(const float* part, float* tmp, float* out, int nchunk, int N, int accumulate,
                                hipStream_t s) {
-  if (nchunk > 256) {
+  if (nchunk > REDUCE2M_MAX) {
     const int G = 16, per = cdiv(nchunk, G);
     hipLaunchKernelGGL(reduce_chunksA_kernel, dim3(cdiv(N, 64), G), dim3(256), 0, s, part, tmp, nchunk, N, per);
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, tmp, out, G, (long)N, accumulate);
@@ -302,7 +305,7 @@ static inline void reduce_cols(const float* part, float* tmp, float* out, int nc
 static inline void reduce_params(const float* part, float* tmp, float* out0, float* out1, int nchunk, int N,
                                  int accumulate, hipStream_t s, float* out2 = nullptr) {
   const int np = out2 ? 3 : 2;
-  if (nchunk > 16 && nchunk <= 256) {
+  if (nchunk > 16 && nchunk <= REDUCE2M_MAX) {
     hipLaunchKernelGGL(reduce_chunks2m_kernel, dim3(cdiv(np * N, 64)), dim3(256), 0, s, part, out0, out1, out2, nchunk, N,
                        np, accumulate);
   } else if (nchunk > 16) {
