@@ -169,7 +169,10 @@ def main():
                     help='32 (default, the parity-pinned path) or 16: bf16 MFMA operands, fp32 accumulation/storage '
                          '(SURVEY 8f.4; reported as its own dtype, never mixed into the fp32 headline)')
     ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
-                    help='replay the iteration as captured hipGraphs (collectives stay eager between graphs)')
+                    help='replay the iteration as captured hipGraphs')
+    ap.add_argument('--dp-graph', default='auto', choices=['auto', 'cut'],
+                    help='data parallel: auto = collectives captured inside the graph when the backend is RCCL (falls back to '
+                         'cuts, then eager); cut = collectives eager between graph segments')
     args = ap.parse_args()
     global PEAK_F32_MFMA_TFLOPS
     if args.precision == 16:
@@ -190,8 +193,9 @@ def main():
 
     B, T = args.batch, args.length
     torch.manual_seed(0)                         # identical random-init weights on every rank
-    cfg = config.default_cfg(B // world, T, device=dev, overlap_detached=(world == 1 and not args.no_overlap),
-                             precision=args.precision)
+    # (the connector's side stream: always on one GPU; under data parallelism only with RCCL's stream-ordered collectives --
+    # WorldModel.update_additional_detached_modules checks Optimizer.overlap_under_dp, set by dp.install)
+    cfg = config.default_cfg(B // world, T, device=dev, overlap_detached=not args.no_overlap, precision=args.precision)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):   # (the agent announces its parameter counts like the reference does;
         ag = config.make_agent(cfg)                #  stdout carries the ONE JSON line only)
@@ -210,18 +214,60 @@ def main():
             replay.store_episode({k: v[0] for k, v in ep.items()})
         np.random.seed(4321 + rank)
 
-    graphed = None
+    # ---- hipGraph capture.  One GPU: the whole iteration is one graph.  Data parallel: the collectives are captured INSIDE the
+    # graph when the backend is RCCL ('ingraph': no cuts, the connector's side stream stays on), else -- or when that capture
+    # fails or does not pass the cross-rank self-check below -- they run eagerly between graph segments ('cut'), else the
+    # whole iteration runs eagerly.  Whatever happens, the JSON line is printed.
+    graphed, launch_mode = None, 'eager'
+    backend = torch.distributed.get_backend() if world > 1 else None
+
+    def ranks_agree(mets):
+        """data parallel: after a step every rank must hold the same (finite) reduced gradient norms"""
+        if world == 1:
+            return True
+        keys = [k for k in ('model_grad_norm', 'connector_model_grad_norm', 'imag_actor_grad_norm', 'imag_critic_grad_norm') if k in mets]
+        mine = torch.stack([mets[k].detach().float().reshape(()) for k in keys]).to(dev)
+        allv = [torch.empty_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allv, mine)
+        ok = bool(torch.isfinite(mine).all()) and all(torch.equal(v, allv[0]) for v in allv)
+        flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        return bool(flag.item() > 0)
+
+    def resync_weights():
+        """a failed attempt may have left the ranks with different weights: rank 0's are broadcast"""
+        for o in (ag.wm.model_opt, ag._imag_behavior.actor_opt, ag._imag_behavior.critic_opt):
+            for g in o._groups:
+                for t in (g.flat, g.m, g.v, g.grad):
+                    torch.distributed.broadcast(t, 0)
+                planes.invalidate(g.params)
+        torch.cuda.synchronize()
+
     if args.graph != 'off':
-        try:
-            from genrl_amd.graph import GraphedStep
-            graphed = GraphedStep(ag, batch, one_step, warmup=2)
-        except Exception as e:                      # capture unsupported -> eager launches
-            if args.graph == 'on':
-                raise
-            print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
-            graphed = None
-            ag._imag_behavior._defer_slow_target = False
-            torch.cuda.synchronize()
+        from genrl_amd.graph import GraphedStep
+        modes = ['cut'] if world == 1 else ((['ingraph'] if backend == 'nccl' and args.dp_graph != 'cut' else []) + ['cut'])
+        for mode in modes:
+            try:
+                g_try = GraphedStep(ag, batch, one_step, warmup=2, collectives=mode)
+                m_try = g_try()
+                torch.cuda.synchronize()
+                if not ranks_agree(m_try):
+                    raise RuntimeError('ranks disagree on the reduced gradient norms after a replayed step')
+                graphed, launch_mode = g_try, ('hipGraph replay' if world == 1 else f'hipGraph replay, collectives {mode}')
+                break
+            except Exception as e:                      # capture unsupported / unsound -> next mode, finally eager launches
+                if args.graph == 'on' and mode == modes[-1]:
+                    raise
+                print(f'[bench] hipGraph capture ({mode}) failed ({type(e).__name__}: {e}); falling back', file=sys.stderr)
+                graphed = None
+                ag._imag_behavior._defer_slow_target = False
+                torch.cuda.synchronize()
+                if world > 1:
+                    resync_weights()
+    if graphed is None and world > 1:
+        m_try = one_step(ag, batch); torch.cuda.synchronize()
+        if not ranks_agree(m_try):
+            print('[bench] WARNING: ranks disagree on reduced gradient norms in eager mode', file=sys.stderr)
     if replay is None:
         run_step = (lambda: graphed()) if graphed is not None else (lambda: one_step(ag, batch))
     elif graphed is not None:
@@ -294,26 +340,30 @@ def main():
                          'of the imagination rollout and of the Dense+LN+SiLU chains from 512 rows up take fp32 operands pre-split '
                          'into two fp16 planes of the row-scaled value (22 mantissa bits + fp32 accumulation of 3 fp16-MFMA '
                          'products), the remaining 128x128-tile GEMMs split each fp32 operand exactly into 3 bf16 terms in registers '
-                         '(6 bf16-MFMA products): error vs float64 at or below the fp32 MFMAs\' in both cases; GENRL_GEMM_MODE=0 '
-                         'GENRL_PLANES=0 = fp32 MFMAs throughout, timed beside as fp32_mfma_mode)') if args.precision == 32
-               else 'bf16 MFMA operands, f32 accumulate and storage',
+                         '(6 bf16-MFMA products).  Error vs float64: same order as the fp32 MFMAs\' -- measured 0.4-2x theirs for '
+                         'the fp16 planes (operand representation 2^-23 relative; profiles/*planes_bench*), at or below theirs for '
+                         'the exact 3-term bf16 split; GENRL_GEMM_MODE=0 GENRL_PLANES=0 = fp32 MFMAs throughout, timed beside as '
+                         'fp32_mfma_mode)') if args.precision == 32
+               else 'precision-16 variant: bf16-rounded MFMA operands in the fp32-operand kernels, f32 accumulate and storage; the '
+                    'products that run on fp16 planes (rollout, Dense+LN+SiLU chains from 512 rows up) keep fp32-grade arithmetic',
                'data': 'synthetic (seeded uint8 64x64 RGB replay, random-init weights, stub text embedding); '
                        + ('fresh batch per step gathered on-GPU from a device-resident replay store' if replay is not None
                           else 'one fixed batch'),
                'config': {'workload': 'configs[1]: full WM + 2x connector + imag-behaviour update, video_text_reward, '
                                       f'batch {B} x seq {T}, 64x64x3, horizon 16, A=10',
                           'global_batch': B, 'seq_len': T, 'parallelism': f'dp{world}',
-                          'launch': f'hipGraph replay ({sum(1 for k_, _ in graphed.items if k_ == "graph")} graphs per iteration)' if graphed is not None else 'eager'},
-               'algorithmic_gflop_per_step': fl['total'],
-               'step_roofline': {'bound': 'mfma', 'achieved': fl['total'] * sps / 1e3 / world, 'peak': PEAK_F32_MFMA_TFLOPS,
-                                 'unit': 'TFLOP/s', 'frac': fl['total'] * sps / 1e3 / world / PEAK_F32_MFMA_TFLOPS},
+                          'launch': f'{launch_mode} ({sum(1 for k_, _ in graphed.items if k_ == "graph")} graphs per iteration)' if graphed is not None else 'eager'},
+               'algorithmic_gflop_per_step': fl['total'], 'executed_gflop_per_step': fl['executed'],
+               # priced on the work this build EXECUTES (SURVEY's algorithmic count includes the policy's entropy re-evaluation,
+               # 421 GF at c2, which contributes nothing with actor_ent = 0 and is not run here); the algorithmic figure beside it
+               'step_roofline': {'bound': 'mfma', 'achieved': fl['executed'] * sps / 1e3 / world, 'peak': PEAK_F32_MFMA_TFLOPS,
+                                 'unit': 'TFLOP/s', 'frac': fl['executed'] * sps / 1e3 / world / PEAK_F32_MFMA_TFLOPS,
+                                 'on': 'executed GF per step', 'frac_on_algorithmic_gflop': fl['total'] * sps / 1e3 / world / PEAK_F32_MFMA_TFLOPS},
                'final_model_loss': loss, 'fp32_mfma_mode': fp32_mode}
     # ---- kernel roofline: HIP events around every launch of the fp32-MFMA GEMM kernel in one extra step
-    if rank != 0 and world > 1 and not args.no_kernel_profile:
-        for _ in range(2):               # the two profiled extra steps contain collectives: every rank takes part
-            one_step(ag, batch)
-        torch.cuda.synchronize()
-    if rank == 0 and not args.no_kernel_profile:
+    # (data parallel: no event-instrumented extra steps -- they would contain collectives and every rank would have to take
+    # part in lock step; the kernel roofline is the N=1 line's business)
+    if rank == 0 and not args.no_kernel_profile and world == 1:
         ov, ag.cfg.overlap_detached = ag.cfg.overlap_detached, False   # single stream: clean per-launch durations
 
         def profiled_step():

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import dreamer_utils as common
-from .. import noise, ops, ops_planes, streams, planes
+from .. import graph, noise, ops, ops_planes, streams, planes
 from ..tools.genrl_utils import *          # reward functions resolved through globals(), ref :9
 
 
@@ -224,7 +224,12 @@ class WorldModel(Module):  # ref :120-321
         # (only when a behaviour update follows: GenRLAgent.update_imag_behavior joins the side stream; in the
         # pre-training configuration -- imag_reward_fn None -- train.py never calls it, so nothing would order the side
         # stream's reads of the batch before the caller recycles it)
-        overlap = (getattr(self.cfg, 'overlap_detached', False) and common.Optimizer.grad_reduce is None
+        # Data parallel: only with stream-ordered collectives (RCCL: Optimizer.overlap_under_dp) -- the branch's own
+        # reductions then queue behind the world model's on the backend's stream, in the same program order on every rank,
+        # and the world-model step that is still pending (its reduction runs beside this branch) is completed by the MAIN
+        # stream (flush_pending=False here; WorldModel.update flushes after the fork).
+        overlap = (getattr(self.cfg, 'overlap_detached', False)
+                   and (common.Optimizer.grad_reduce is None or (common.Optimizer.overlap_under_dp and not graph.cutting()))
                    and getattr(self.cfg, 'imag_reward_fn', None) is not None)
         ctx = streams.fork('detached') if overlap else contextlib.nullcontext()
         with ctx:
@@ -233,7 +238,7 @@ class WorldModel(Module):  # ref :120-321
                 with common.RequiresGrad(detached_module):
                     add_loss, add_metrics = self.detached_update_fns[k](self, k, data, outputs, metrics)
                     metrics.update(add_metrics)
-                    opt_metrics = self.model_opt(add_loss, detached_module.parameters())
+                    opt_metrics = self.model_opt(add_loss, detached_module.parameters(), flush_pending=not overlap)
                     metrics.update({f'{k}_{m}': opt_metrics[m] for m in opt_metrics})
         return detached_loss, metrics
 
@@ -258,8 +263,11 @@ class WorldModel(Module):  # ref :120-321
         # cfg.overlap_detached: the prior branch (GRU scan -> prior head -> KL) runs on a side stream
         # beside the decoder / reward-head branch (genrl_amd/streams.py); only possible when the heads
         # do not read `deter` with a gradient path that the KL shares, i.e. the GenRL configuration
+        # (not under data parallelism: at the per-rank batch sizes the fork / join idles cost more than the branch hides,
+        # DESIGN par.6)
         fork = (getattr(self.cfg, 'overlap_detached', False) and self.rssm.single_obs_posterior
-                and self.cfg.decoder_inputs == 'stoch' and self.grad_heads == ['decoder'])
+                and self.cfg.decoder_inputs == 'stoch' and self.grad_heads == ['decoder']
+                and common.Optimizer.grad_reduce is None)
         self.rssm.fork_prior = fork
         post, prior = self.rssm.observe(embed, data['action'], data['is_first'], state)
         self.rssm.fork_prior = False

@@ -320,7 +320,11 @@ class MLP(Module):  # ref :718-747
         for index in range(self._layers):
             x = _dense_ln_silu(x, getattr(self, f'dense{index}'), getattr(self, f'norm{index}'), x2, planes=planes)
             x2 = planes = None
-        return x.reshape(list(features.shape[:-1]) + [x.shape[-1]])
+        out = x.reshape(list(features.shape[:-1]) + [x.shape[-1]])
+        h = getattr(x, '_planes', None)        # (reshape returns a new tensor object: carry the operand planes of the rows along)
+        if h is not None:
+            out._planes = h
+        return out
 
     def forward(self, features, features2=None, planes=None):
         return self._out(self.trunk(features, features2, planes))
@@ -584,6 +588,7 @@ class FlatGroup:
     """Parameters of one optimiser group re-homed into one flat fp32 buffer (params and grads are
     views), so clip-norm + decay + Adam is one pass and DP needs one all-reduce per group."""
     ALIGN = 64          # floats: every parameter starts on a 256-byte boundary (the vector-load GEMMs need 16)
+    NORM_SLOTS = 8
 
     def __init__(self, params):
         self.params = [p for p in params]
@@ -604,7 +609,15 @@ class FlatGroup:
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view(p.shape)
             p.grad = self.grad[off:off + k].view(p.shape)
-        self.norm = torch.zeros(1, device=dev)
+        # gradient-norm metric slots, used round-robin: the 0-d tensor an optimiser call hands out stays valid for the next
+        # NORM_SLOTS - 1 steps of this group (a caller that aggregates metrics over a few steps reads what it was given)
+        self.norm = torch.zeros(self.NORM_SLOTS, device=dev)
+        self.norm_i = 0
+
+    def norm_slot(self):
+        k = self.norm_i
+        self.norm_i = (k + 1) % self.NORM_SLOTS
+        return self.norm[k:k + 1]
 
     def owns(self, params):
         return len(params) == len(self.params) and all(a is b for a, b in zip(params, self.params))
@@ -625,6 +638,7 @@ class Optimizer:
     0-d device tensors).  `grad_reduce` is the DP hook (one all-reduce per group)."""
     grad_reduce = None      # set by genrl_amd.dp: callable(flat_grad) -> divisor
     grad_reduce_async = None   # set by genrl_amd.dp: callable(flat_grad) -> (wait(), world): the reduction runs beside later work
+    overlap_under_dp = False   # set by genrl_amd.dp for RCCL: collectives are stream-ordered, the connector's side stream may stay on
     grad_hook = None        # test hook: callable(opt_name, params) after backward, before the step
     reduce_hook = None      # test hook: callable(opt_name, group, gscale) after the DP reduction, before clip / Adam
 
@@ -652,12 +666,14 @@ class Optimizer:
         self._groups.append(g)
         return g
 
-    def __call__(self, loss, params, decay_only=(), defer=False):
+    def __call__(self, loss, params, decay_only=(), defer=False, flush_pending=True):
         """defer=True (data parallel only): the gradient all-reduce is STARTED here and the clip / Adam pass is left
-        pending until flush() -- or this optimiser's next call, after that call's backward: the reduction then runs
+        pending until flush() -- or this optimiser's next call, after that call's backward (flush_pending=False: not by
+        that call -- it runs on a side stream and the pending step belongs to the main one): the reduction then runs
         beside whatever the caller enqueues in between (the connector update behind the world-model reduction, the
-        critic update behind the actor's).  The returned grad-norm metric is the group's own device scalar, written
-        when the step completes (stream order makes that invisible to a reader on the same stream)."""
+        critic update behind the actor's).  The returned grad-norm metric is a device scalar in one of the group's
+        NORM_SLOTS round-robin slots, written when the step completes (stream order makes that invisible to a reader on
+        the same stream): it keeps its value for the next NORM_SLOTS - 1 steps of the group; read (or clone) it before."""
         params = [p for p in params]
         assert len(loss.shape) == 0 or (len(loss.shape) == 1 and loss.shape[0] == 1), (self._name, loss.shape)
         metrics = {}
@@ -682,7 +698,8 @@ class Optimizer:
         ops.wgrad_stream.join()
         if Optimizer.grad_hook is not None:
             Optimizer.grad_hook(self._name, live)
-        self.flush()                   # an earlier deferred step: its reduction had this backward to hide behind
+        if flush_pending:
+            self.flush()               # an earlier deferred step: its reduction had this backward to hide behind
         gscale, wait = 1.0, None
         if Optimizer.grad_reduce is not None:
             if defer and Optimizer.grad_reduce_async is not None:
@@ -701,8 +718,9 @@ class Optimizer:
             for g in self._decay_groups(params, live_ids):
                 ops.scale_(g.flat, 1.0 - self._wd)
             pl.invalidate([p for p in params if id(p) not in live_ids])     # (their cached weight planes are stale)
-        metrics[f'{self._name}_grad_norm'] = group.norm[0]
-        pend = (group, gscale, wait)
+        slot = group.norm_slot()
+        metrics[f'{self._name}_grad_norm'] = slot[0]
+        pend = (group, gscale, wait, slot)
         if wait is not None:
             self._pending.append(pend)
         else:
@@ -710,15 +728,15 @@ class Optimizer:
         return metrics
 
     def _finish(self, pend):
-        group, gscale, wait = pend
+        group, gscale, wait, slot = pend
         if wait is not None:
             wait()
         if Optimizer.reduce_hook is not None:
             Optimizer.reduce_hook(self._name, group, gscale)
-        ops.grad_norm(group.grad, group.norm, gscale, step_inc=group.step_dev)     # (also: device step count += 1)
+        ops.grad_norm(group.grad, slot, gscale, step_inc=group.step_dev)     # (also: device step count += 1)
         group.step += 1
         pl.invalidate(group.params)         # (these weights change below: their cached weight planes are stale)
-        ops.adam_step(group.flat, group.grad, group.m, group.v, group.norm, gscale, float(self._clip or 0.0),
+        ops.adam_step(group.flat, group.grad, group.m, group.v, slot, gscale, float(self._clip or 0.0),
                       self._lr, self._eps, float(self._wd or 0.0), group.step, step_dev=group.step_dev, zero_grad=True)
         # (the gradient buffer was cleared by the Adam pass)
 
@@ -792,11 +810,11 @@ class StreamNorm:
         self.step += 1
         if self._momentum == 1 and self.mag is not None:
             return                                  # ema(old, new) = 1 * old + 0 * new: the statistics never move again
-        if mom is not None:
-            self.mag, self.mean, self.square_mean = mom[2].clone(), mom[0].clone(), mom[3].clone()
+        ema = lambda old, new: new.clone() if old is None else self._momentum * old + (1 - self._momentum) * new
+        if mom is not None:        # scalar statistics from the one-pass kernel: the same EMA (ref :972-984), first call = copy
+            self.mag, self.mean, self.square_mean = ema(self.mag, mom[2]), ema(self.mean, mom[0]), ema(self.square_mean, mom[3])
             return
         batch = inputs.detach().reshape((-1,) + self._shape)
-        ema = lambda old, new: new.clone() if old is None else self._momentum * old + (1 - self._momentum) * new
         self.mag = ema(self.mag, torch.abs(batch).mean(0))
         self.mean = ema(self.mean, torch.mean(batch))
         self.square_mean = ema(self.square_mean, torch.mean(batch * batch))

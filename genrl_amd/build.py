@@ -2,7 +2,7 @@
 import os, subprocess, sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = ['gemm.hip', 'gemm_planes.hip', 'rowops.hip', 'dist.hip', 'conv.hip', 'optim.hip', 'stats.hip']
+SRC = ['gemm.hip', 'gemm_planes.hip', 'gemm_planes_tn.hip', 'rowops.hip', 'dist.hip', 'conv.hip', 'optim.hip', 'stats.hip']
 OUT = os.path.join(HERE, 'libgenrl_hip.so')
 
 
@@ -18,7 +18,7 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-Wno-c++20-extensions', '-shared', '-fPIC',
            '-I', os.path.join(os.path.dirname(HERE), 'include'),
            '-o', OUT] + [os.path.join(HERE, 'csrc', f) for f in SRC]
     if verbose:

@@ -5,8 +5,11 @@ SURVEY.md §8e); every optimiser group lives in ONE flat gradient buffer
 (world model, connector x2, actor, critic) right after its backward — the clip-norm and Adam
 kernels then consume the reduced buffer with the 1/world factor folded in.  The world-model and actor
 reductions are asynchronous (grad_reduce_async): they run beside the connector's / the critic's forward +
-backward and are waited for just before their own clip / Adam pass, so three waits per step are exposed
-(connector x2, critic) instead of five.  The RewardEMA
+backward and are waited for just before their own clip / Adam pass.  With RCCL (stream-ordered collectives) the
+connector updates -- their two reductions included -- stay on their side stream beside the imagination phase
+(Optimizer.overlap_under_dp), and under hipGraph replay every collective is captured inside the one graph
+(graph.GraphedStep(collectives='ingraph')): the only reduction nothing runs beside is the critic's, the last of the
+iteration.  With gloo (tests) the connector stays on the main stream and three waits are exposed.  The RewardEMA
 quantiles are taken over the all-gathered lambda-returns so every rank normalises identically.
 Works with gloo on CPU tensors too (used by the world_size-2 tests)."""
 import os
@@ -110,18 +113,23 @@ def all_gather_flat(x):
     return out
 
 
-def install(optimizer_cls, reward_ema_cls):
-    """Hook the collectives into the product classes (no-op for world size 1)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+def install(optimizer_cls, reward_ema_cls, force=False):
+    """Hook the collectives into the product classes (no-op for world size 1 unless force=True: the 1-rank RCCL test
+    drives the real hooks, captured collectives included, on a single GPU)."""
+    if dist.is_initialized() and (dist.get_world_size() > 1 or force):
         optimizer_cls.grad_reduce = staticmethod(grad_reduce)
         if os.environ.get('GENRL_DP_ASYNC', '1') != '0':
             optimizer_cls.grad_reduce_async = staticmethod(grad_reduce_async)
         reward_ema_cls.all_gather = staticmethod(all_gather_flat)
+        # RCCL orders every collective of the process group on its own stream: the connector's side stream
+        # (cfg.overlap_detached) may issue its reductions beside the main stream's (gloo's worker threads give no such order)
+        optimizer_cls.overlap_under_dp = dist.get_backend() == 'nccl' and os.environ.get('GENRL_DP_OVERLAP', '1') != '0'
 
 
 def uninstall(optimizer_cls, reward_ema_cls):
     optimizer_cls.grad_reduce = None
     optimizer_cls.grad_reduce_async = None
+    optimizer_cls.overlap_under_dp = False
     reward_ema_cls.all_gather = None
 
 

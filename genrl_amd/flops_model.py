@@ -55,5 +55,10 @@ def iteration_gflop(N, H=16, connector_steps=2, **kw):
     imag_bwd = H * m['img_step'] + H * (2 * m['actor'] - d0) + (H + 1) * m['critic'] + (H + 1) * m['conv_in'] \
         + (H - 1) * (2 * m['actor'] - d0) + H * (2 * m['critic'] - d0)
     g = lambda macs: 2.0 * macs * N / 1e9
+    total = g(wm_fwd + wm_bwd) + g(conn) * connector_steps + g(imag_fwd + imag_bwd)
+    # what this build does NOT execute of that count: the policy's re-evaluation on sg(feat[:-2]) for the entropy term
+    # (agent/dreamer.py:404-416) -- its loss weight actor_ent is 0 on the GenRL configuration, so the forward + backward
+    # contribute nothing, and the entropy METRIC is taken from the rollout's own policy outputs
+    ent_reeval = g((H - 1) * m['actor'] + (H - 1) * (2 * m['actor'] - d0))
     return dict(wm=g(wm_fwd + wm_bwd), connector=g(conn) * connector_steps, imag=g(imag_fwd + imag_bwd),
-                total=g(wm_fwd + wm_bwd) + g(conn) * connector_steps + g(imag_fwd + imag_bwd))
+                total=total, entropy_reevaluation=ent_reeval, executed=total - ent_reeval)

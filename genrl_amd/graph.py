@@ -1,6 +1,6 @@
 """hipGraph capture of one whole training iteration.
 
-The hot path launches ~5 k kernels per iteration, many of them a few microseconds long (the
+The hot path launches ~1.5 k kernels per iteration, many of them a few microseconds long (the
 sequential RSSM / imagination chains).  Eager Python cannot always feed those fast enough — above
 all when the replay batch is sharded over 8 GPUs and each rank's kernels shrink while the host work
 per iteration stays the same.  `GraphedStep` captures the iteration once into hipGraphs
@@ -11,30 +11,44 @@ What makes the iteration capturable: no host synchronisation anywhere on the pat
 device tensors), sampling noise from the device generator, Adam's step count on the device
 (`FlatGroup.step_dev`), workspaces from torch's graph-private pool.
 
-Collectives are NOT captured: data-parallel all-reduces / all-gathers are "cuts" — the capture is
-split into consecutive graphs sharing one memory pool, and the collective runs eagerly between two
-replays on buffers that are static across replays (flat gradient buffers; a preallocated gather
-output).  `cut()` is called by genrl_amd/dp.py's hooks.
+Collectives, two modes (`GraphedStep(collectives=...)`):
+* 'ingraph' (RCCL only): the all-reduces / all-gathers that genrl_amd/dp.py issues are captured INSIDE the one
+  graph -- torch's NCCL process group records them on its own stream, which the capture follows through the
+  event edges, so an asynchronous reduction becomes a graph branch beside the next phase's kernels and the
+  connector's side stream (cfg.overlap_detached) stays usable under data parallelism.  `cut()` runs inline.
+* 'cut' (any backend; the fallback): the capture is split into consecutive graphs sharing one memory pool and
+  the collective runs eagerly between two replays on buffers that are static across replays (flat gradient
+  buffers; a preallocated gather output).  `cut()` is called by genrl_amd/dp.py's hooks.
 
 The only host-side decision of the reference's iteration — the slow-critic hard copy every
 `slow_target_update` updates (agent/dreamer.py:455-462) — is deferred to after the replay."""
 import torch
 
 _active = None      # the GraphedStep currently capturing (None otherwise)
+_abandoned = []     # graphs whose capture failed: never destroyed (destroying a graph whose stream is still capturing aborts the process)
 
 
 def cut(eager_fn):
     """Run `eager_fn` outside graph capture.  Inside a capture: close the current graph, run the
     function eagerly (and remember it for every replay), open the next graph."""
-    if _active is None:
+    if _active is None or _active.collectives == 'ingraph':
         return eager_fn()
     return _active._cut(eager_fn)
 
 
+def cutting():
+    """True while a capture is running whose collectives are cuts: a cut ends the capture on the capturing stream, so nothing
+    that contains a collective may sit on a forked side stream then (WorldModel.update_additional_detached_modules)"""
+    return _active is not None and _active.collectives == 'cut'
+
+
 class GraphedStep:
-    def __init__(self, agent, batch, step_fn, warmup=3):
-        """batch: dict of device tensors whose storage becomes the graphs' static input."""
+    def __init__(self, agent, batch, step_fn, warmup=3, collectives='cut'):
+        """batch: dict of device tensors whose storage becomes the graphs' static input.
+        collectives: 'cut' (eager between graph segments) or 'ingraph' (captured; RCCL only)."""
         global _active
+        assert collectives in ('cut', 'ingraph')
+        self.collectives = collectives
         self.agent = agent
         self.static_batch = {k: v.clone() for k, v in batch.items()}
         self.step_fn = step_fn
@@ -52,6 +66,7 @@ class GraphedStep:
         torch.cuda.synchronize()
         self.pool = torch.cuda.graph_pool_handle()
         self._g = None
+        steps_before = [g.step for g in self._groups()]
         _active = self
         try:
             with torch.cuda.stream(self.stream):
@@ -66,11 +81,13 @@ class GraphedStep:
         except BaseException:
             # leave no stream in capture mode and no half-built state behind: the caller may fall back to eager steps
             if self._g is not None:
+                _abandoned.append(self._g)
                 try:
                     self._g.capture_end()
                 except Exception:
                     pass
                 self._g = None
+            _abandoned.extend(it for kind, it in self.items if kind == 'graph')
             self.items = []
             ac._defer_slow_target = False
             raise
@@ -79,9 +96,12 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
         # the captured iteration did not execute: undo the host-side bookkeeping its Python ran (optimiser step
-        # counters; the slow-critic cadence is advanced by __call__ only, once per replay)
-        for g in self._groups():
-            g.step -= 1
+        # counters -- per group by what the capture really added: the connector's group steps twice per iteration, SURVEY
+        # Q1 -- ; the slow-critic cadence is advanced by __call__ only, once per replay)
+        self._groups_captured = self._groups()
+        self._step_delta = [g.step - b for g, b in zip(self._groups_captured, steps_before)]
+        for g, d in zip(self._groups_captured, self._step_delta):
+            g.step -= d
 
     def _begin(self):
         self._g = torch.cuda.CUDAGraph()
@@ -110,12 +130,13 @@ class GraphedStep:
                 it.replay()
             else:
                 it()
-        for g in self._groups():
-            g.step += 1
+        for g, d in zip(self._groups_captured, self._step_delta):
+            g.step += d
         self.agent._imag_behavior.update_slow_target()
         return self.metrics
 
     def _groups(self):
+        """every flat optimiser group the iteration steps (the connector's lives in wm.model_opt beside the world model's)"""
         ag = self.agent
         opts = [ag.wm.model_opt, ag._imag_behavior.actor_opt, ag._imag_behavior.critic_opt]
         return [g for o in opts for g in o._groups]

@@ -100,17 +100,27 @@ class ActorTapePlanes(ops.ActorTape):
             tw = _grad_buf(W)
             acc = tw is not None
             dW = tw if acc else torch.empty(U, K, device=dev)
+            # weight gradients: on the same planes through the transposing kernel (genrl_gemm_h2_tn) from TN_MIN_ROWS rows up
+            tn = planes.tn_ok(M, U, K, K)
             if l > 0:
                 x = self.y[l - 1]
-                sgemm(dpre, 1, U, x, 1, K, dW, K, None, U, K, M, accumulate=acc)
+                if tn:
+                    planes.gemm_tn(dpre_p, self.yp[l - 1], dW, K, U, K, M, accumulate=acc)
+                else:
+                    sgemm(dpre, 1, U, x, 1, K, dW, K, None, U, K, M, accumulate=acc)
                 dy = torch.empty(M, K, device=dev)
                 planes.gemm(dpre_p, planes.weight(W, transpose=True), dy, K, None, M, K)
             else:
                 x1, x2 = self.inputs
                 K1, K2 = x1.shape[-1], x2.shape[-1]
                 assert x1.is_contiguous() and x2.is_contiguous() and x1.shape[0] >= H and K1 + K2 == K
-                sgemm(dpre, 1, U, x1, 1, K1, dW, K, None, U, K1, M, accumulate=acc)
-                sgemm(dpre, 1, U, x2, 1, K2, dW, K, None, U, K2, M, c_off=K1, accumulate=acc)
+                sp_ = getattr(self, 'state_planes', None)
+                if tn and sp_ is not None and K1 % 4 == 0:
+                    planes.gemm_tn(dpre_p, sp_[0], dW, K, U, K1, M, accumulate=acc)
+                    planes.gemm_tn(dpre_p, sp_[1], dW, K, U, K2, M, accumulate=acc, c_off=K1)
+                else:
+                    sgemm(dpre, 1, U, x1, 1, K1, dW, K, None, U, K1, M, accumulate=acc)
+                    sgemm(dpre, 1, U, x2, 1, K2, dW, K, None, U, K2, M, c_off=K1, accumulate=acc)
             grads[l] = (None if acc else dW, None if (direct or b is None) else g2, None if direct else g0,
                         None if direct else g1)
         return dWh, dbh, grads
@@ -275,6 +285,8 @@ class _DenseLNActPlanes(Function):
         ctx.save_for_backward(a, c if c is not None else a.new_empty(0), W, gamma, beta, pre, mean, rstd)
         ctx.has2 = c is not None
         ctx.bias = b
+        # the inputs' planes serve the weight gradient again (genrl_gemm_h2_tn): kept with the node
+        ctx.in_planes = ((P1, r1), (P2, r2)) if (P1 is not None and (c is None or P2 is not None)) else None
         ctx.shapes = (x1.shape, x2.shape if x2 is not None else None)
         return y.reshape(*x1.shape[:-1], N)
 
@@ -315,9 +327,15 @@ class _DenseLNActPlanes(Function):
             acc = tgt is not None
             if not acc:
                 dW = tgt = torch.empty(N, K, device=dev)
-            sgemm(dpre, 1, N, a, 1, K1, tgt, K, None, N, K1, M, accumulate=acc)
-            if ctx.has2:
-                sgemm(dpre, 1, N, c, 1, K2, tgt, K, None, N, K2, M, accumulate=acc, c_off=K1)
+            ip = ctx.in_planes
+            if ip is not None and planes.tn_ok(M, N, K1, K) and (not ctx.has2 or K2 % 4 == 0):
+                planes.gemm_tn(dpre_p, ip[0][0], tgt, K, N, K1, M, accumulate=acc, b_row0=ip[0][1])
+                if ctx.has2:
+                    planes.gemm_tn(dpre_p, ip[1][0], tgt, K, N, K2, M, accumulate=acc, b_row0=ip[1][1], c_off=K1)
+            else:
+                sgemm(dpre, 1, N, a, 1, K1, tgt, K, None, N, K1, M, accumulate=acc)
+                if ctx.has2:
+                    sgemm(dpre, 1, N, c, 1, K2, tgt, K, None, N, K2, M, accumulate=acc, c_off=K1)
         if need_p and not direct:
             return d1, d2, dW, (g2 if b is not None else None), g0, g1, None, None, None, None, None, None
         return d1, d2, dW, None, None, None, None, None, None, None, None, None
@@ -340,6 +358,7 @@ class _LinearPlanes(Function):
         ctx.save_for_backward(x2, W)
         ctx.bias = b
         ctx.xshape = x.shape
+        ctx.in_planes = (P, r0)
         return (y if Np == N else y[:, :N]).view(*x.shape[:-1], N)
 
     @staticmethod
@@ -350,16 +369,21 @@ class _LinearPlanes(Function):
         b = ctx.bias
         dy2, ldy = ops._rows_ld(dy.reshape(M, N))        # (a gradient arriving in padded rows is read in place)
         dx = dW = db = None
+        tn = ctx.needs_input_grad[1] and planes.tn_ok(M, N, K, K)
+        dyp = planes.split(dy2) if (ctx.needs_input_grad[0] or tn) else None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dy.device)
-            planes.gemm(planes.split(dy2), planes.weight(W, transpose=True), dx, K, None, M, K)
+            planes.gemm(dyp, planes.weight(W, transpose=True), dx, K, None, M, K)
             dx = dx.reshape(ctx.xshape)
         if ctx.needs_input_grad[1]:
             tgt = _grad_buf(W)
             acc = tgt is not None
             if not acc:
                 dW = tgt = torch.empty(N, K, device=dy.device)
-            sgemm(dy2, 1, ldy, x2, 1, K, tgt, K, None, N, K, M, accumulate=acc)
+            if tn:
+                planes.gemm_tn(dyp, ctx.in_planes[0], tgt, K, N, K, M, accumulate=acc, b_row0=ctx.in_planes[1])
+            else:
+                sgemm(dy2, 1, ldy, x2, 1, K, tgt, K, None, N, K, M, accumulate=acc)
         if b is not None and ctx.needs_input_grad[2]:
             tgt = _grad_buf(b)
             if tgt is not None:

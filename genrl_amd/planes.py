@@ -175,3 +175,34 @@ def gemm_sample(A, B, C, ldc, bias, M, N, q, ldq, unimix, sample, lds, SP=None, 
     if gemm_profile is not None:
         e1 = torch.cuda.Event(enable_timing=True); e1.record()
         gemm_profile.append((M, N, A.cols, e0, e1, 'kk/h2/pipe4'))
+
+
+def gemm_tn(A, B, C, ldc, NI, NJ, M, accumulate=False, a_row0=0, b_row0=0, c_off=0):
+    """C[NI, NJ] (+)= A[a_row0 .. a_row0 + M, :NI]^T B[b_row0 .. b_row0 + M, :NJ]: the weight gradient dW = dY^T X on the planes
+    the row kernels emit for the forward / dgrad products (genrl_gemm_h2_tn: transposing LDS reads, the row scales folded
+    into the fragments).  A, B: Planes handles with >= M rows from their first row; M % 64 == 0."""
+    assert M % 64 == 0 and a_row0 + M <= A.rows and b_row0 + M <= B.rows and NI <= A.ld and NJ <= B.ld, (M, A.rows, B.rows)
+    if gemm_profile is not None:
+        e0 = torch.cuda.Event(enable_timing=True); e0.record()
+    nb = lib().genrl_gemm_h2_tn_ws_bytes(NI, NJ, M)
+    ws = torch.empty(nb + 256, dtype=torch.uint8, device=C.device)
+    wp = (ws.data_ptr() + 255) // 256 * 256
+    check(lib().genrl_gemm_h2_tn(A.ptr(a_row0), A.ld, A.plane, A.inv_ptr(a_row0), B.ptr(b_row0), B.ld, B.plane, B.inv_ptr(b_row0),
+                                 C.data_ptr() + 4 * c_off, ldc, NI, NJ, M, int(accumulate), wp, nb, _stream()), 'gemm_h2_tn')
+    if gemm_profile is not None:
+        e1 = torch.cuda.Event(enable_timing=True); e1.record()
+        gemm_profile.append((NI, NJ, M, e0, e1, 'rr/h2tn/pipe4'))
+
+
+TN_ENABLED = os.environ.get('GENRL_PLANES_WGRAD', '1') != '0'
+
+
+def tn_min_rows():
+    """rows from which weight gradients take the plane kernel (below: few stages per workgroup, the fp32-operand kernels win;
+    GENRL_TN_MIN_ROWS overrides -- the parity tests run it at tiny sizes)"""
+    return int(os.environ.get('GENRL_TN_MIN_ROWS', '2048'))
+
+
+def tn_ok(M, NI, NJ, ldc):
+    """should genrl_gemm_h2_tn take this weight gradient?  (whole 64-row stages; 16-byte output rows for the split-K reduce)"""
+    return ENABLED and TN_ENABLED and M % 64 == 0 and M >= tn_min_rows() and NJ % 4 == 0 and ldc % 4 == 0

@@ -43,13 +43,92 @@ def _conv_in(agent, stoch, stoch_planes=None):
     return ops.linear(x, lin.weight, lin.bias)
 
 
+_CONV_SCORES = ('cosine', 'max_cosine', 'neg_mse', 'exp_neg_mse')
+_SCORES = _CONV_SCORES + ('neg_kl', 'max_like', 'combo')
+
+
+def _features(agent, seq, score_fn, planes_of_stoch=None):
+    """What a score function reads of a sequence, computed ONCE per sequence (the reference re-projects every alignment
+    window): the decoder's input projection of stoch for the distance scores, logits / samples for the
+    distribution scores."""
+    f = {}
+    if score_fn in _CONV_SCORES or score_fn == 'combo':
+        f['conv'] = _conv_in(agent, seq['stoch'], planes_of_stoch)
+    if score_fn in ('neg_kl', 'max_like', 'combo'):
+        f['logit'], f['stoch'] = seq['logit'], seq['stoch']
+    return f
+
+
+def _bcast(t, like):
+    """target features (possibly without the leading time axis) against the agent's: expanded, contiguous"""
+    return t.expand(like.shape).contiguous() if t.shape != like.shape else t
+
+
+def _score(score_fn, fa, ft):
+    """ref :250-277 on precomputed features: fa the agent's (gradient), ft the target's (constant)."""
+    import numpy as np
+    if score_fn == 'combo':
+        return _score('cosine', fa, ft) + _score('neg_kl', fa, ft)
+    if score_fn in _CONV_SCORES:
+        ca = fa['conv']
+        ct = _bcast(ft['conv'].detach(), ca)
+        if score_fn == 'max_cosine':
+            return ops.maxcos(ct, ca)
+        if score_fn == 'cosine':
+            return torch.nn.functional.cosine_similarity(ct, ca, dim=-1)
+        r = -torch.norm(ct - ca, dim=-1) / float(np.sqrt(ca.shape[-1]))
+        return torch.exp(r) if score_fn == 'exp_neg_mse' else r
+    la = fa['logit']
+    if score_fn == 'neg_kl':        # -KL(agent || target) of the unimix categoricals, summed over the latents (ref :262-270)
+        lt = _bcast(ft['logit'].detach(), la)
+        return -ops.cat_kl(la, lt) / float(np.log(la.shape[-1]) * la.shape[-2])
+    if score_fn == 'max_like':      # log-probability of the target's sample under the agent's latent distribution (ref :271-274)
+        K = la.shape[-1]
+        probs = ops.UNIMIX * torch.softmax(la.float(), -1) + (1.0 - ops.UNIMIX) / K
+        logp = torch.log(probs) - torch.log(probs.sum(-1, keepdim=True))
+        return (logp * _bcast(ft['stoch'].detach(), la)).sum((-1, -2))
+    raise NotImplementedError(f'{score_fn} reward not implemented')
+
+
 def compute_reward(agent, agent_seq, target_seq, score_fn='cosine'):  # ref :250-277
-    if score_fn != 'max_cosine':
-        raise NotImplementedError(f'{score_fn}: the GenRL configuration uses max_cosine (agent/genrl.yaml:21)')
+    if score_fn not in _SCORES:
+        raise NotImplementedError(f'{score_fn} reward not implemented')
     with torch.no_grad():
-        conv_target = _conv_in(agent, target_seq['stoch'])
-    conv_agent = _conv_in(agent, agent_seq['stoch'])
-    return ops.maxcos(conv_target, conv_agent)
+        ft = _features(agent, target_seq, score_fn)
+    return _score(score_fn, _features(agent, agent_seq, score_fn), ft)
+
+
+def _shift_target(target, best):
+    """ref :329-337 / :356-364: per row b the target sequence is delayed to start at step best[b] (held at its first entry
+    before): index (t, b) -> max(t - best[b], 0) -- what the reference builds with one_hot + two cumsums + gather."""
+    T, B = target['stoch'].shape[:2]
+    dev = best.device
+    ts = (torch.arange(T, device=dev)[:, None] - best[None, :]).clamp(min=0)
+    cols = torch.arange(B, device=dev)[None, :].expand(T, B)
+    return {k: v[ts, cols] for k, v in target.items()}
+
+
+def _reward_general(agent, seq, target, score_fn, weighted_align, align_initial, align_sequence, n_frames):
+    """Every (score function, alignment) combination of ref :322-368 outside the shipped fast path."""
+    assert not (align_initial and align_sequence), 'Cannot align initial and sequence at the same time'
+    sp = getattr(seq, 'planes', None)
+    fa = _features(agent, seq, score_fn, (sp[0], 0) if (sp and score_fn in _CONV_SCORES) else None)
+    with torch.no_grad():
+        ft = _features(agent, target, score_fn)
+        if align_initial or align_sequence:
+            T = seq['deter'].shape[0]
+            fa_d = {k: v.detach() for k, v in fa.items()}
+            if align_initial:
+                score = _score(score_fn, fa_d, {k: v[0] for k, v in ft.items()})                     # (T, B)
+            else:
+                win = {k: v[:n_frames] for k, v in ft.items()}
+                score = torch.stack([_score(score_fn, {k: v[t:t + n_frames] for k, v in fa_d.items()}, win).mean(0)
+                                     for t in range(T - n_frames)], 0)                                # (T - n_frames, B)
+            if weighted_align:          # (the reference's cumprod runs along dim 1, the ROW axis: kept as is)
+                score = torch.cumprod(0.99 * torch.ones_like(score), dim=1) * score
+            target = _shift_target(target, torch.argmax(score, dim=0))
+            ft = _features(agent, target, score_fn)
+    return _score(score_fn, fa, ft)
 
 
 def _text_feature(agent, task_prompt):
@@ -87,8 +166,6 @@ def video_text_reward(agent, seq, score_fn='cosine', sample_for_target=False, we
                       align_initial=False, align_sequence=False, task_prompt='', skip_first_target=False, **kwargs):
     """ref :279-370.  The per-window conv_in projections of the reference (9x redundant)
     are computed once; alignment + final max-cosine reward run in two HIP kernels."""
-    if score_fn != 'max_cosine' or weighted_align or align_initial:
-        raise NotImplementedError('only the shipped configuration (max_cosine, align_sequence) is implemented')
     n_frames = agent.wm.connector.n_frames
     T, B = seq['deter'].shape[:2]
     if not hasattr(agent, 'unconditional_target'):      # computed once, never refreshed (SURVEY Q10)
@@ -98,6 +175,10 @@ def video_text_reward(agent, seq, score_fn='cosine', sample_for_target=False, we
         agent.unconditional_target = _build_target(agent, _text_feature(agent, task_prompt), T, B,
                                                    sample_for_target, skip_first_target)
     target = agent.unconditional_target
+    if score_fn != 'max_cosine' or weighted_align or align_initial:
+        # the other score functions / alignments of the reference (ref :250-277, :322-343): composed from the same HIP ops
+        # (decoder projection, KL, max-cosine) and torch elementwise glue -- off the shipped configuration, not tuned
+        return _reward_general(agent, seq, target, score_fn, weighted_align, align_initial, align_sequence, n_frames).unsqueeze(-1)
     if not hasattr(agent, '_target_stoch_planes'):       # (the target never changes: split once)
         t2 = target['stoch'].reshape(-1, target['stoch'].shape[-2] * target['stoch'].shape[-1]).float().contiguous()
         ok = planes.ENABLED and t2.is_cuda and t2.shape[0] >= ops_planes.min_rows()

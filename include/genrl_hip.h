@@ -90,6 +90,16 @@ int genrl_gemm_h2_sample(const uint16_t* a0, long a0_ld, long a0_plane, const fl
                          long b0_plane, const float* b0_inv, int k0, float* C, long ldc, const float* bias, int M, int N,
                          const float* q, long ldq, float unimix, float* sample, long lds, uint16_t* sp, long sld, long splane,
                          float* sinv, void* stream);
+/* Weight-gradient product on the SAME planes (csrc/gemm_planes_tn.hip):  C[i, j] (+)= sum_m A(m, i) B(m, j) for h2 planes
+ * A [2][M][a_ld] (columns i < NI) and B [2][M][b_ld] (columns j < NJ) with per-row inverse scales a_inv[M], b_inv[M] -- dW = dY^T X
+ * (agent/dreamer_utils.py:739-747 backward) read against the planes' storage order through the transposing LDS read
+ * ds_read_b64_tr_b16, the row scales (which sit inside the sum) folded into one operand's fragments as exact powers of two;
+ * deterministic split-K over m.  M % 64 == 0; a_ld, b_ld % 64 == 0; with more than one split NJ % 4 == ldc % 4 == 0.
+ * ws: genrl_gemm_h2_tn_ws_bytes(NI, NJ, M) bytes of device workspace, 256-byte aligned. */
+long genrl_gemm_h2_tn_ws_bytes(int NI, int NJ, int M);
+int genrl_gemm_h2_tn(const uint16_t* a, long a_ld, long a_plane, const float* a_inv, const uint16_t* b, long b_ld, long b_plane,
+                     const float* b_inv, float* C, long ldc, int NI, int NJ, int M, int accumulate, void* ws, long ws_bytes,
+                     void* stream);
 /* the same for n matrices in one launch set (row splits: one launch; transposed splits: two) -- all weights of an optimiser group
  * after its step.  Descriptors are read on the host at call time. */
 typedef struct {

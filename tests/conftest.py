@@ -16,3 +16,6 @@ def pytest_configure(config):
 # reference's vectors; test_gpu_planes.py::test_small_rollouts_take_the_fp32_operand_path covers the default policy and the
 # fp32-operand rollout (ops._Rollout).
 os.environ.setdefault('GENRL_PLANES_MIN_ROWS', '0')
+# likewise the weight gradients on plane operands (genrl_gemm_h2_tn, from 2048 rows up by default): every product with a whole
+# number of 64-row stages takes it in the suite
+os.environ.setdefault('GENRL_TN_MIN_ROWS', '64')

@@ -149,3 +149,4 @@ def test_dp2_product_path_equals_dp1():
         assert np.array_equal(rank_g[0]['ema'], rank_e[1]['ema'])
     for k in GLOBAL:                                        # third step, graphed only: still in step with DP-1
         assert rel(g0[1]['metrics'][k], ref_g[1]['metrics'][k]) <= 1e-4, k
+

@@ -1,0 +1,124 @@
+"""Multi-step parity at FULL width: three consecutive training iterations (c1 size: B4 x T16, default widths, the real
+learning rates) through the product -- plane operands on, eager and as a replayed hipGraph -- against the CPU oracle chained
+over the same three iterations with apply_updates=True (oracle/iteration.py), i.e. through Optimizer.__call__
+(agent/dreamer_utils.py:892-932: clip, decay, Adam with its step count), the plane-cache invalidation after every Adam step and
+the slow-critic hard copy (agent/dreamer.py:455-462; slow_target_update=2 puts two copy boundaries inside the three steps).
+Both sides consume the SAME noise: genrl_amd.noise.static hands every site one fixed tensor, which the test reads back and
+feeds to the oracle.  Pinned: every metric of steps 1-3 within 1e-3; the per-group parameter deltas after three steps within
+SURVEY 8(c)'s bound (Adam's first steps are ~lr * sign(g): a near-zero gradient may flip under reassociation, so elementwise
+|delta_product - delta_oracle| <= 2 lr per step taken, and the groups' deltas agree to a few percent in L1); the slow critic
+equals the critic where the copy fell."""
+import numpy as np
+import pytest
+import torch
+
+import detgen
+from oracle import genrl_oracle as O
+from oracle.iteration import run_iteration, group_names
+from param_shapes import agent_param_shapes
+
+pytestmark = pytest.mark.gpu
+B, T, A, H, SEED, STEPS, SLOW = 4, 16, 10, 16, 21, 3, 2
+
+
+class FakeClip:
+    def get_txt_feat(self, text):
+        g = torch.Generator().manual_seed(123)
+        return torch.nn.functional.normalize(torch.randn(1, 512, generator=g), dim=-1)
+
+
+def _product(graphed, cache, p0, batch_cpu):
+    from genrl_amd import config, noise
+    from genrl_amd.graph import GraphedStep
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import one_step
+    cfg = config.default_cfg(B, T, device='cuda', slow_target_update=SLOW)
+    ag = config.make_agent(cfg, act_dim=A)
+    ag.load_state_dict({k: v.cuda() for k, v in p0.items()})
+    ag.wm.viclip_model = FakeClip()
+    batch = {k: v.cuda() for k, v in batch_cpu.items()}
+    mets = []
+    grab = lambda m: {k: float(torch.as_tensor(v).detach()) for k, v in m.items()}
+    with noise.static(seed=SEED, cache=cache):
+        if graphed:
+            gs = GraphedStep(ag, batch, one_step, warmup=1)          # step 1 = the warm-up (eager), then two replays
+            mets.append(None)
+            for _ in range(STEPS - 1):
+                m = gs(); torch.cuda.synchronize(); mets.append(grab(m))
+        else:
+            for _ in range(STEPS):
+                m = one_step(ag, batch); torch.cuda.synchronize(); mets.append(grab(m))
+    return mets, {k: v.detach().cpu() for k, v in ag.state_dict().items()}
+
+
+def _oracle_noise(cache, S, K):
+    """the fixed per-site tensors the product consumed -> the oracle's named noise (detgen.iteration_noise's layout)"""
+    by = {site: t.cpu() for (site, shape), t in cache.items()}
+    N, G = B * T, T // 8
+    dummy = torch.ones(T, B * S, K)            # the connector's per-step prior samples are never read (teacher forcing)
+    conn = dict(clip_eps=by['conn.clip_eps'], init_q=by['conn.init_q'], step_q=dummy, ikl_init_q=by['conn.ikl_init_q'],
+                ikl_step_q=by['conn.ikl_step_q'])
+    return dict(wm=dict(prior_q=by['wm.prior_q'], post_q=by['wm.post_q']), conn1=conn, conn2=conn,
+                imag=dict(act_eps0=torch.zeros(N, A), act_eps=by['imag.act_eps'], step_q=by['imag.step_q'],
+                          target_init_q=by['imag.target_init_q']))
+
+
+def test_three_full_width_steps_vs_chained_oracle():
+    if not torch.cuda.is_available():
+        pytest.skip('needs MI355X')
+    ocfg = O.make_cfg(act_dim=A, horizon=H)
+    S, K = ocfg.stoch, ocfg.discrete
+    p0 = detgen.det_state_dict(agent_param_shapes(ocfg), SEED)
+    batch_cpu = {k: torch.from_numpy(v) for k, v in detgen.det_batch(B, T, A=A, seed=SEED).items()}
+    cache = {}
+    m_eager, sd_eager = _product(False, cache, p0, batch_cpu)
+    m_graph, sd_graph = _product(True, cache, p0, batch_cpu)
+    # ---- the oracle, chained
+    noise = _oracle_noise(cache, S, K)
+    text = FakeClip().get_txt_feat('')
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    p, opt_state, tcache, m_or = dict(p0), None, None, []
+    tc = [n for n in p0 if n.startswith('_imag_behavior._target_critic.')]
+    for i in range(STEPS):
+        res = run_iteration(p, ocfg, batch_cpu, noise, text, opt_state=opt_state, apply_updates=True, target_cache=tcache)
+        p, opt_state, tcache = res['p'], res['opt_state'], res['target_cache']
+        if i % SLOW == 0:                       # update_slow_target after the i-th update (agent/dreamer.py:455-462), hard copy
+            for n in tc:
+                p[n] = p[n.replace('_target_critic', 'critic')].clone()
+        m_or.append({k: float(v) for k, v in res['metrics'].items()})
+    # ---- metrics of every step
+    for name, mets in (('eager', m_eager), ('graph', m_graph)):
+        for i in range(STEPS):
+            if mets[i] is None:
+                continue
+            for k, v in m_or[i].items():
+                if k not in mets[i]:
+                    continue
+                tol = 1e-3 * abs(v) + 2e-6
+                assert abs(mets[i][k] - v) <= tol, (name, i, k, mets[i][k], v)
+    assert all(k in m_eager[0] for k in ('model_loss', 'imag_actor_loss', 'imag_critic_loss', 'connector_model_loss'))
+    # graph replay == eager, bit for bit (same noise, same arithmetic)
+    for i in (1, 2):
+        for k, v in m_eager[i].items():
+            assert m_graph[i][k] == v, (i, k, m_graph[i][k], v)
+    for k in sd_eager:
+        assert torch.equal(sd_eager[k], sd_graph[k]), k
+    # ---- parameter deltas after three steps, per optimiser group
+    groups = group_names(p0)
+    lrs = dict(wm=ocfg.model_opt['lr'], conn=ocfg.model_opt['lr'], actor=ocfg.actor_opt['lr'], critic=ocfg.critic_opt['lr'])
+    nsteps = dict(wm=STEPS, conn=2 * STEPS, actor=STEPS, critic=STEPS)
+    for gname, names in groups.items():
+        num = den = 0.0
+        for n in names:
+            dp = (sd_eager[n] - p0[n]).double(); do = (p[n] - p0[n]).double()
+            worst = float((dp - do).abs().max())
+            assert worst <= 2.0 * lrs[gname] * nsteps[gname] * 1.05 + 1e-7, (gname, n, worst)
+            num += float((dp - do).abs().sum()); den += float(do.abs().sum())
+        assert den > 0 and num / den <= 0.05, (gname, num / den)
+    # ---- slow critic: hard copies fell after updates 0 and 2 -> it equals the critic now, exactly, and tracks the oracle's
+    for n in tc:
+        assert torch.equal(sd_eager[n], sd_eager[n.replace('_target_critic', 'critic')]), n
+        assert float((sd_eager[n] - p[n]).abs().max()) <= 2.0 * lrs['critic'] * STEPS * 1.05 + 1e-7, n
+    ema_or = p['_imag_behavior.ema_vals']
+    assert torch.allclose(sd_eager['_imag_behavior.ema_vals'], ema_or, rtol=1e-3, atol=1e-6)

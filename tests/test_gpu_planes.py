@@ -392,3 +392,82 @@ def test_noise_arena_slices_are_disjoint_and_replanned():
     assert tuple(third[2].shape) == (5,) and (third[2] > 0).all()
     fourth = step(shapes[:2] + [('exp', (5,))])         # ... and is the plan now
     assert noise._flat['exp'][0].data_ptr() <= fourth[2].data_ptr() < noise._flat['exp'][0].data_ptr() + 4 * noise._flat['exp'][0].numel()
+
+
+@pytest.mark.parametrize('M,NI,NJ', [(512, 128, 128), (1024, 1024, 1024), (16384, 1024, 1024), (2048, 1024, 2048), (1024, 3072, 1024),
+                                     (4096, 200, 520), (640, 1024, 1536), (17408, 256, 1024), (64, 32, 16), (1088, 255, 1024),
+                                     (192, 32, 48)])
+@pytest.mark.parametrize('decades', [6, 20])
+def test_gemm_h2_tn_weight_gradient_vs_float64(env, M, NI, NJ, decades):
+    """genrl_gemm_h2_tn (csrc/gemm_planes_tn.hip): dW = dY^T X on the row-scaled planes of dY and X, the reduction over the ROW index
+    -- transposing LDS reads, the row scales (inside the sum) folded into the fragments -- against float64, every output against
+    ITS OWN sum of |terms|.  Row magnitudes spread over 2^+-6 per operand (what gradients and activations do) must stay within
+    1e-6; over 2^+-20 per operand (products over 80 binary orders: rows more than 2^14 below the largest lose bits of their
+    relative precision, rows more than 2^24 below vanish -- their whole contribution is smaller than the largest row's rounding)
+    within 4e-6.  Odd and single stage counts, accumulate, ragged tiles, every split-K count, bit-reproducibility."""
+    planes, ops, L, check = env
+    g = torch.Generator(device='cuda').manual_seed(M + NI + NJ)
+    rs = torch.exp2(torch.randint(-decades, decades + 1, (M, 1), device='cuda', generator=g).float())        # per-row magnitudes
+    dY = torch.randn(M, NI, device='cuda', generator=g) * rs * 1e-3
+    X = torch.randn(M, NJ, device='cuda', generator=g) / rs.flip(0) * 3.0
+    dY[5] = 0.0; X[7] = 0.0                                        # all-zero rows (a finite scale, zero planes)
+    pa, pb = planes.split(dY), planes.split(X)
+    ldc = NJ + 4
+    C0 = torch.randn(NI, ldc, device='cuda', generator=g)
+    ref = dY.double().t() @ X.double()
+    asum = dY.double().abs().t() @ X.double().abs()
+    k = 1e-6 if decades <= 6 else 4e-6
+    bound = k * asum + 0.02 * k * asum.mean()
+    for acc in (False, True):
+        C = C0.clone()
+        planes.gemm_tn(pa, pb, C, ldc, NI, NJ, M, accumulate=acc)
+        want = ref + (C0[:, :NJ].double() if acc else 0.0)
+        err = (C[:, :NJ].double() - want).abs()
+        tol = bound + (2e-7 * C0[:, :NJ].double().abs() if acc else 0.0)
+        assert (err <= tol).all(), (acc, (err / tol).max().item())
+        assert torch.equal(C[:, NJ:], C0[:, NJ:])                  # padding columns untouched
+    # bit-reproducible (fixed split-K order)
+    Cb = C0.clone(); planes.gemm_tn(pa, pb, Cb, ldc, NI, NJ, M, accumulate=True)
+    assert torch.equal(Cb, C)
+
+
+def test_gemm_h2_tn_row_blocks_of_a_rollout(env):
+    """operands that are row ranges of larger plane sets (a rollout's time-major states: rows h * N + n) and an output that is a
+    column block of a wider weight gradient"""
+    planes, ops, L, check = env
+    g = torch.Generator(device='cuda').manual_seed(3)
+    Mtot, M, NI, NJ, K = 1024 + 128, 1024, 256, 192, 512
+    dY = torch.randn(Mtot, NI, device='cuda', generator=g)
+    X = torch.randn(Mtot, NJ, device='cuda', generator=g)
+    pa, pb = planes.split(dY), planes.split(X)
+    dW = torch.zeros(NI, K, device='cuda')
+    planes.gemm_tn(pa, pb, dW, K, NI, NJ, M, a_row0=64, b_row0=128, c_off=256)
+    ref = dY[64:64 + M].double().t() @ X[128:128 + M].double()
+    err = (dW[:, 256:256 + NJ].double() - ref).abs().max().item() / (dY.abs().double().t() @ X.abs().double()).mean().item()
+    assert err < 2e-6, err
+    assert (dW[:, :256] == 0).all() and (dW[:, 256 + NJ:] == 0).all()
+
+
+def test_gemm_h2_tn_all_zero_gradient_gives_exact_zero(env):
+    """a zero-initialised output layer (agent/dreamer.py:143-145,357-359) makes every gradient row of the trunk in front of it
+    EXACTLY zero on the first step: the rows' inverse scales are 2^-123, their products with the activations' scales leave
+    fp32's range -- the weight gradient must come out as 0, not NaN"""
+    planes, ops, L, check = env
+    g = torch.Generator(device='cuda').manual_seed(9)
+    M, NI, NJ = 1024, 256, 512
+    dY = torch.zeros(M, NI, device='cuda')
+    X = torch.randn(M, NJ, device='cuda', generator=g)
+    C0 = torch.randn(NI, NJ, device='cuda', generator=g)
+    C = C0.clone()
+    planes.gemm_tn(planes.split(dY), planes.split(X), C, NJ, NI, NJ, M, accumulate=True)
+    assert torch.equal(C, C0)
+    C = torch.full((NI, NJ), float('nan'), device='cuda')
+    planes.gemm_tn(planes.split(dY), planes.split(X), C, NJ, NI, NJ, M)
+    assert (C == 0).all()
+    # half of the rows zero, the others not: the zero rows must not disturb the rest
+    dY[::2] = torch.randn(M // 2, NI, device='cuda', generator=g) * 1e-4
+    C = torch.empty(NI, NJ, device='cuda')
+    planes.gemm_tn(planes.split(dY), planes.split(X), C, NJ, NI, NJ, M)
+    ref = dY.double().t() @ X.double()
+    asum = dY.double().abs().t() @ X.double().abs()
+    assert ((C.double() - ref).abs() <= 1e-6 * asum + 1e-8 * asum.mean()).all()

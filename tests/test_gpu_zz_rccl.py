@@ -1,0 +1,95 @@
+"""RCCL on the one GPU a test box has (runs last: the file name sorts behind the other GPU tests)."""
+import os, sys
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class Clip:
+    def get_txt_feat(self, text):
+        g = torch.Generator().manual_seed(123)
+        return torch.nn.functional.normalize(torch.randn(1, 512, generator=g), dim=-1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# RCCL on the one GPU a test box has: a 1-rank "nccl" process group drives the REAL dp hooks (dp.install(force=True)) -- the
+# asynchronous all-reduces, the all-gather of the returns, the connector's side stream under data parallelism
+# (Optimizer.overlap_under_dp) -- eagerly, with the collectives captured INSIDE the hipGraph ('ingraph') and as cuts between
+# graph segments.  A 1-rank reduction is the identity, so every variant must reproduce the plain single-process iteration
+# bit for bit; what this pins is that RCCL work objects, their stream edges and torch's capture of them behave on this ROCm build
+# before the driver's multi-GPU run meets them.
+
+def _rccl_worker(port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import torch.distributed as dist
+    from genrl_amd import config, dp, noise
+    from genrl_amd.agent import dreamer_utils as common
+    from genrl_amd.graph import GraphedStep
+    from bench import synth_batch, one_step
+    try:
+        torch.cuda.set_device(0)
+        over = dict(config.tiny_overrides(), overlap_detached=True)
+        full = {k: torch.from_numpy(v) for k, v in synth_batch(4, 16, seed=2).items()}
+
+        def run(mode, steps=3):
+            torch.manual_seed(0)
+            cfg = config.default_cfg(4, 16, device='cuda', **over)
+            ag = config.make_agent(cfg); ag.wm.viclip_model = Clip()
+            batch = {k: v.cuda() for k, v in full.items()}
+            out = []
+            with noise.static(seed=11):
+                if mode == 'eager':
+                    for _ in range(steps):
+                        m = one_step(ag, batch); torch.cuda.synchronize()
+                        out.append({k: float(torch.as_tensor(v).detach()) for k, v in m.items()})
+                    return out, 0
+                gs = GraphedStep(ag, batch, one_step, warmup=1, collectives=mode)
+                for _ in range(steps - 1):
+                    m = gs(); torch.cuda.synchronize()
+                    out.append({k: float(torch.as_tensor(v).detach()) for k, v in m.items()})
+                return out, sum(1 for k, _ in gs.items if k == 'graph')
+        ref, _ = run('eager')                                  # no process group, no hooks
+        dist.init_process_group('nccl', rank=0, world_size=1)
+        dp.install(common.Optimizer, common.RewardEMA, force=True)
+        assert common.Optimizer.grad_reduce is not None and common.Optimizer.overlap_under_dp
+        eager, _ = run('eager')
+        ingraph, n_in = run('ingraph')
+        cut, n_cut = run('cut')
+        dp.uninstall(common.Optimizer, common.RewardEMA)
+        dist.destroy_process_group()
+        q.put(('ok', ref, eager, ingraph, cut, n_in, n_cut))
+    except BaseException:
+        import traceback
+        q.put(('error', traceback.format_exc()))
+        raise
+
+
+def test_rccl_one_rank_eager_ingraph_and_cut():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p_ = ctx.Process(target=_rccl_worker, args=(29650 + os.getpid() % 100, q))
+    p_.start()
+    try:
+        item = q.get(timeout=150)
+        assert item[0] == 'ok', item[1]
+        p_.join(timeout=60)
+    finally:
+        if p_.is_alive():
+            p_.terminate()
+    _, ref, eager, ingraph, cut, n_in, n_cut = item
+    assert n_in == 1, n_in                 # every collective inside the one captured graph
+    assert n_cut > 1, n_cut                # the fallback really cuts
+    for step in range(3):
+        for k, v in ref[step].items():
+            assert np.isfinite(v), (step, k)
+            assert eager[step][k] == v, ('eager', step, k, eager[step][k], v)
+    for step in (1, 2):                    # replays = eager steps 2 and 3 (step 1 was the warm-up)
+        for k, v in ref[step].items():
+            assert ingraph[step - 1][k] == v, ('ingraph', step, k, ingraph[step - 1][k], v)
+            assert cut[step - 1][k] == v, ('cut', step, k, cut[step - 1][k], v)
