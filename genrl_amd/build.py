@@ -2,7 +2,7 @@
 import os, subprocess, sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = ['gemm.hip', 'gemm_planes.hip', 'gemm_planes_tn.hip', 'rowops.hip', 'dist.hip', 'conv.hip', 'optim.hip', 'stats.hip']
+SRC = ['gemm.hip', 'gemm_planes.hip', 'gemm_planes_tn.hip', 'scan_coop.hip', 'rowops.hip', 'dist.hip', 'conv.hip', 'optim.hip', 'stats.hip']
 OUT = os.path.join(HERE, 'libgenrl_hip.so')
 
 

@@ -1432,6 +1432,18 @@ def gru_step(x, h, W, gamma, beta):
     return _GRUStep.apply(x, h, W, gamma, beta)
 
 
+def scan_coop_variant(B, D, T):
+    """0: the per-step launches (default); 1 / 2: the persistent scan kernel with one / two grid barriers per step
+    (GENRL_SCAN_COOP=1|2|auto; auto = one barrier where it exists (B <= 8), else two)"""
+    mode = os.environ.get('GENRL_SCAN_COOP', '0')
+    if mode in ('', '0') or D % 4 or not (8 <= D // 4 <= 256) or B not in (4, 8, 16, 32):
+        return 0
+    if mode == 'auto':
+        return 1 if B <= 8 else 2
+    v = int(mode)
+    return v if (v == 2 or B <= 8) else 0
+
+
 class _GRUSeq(Function):
     """The whole GRU recurrence of EnsembleRSSM.observe / VideoSSM.update over T steps with the
     non-recurrent half hoisted: pre_x = x W_x^T for all T at once; per step only
@@ -1457,7 +1469,15 @@ class _GRUSeq(Function):
         else:
             hm = None
         BD, B3D = B * D, B * 3 * D
-        for t in range(T):
+        variant = scan_coop_variant(B, D, T)
+        if variant:
+            # the whole recurrence in ONE persistent launch (csrc/scan_coop.hip): W_h resident in LDS, grid barriers per step
+            ws = torch.empty(lib().genrl_gru_scan_coop_ws_floats(B, D) + 64, device=dev)
+            wsp = (ws.data_ptr() + 255) // 256 * 256
+            check(lib().genrl_gru_scan_coop(_p(pre), W.data_ptr() + 4 * I, K, _p(gamma), _p(beta), _p(h0), _p(mask), _p(out),
+                                            _p(hm), _p(mean), _p(rstd), wsp, T, B, D, 1e-5, variant, _stream()), 'gru_scan_coop')
+            ctx._coop_ws = ws
+        for t in (range(T) if not variant else ()):
             if hm is not None:
                 hprev, hoff = hm, t * BD
             else:

@@ -90,6 +90,23 @@ int genrl_gemm_h2_sample(const uint16_t* a0, long a0_ld, long a0_plane, const fl
                          long b0_plane, const float* b0_inv, int k0, float* C, long ldc, const float* bias, int M, int N,
                          const float* q, long ldq, float unimix, float* sample, long lds, uint16_t* sp, long sld, long splane,
                          float* sinv, void* stream);
+/* State-resident GRU scan, forward (csrc/scan_coop.hip): the recurrence of EnsembleRSSM.observe / VideoSSM.update
+ * (agent/dreamer_utils.py:362-371,771-785) over T steps in ONE persistent launch -- D/4 workgroups, each with its 12 columns of
+ * the recurrent weight block W_h (rows 0 .. 3D-1, columns 0 .. D-1, row stride ldw) resident in LDS for the whole sequence, the
+ * LayerNorm statistics and the new state exchanged behind XCD-hierarchical grid barriers.  pre (T, B, 3D) holds x W_x^T on entry
+ * and the full pre-LayerNorm values on return; out (T, B, D); hm (T, B, D) = masked previous states when mask (T, B) != NULL
+ * (hm[0] = mask[0] * h0 is the caller's); mean / rstd (T, B): exactly what the backward (genrl_gru_gates_bwd per step) reads.
+ * variant 2: two grid barriers per step, B in {4, 8, 16, 32}; variant 1: one barrier per step (every workgroup evaluates all
+ * gates, state in LDS), B in {4, 8}.  D % 4 == 0, 8 <= D/4 <= 256 workgroups that must all be resident.  ws:
+ * genrl_gru_scan_coop_ws_floats(B, D) floats, 256-byte aligned; ws word 416 (uint32) != 0 afterwards: a barrier timed out
+ * (bounded spins: the launch ends early instead of hanging). */
+long genrl_gru_scan_coop_ws_floats(int B, int D);
+/* n XCD-hierarchical grid barriers over G <= 256 workgroups and nothing else (ws: >= 1088 floats, 256-byte aligned): the floor
+ * under any per-step exchange of a persistent kernel (scripts/scan_proto.py) */
+int genrl_grid_barrier_bench(float* ws, int n, int G, void* stream);
+int genrl_gru_scan_coop(float* pre, const float* Wh, long ldw, const float* gamma, const float* beta, const float* h0,
+                        const float* mask, float* out, float* hm, float* mean, float* rstd, float* ws, int T, int B, int D,
+                        float eps, int variant, void* stream);
 /* Weight-gradient product on the SAME planes (csrc/gemm_planes_tn.hip):  C[i, j] (+)= sum_m A(m, i) B(m, j) for h2 planes
  * A [2][M][a_ld] (columns i < NI) and B [2][M][b_ld] (columns j < NJ) with per-row inverse scales a_inv[M], b_inv[M] -- dW = dY^T X
  * (agent/dreamer_utils.py:739-747 backward) read against the planes' storage order through the transposing LDS read
