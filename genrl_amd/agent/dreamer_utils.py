@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 import os
-from .. import noise, ops, ops_planes, streams
+from .. import noise, ops, ops_conv_planes, ops_planes, streams
 from .. import planes as pl          # (module; `planes=` below are operand handles)
 
 
@@ -370,9 +370,10 @@ class Encoder(Module):  # ref :558-628
         """x: uint8 NCHW frames (x/255-0.5 fused into the first layer's patch gather) or float NCHW."""
         if x.dtype != torch.uint8:
             x = x.permute(0, 2, 3, 1).contiguous()
+        conv2d = ops_conv_planes.conv2d_s2 if ops_conv_planes.active(x) else ops.conv2d_s2     # (products on h2 planes where they fit)
         for i in range(len(self._cnn_kernels)):
             conv, ln = self._conv_model[3 * i], self._conv_model[3 * i + 1]
-            x = ops.conv2d_s2(x, conv.weight, conv.bias, ln=(ln.norm.weight, ln.norm.bias, ln.norm.eps))
+            x = conv2d(x, conv.weight, conv.bias, ln=(ln.norm.weight, ln.norm.bias, ln.norm.eps))
         n, h, w, c = x.shape
         return ops.transpose_last2(x.reshape(n, h * w, c)).reshape(n, c * h * w)    # NCHW flatten, ref :621
 
@@ -410,11 +411,12 @@ class Decoder(Module):  # ref :631-715
         x = ops.linear(features.reshape(-1, features.shape[-1]), self._conv_in[0].weight, self._conv_in[0].bias)
         x = x.reshape(-1, 1, 1, 32 * self._cnn_depth)             # NHWC with 1x1 pixels
         n = len(self._cnn_kernels)
+        convT2d = ops_conv_planes.convT2d_s2 if ops_conv_planes.active(x) else ops.convT2d_s2
         for i in range(n):
             conv = self._conv_model[3 * i]
             if i != n - 1:
                 ln = self._conv_model[3 * i + 1]
-                x = ops.convT2d_s2(x, conv.weight, conv.bias, ln=(ln.norm.weight, ln.norm.bias, ln.norm.eps))
+                x = convT2d(x, conv.weight, conv.bias, ln=(ln.norm.weight, ln.norm.bias, ln.norm.eps))
             else:
                 x = ops.convT2d_s2(x, conv.weight, conv.bias, out_nchw=True)     # frames leave in the reference's NCHW
         return {key: MSEDist(x.reshape(tuple(lead) + tuple(x.shape[1:]))) for key in self.channels}

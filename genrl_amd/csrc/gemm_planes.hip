@@ -67,6 +67,15 @@ struct SampleEpi {
   float a;                 // unimix weight of the softmax (0.99)
 };
 
+// Implicit stride-2 convolution operand (CONV kernels): segment 0's A is not a matrix in memory but the patch matrix of an NHWC
+// image held as UNIFORM-scale planes [pixel][ld] (channel fastest, ld >= C, one scale for the whole tensor -- a patch row spans
+// k x k pixel rows): A(m, kk) = img[n][2 oy + kh][2 ox + kw][c], m = (n, oy, ox), kk = (kh k + kw) C + c.  The DMA's per-lane source
+// address does the gather (16-byte chunks = 8 channels of one pixel; C % 8 == 0); chunks beyond K = k k C re-read the last valid
+// one (finite data against the zero padding of the weight planes).
+struct ConvGather {
+  int H, W, C, k, Ho, Wo, K;     // image height / width / channels, kernel size, output height / width, k k C
+};
+
 // a / b for exact powers of two (exponent arithmetic; clamped to the normal range)
 __device__ __forceinline__ float pow2_ratio(float a, float b) {
   const int ea = (int)((__builtin_bit_cast(unsigned, a) >> 23) & 255u), eb = (int)((__builtin_bit_cast(unsigned, b) >> 23) & 255u);
@@ -83,10 +92,10 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 
 // TM x TN 32x32 blocks per wave (2x2 waves per workgroup); BK = 64 (TM*TN == 1) or 32; NACC class accumulators;
 // FMT 0: x3 (three bf16 planes, six products), 1: h2 (two fp16 planes of the row-scaled value, three products); NS LDS stages
-template <int TM, int TN, int BK, int NACC, int FMT, int NS, bool FOLD = true>
+template <int TM, int TN, int BK, int NACC, int FMT, int NS, bool FOLD = true, bool CONV = false>
 __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneSeg s1, float* __restrict__ C, long ldc,
                                                          const float* __restrict__ bias, int M, int N, int accumulate,
-                                                         int tiles_m, int tiles_n, int xcd_m, SampleEpi smp) {
+                                                         int tiles_m, int tiles_n, int xcd_m, SampleEpi smp, ConvGather cg) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int NPL = FMT ? 2 : 3, NPROD = FMT ? 3 : 6;
   constexpr int ROWB = BK * 2;                         // bytes per tile row per plane
@@ -146,6 +155,34 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
       voff[i] = (unsigned)((p * plane + (long)min(r0 + row, rows_total - 1) * ld) * 2 + ((slot ^ f) << 4));
     }
   };
+  // CONV, A waves: voff[i] = byte offset of the patch's first pixel row (plane, image, 2 oy, 2 ox) for the tile row of piece i;
+  // the chunk's place inside the patch -- tap (kh, kw) and channel -- is the same for all pieces of one parity (the swizzle
+  // depends on the tile row through (row >> 1) & 7 = 4 (i & 1) + (r_in >> 1)): two running states, advanced by 64 k per stage
+  unsigned koff[2] = {0u, 0u};                      // byte offset of the chunk inside the patch: ((kh W + kw) ld + ch) * 2
+  int kch[2] = {0, 0}, kkw[2] = {0, 0}, kkk[2] = {0, 0};
+  if constexpr (CONV) {
+    if (!isB) {
+      const long ld = s0.a_ld, plane = s0.a_plane;
+      gbase = reinterpret_cast<const char*>(s0.a);
+#pragma unroll
+      for (int i = 0; i < NPMAX; ++i) {
+        const int q = (wave & 1) * npieces + i;
+        const int p = q / gpp, row = (q % gpp) * RPC + r_in;
+        const int m = min(m0 + row, M - 1);
+        const int n_img = m / (cg.Ho * cg.Wo), rem = m - n_img * (cg.Ho * cg.Wo);
+        const int oy = rem / cg.Wo, ox = rem - oy * cg.Wo;
+        voff[i] = (unsigned)(((long)p * plane + ((long)(n_img * cg.H + 2 * oy) * cg.W + 2 * ox) * ld) * 2);
+      }
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const int f = (4 * par + (r_in >> 1)) & 7;
+        const int kk = 8 * (slot ^ f);
+        const int tap = kk / cg.C, ch = kk - tap * cg.C, kh = tap / cg.k, kw = tap - kh * cg.k;
+        kkk[par] = kk; kch[par] = ch; kkw[par] = kw;
+        koff[par] = (unsigned)((((long)kh * cg.W + kw) * ld + ch) * 2);
+      }
+    }
+  }
   const unsigned piece0 = lds0 + (isB ? A_BYTES : 0) + (wave & 1) * npieces * 1024;
   // ---- fragment side
   const int l32 = lane & 31, h32 = lane >> 5;
@@ -208,19 +245,50 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
   const int nk0 = s0.k / BK, nk = nk0 + s1.k / BK;
   static_assert(NPA == NPB, "square wave grids only (one DMA count per wave)");
   constexpr int NP = NPA;
-  setup(s0);
+  if (!(CONV && !isB)) setup(s0);
   int seg_left = nk0, left = nk;      // stages of the current segment / of the product still to be issued
   // Every stage slot is issued unconditionally (one basic block per iteration, uniform vmcnt counts): once the
   // product's stages are used up the pointers stop advancing and the DMAs re-read the last stage into buffers that
   // nobody reads.
   bool first = true;
   auto next_stage = [&]() __attribute__((always_inline)) {          // called before a stage's DMAs are issued
+    if constexpr (CONV) {
+      if (!isB) {                                                    // (wave-uniform) advance both chunk states by 64 k
+        if (!first && left > 0) {
+          const unsigned ld2 = (unsigned)(s0.a_ld * 2);
+#pragma unroll
+          for (int par = 0; par < 2; ++par) {
+            if (kkk[par] + 64 + 8 <= cg.K) {                       // else: stay on the last valid chunk (zero weights there)
+              kkk[par] += 64;
+              int ch = kch[par] + 64, kw = kkw[par];
+              unsigned off = koff[par] + 128u;
+#pragma unroll
+              for (int rep = 0; rep < 2; ++rep)                      // (C >= 48: at most two taps further)
+                if (ch >= cg.C) {
+                  ch -= cg.C; off -= (unsigned)(cg.C * 2);
+                  ++kw; off += ld2;
+                  if (kw == cg.k) { kw = 0; off += (unsigned)(cg.W - cg.k) * ld2; }
+                }
+              kch[par] = ch; kkw[par] = kw; koff[par] = off;
+            }
+          }
+        }
+        first = false;
+        --seg_left; --left;
+        return;
+      }
+    }
     if (seg_left == 0 && left > 0) { setup(s1); seg_left = left; }       // (at most one switch)
     else if (!first && left > 0) gbase += BK * 2;
     first = false;
     --seg_left; --left;
   };
-  auto issue_one = [&](int buf, int i) __attribute__((always_inline)) { glds16(gbase + (size_t)voff[i], piece0 + buf * STAGE + i * 1024); };
+  auto issue_one = [&](int buf, int i) __attribute__((always_inline)) {
+    if constexpr (CONV) {
+      if (!isB) { glds16(gbase + (size_t)(voff[i] + koff[i & 1]), piece0 + buf * STAGE + i * 1024); return; }
+    }
+    glds16(gbase + (size_t)voff[i], piece0 + buf * STAGE + i * 1024);
+  };
   // prologue: stages 0 .. NS-1 in flight; stage 0 -> fragment set 0
 #pragma unroll
   for (int st = 0; st < NS; ++st) {
@@ -687,11 +755,11 @@ int genrl_gemm_x3(const uint16_t* a0, long a0_ld, long a0_plane, const uint16_t*
   if (big) {
     const int tm = cdiv(M, 128), tn = cdiv(N, 128);
     gemm_planes_kernel<2, 2, 32, 1, 0, 3><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, s1, C, ldc, bias, M, N, accumulate, tm, tn,
-                                                                                xcd_split(tm, tn), SampleEpi{});
+                                                                                xcd_split(tm, tn), SampleEpi{}, ConvGather{});
   } else {
     const int tm = cdiv(M, 64), tn = cdiv(N, 64);
     gemm_planes_kernel<1, 1, 64, 3, 0, 3><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, s1, C, ldc, bias, M, N, accumulate, tm, tn,
-                                                                                xcd_split(tm, tn), SampleEpi{});
+                                                                                xcd_split(tm, tn), SampleEpi{}, ConvGather{});
   }
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
@@ -778,10 +846,10 @@ static int gemm_h2_impl(const uint16_t* a0, long a0_ld, long a0_plane, const flo
       const int acc = seg ? 1 : accumulate;
       if (bk32)
         gemm_planes_kernel<2, 2, 32, 2, 1, 4, false><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
-                                                                                           xcd_split(tm, tn), SampleEpi{});
+                                                                                           xcd_split(tm, tn), SampleEpi{}, ConvGather{});
       else
         gemm_planes_kernel<2, 2, 64, 2, 1, 2, false><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
-                                                                                           xcd_split(tm, tn), SampleEpi{});
+                                                                                           xcd_split(tm, tn), SampleEpi{}, ConvGather{});
       GENRL_CHECK_LAUNCH();
     }
   } else {
@@ -789,8 +857,32 @@ static int gemm_h2_impl(const uint16_t* a0, long a0_ld, long a0_plane, const flo
     // three 32 KiB stages (96 KiB): a fourth stage measured +0.6 ms on the whole step (28.86 vs 28.2 ms) -- with 128 KiB
     // taken, the other streams' small kernels (32 KiB weight-streaming workgroups) cannot share a CU with this one
     gemm_planes_kernel<1, 1, 64, 3, 1, 3><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, s1, C, ldc, bias, M, N, accumulate, tm, tn,
-                                                                                xcd_split(tm, tn), smp);
+                                                                                xcd_split(tm, tn), smp, ConvGather{});
   }
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}
+
+/* C[m, n] (+)= sum_kk patch(m, kk) B[n, kk] (+ bias): the stride-2 convolution product with the patch matrix of an NHWC image
+ * gathered by the operand DMA (see ConvGather).  img: UNIFORM-scale planes [Nimg H W][ld_img] (+ img_inv, the same value in every
+ * row), Cc % 8 == 0; B: planes [N][b_ld], b_ld = k k Cc rounded up to 64.  m = (image, oy, ox), Ho = (H - k) / 2 + 1. */
+int genrl_gemm_h2_conv(const uint16_t* img, long ld_img, long plane_img, const float* img_inv, int Nimg, int H, int W, int Cc, int k,
+                       const uint16_t* b, long b_ld, long b_plane, const float* b_inv, float* C, long ldc, const float* bias, int N,
+                       int accumulate, void* stream) {
+  GENRL_ENTER();
+  const int Ho = (H - k) / 2 + 1, Wo = (W - k) / 2 + 1, K = k * k * Cc;
+  const long Ml = (long)Nimg * Ho * Wo;
+  if (Nimg <= 0 || Ho <= 0 || Wo <= 0 || N <= 0 || (Cc & 7) || Cc < 48 || ld_img < Cc || (ld_img & 7) || (b_ld & 63) || b_ld < K || b_ld >= K + 64 ||
+      !img_inv || !b_inv || Ml > 0x7fffffffL)
+    return GENRL_EINVAL;
+  if ((((long)Nimg * H * W * ld_img + plane_img) * 2) >= 0xffffffffL) return GENRL_EINVAL;     // (32-bit byte offsets in the gather)
+  const int M = (int)Ml;
+  PlaneSeg s0{img, ld_img, plane_img, b, b_ld, b_plane, (int)b_ld, img_inv, b_inv};
+  const PlaneSeg none{nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, nullptr};
+  const int tm = cdiv(M, 128), tn = cdiv(N, 128);
+  gemm_planes_kernel<2, 2, 64, 2, 1, 2, false, true><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, none, C, ldc, bias, M, N, accumulate, tm, tn,
+                                                                                           xcd_split(tm, tn), SampleEpi{},
+                                                                                           ConvGather{H, W, Cc, k, Ho, Wo, K});
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }

@@ -42,6 +42,9 @@ struct TnArgs {
   float* out; long ldo; long split_stride;      // partial of split s at out + s * split_stride
   const float* bias_unused;
   int NI, NJ, M, stages_per_split, accumulate, tiles_i, tiles_j;
+  // CONVB: B(m, j) is the stride-2 patch matrix of an NHWC image held as uniform-scale planes (b = image planes [pixel][b_ld]):
+  // j = (kh k + kw) C + c, m = (image, oy, ox); rowoff[m] = byte offset of the patch's first pixel row, ((n H + 2 oy) W + 2 ox) ld 2
+  const unsigned* rowoff; int cW, cC, ck;
 };
 
 __device__ __forceinline__ void tn_glds16(const void* g, unsigned lds_byte_addr) {
@@ -99,6 +102,7 @@ constexpr int tn_ready_of(int u) {                 // MFMA slot, counted from th
   return o / TN_PER + TN_KB + TN_LAG;
 }
 
+template <bool CONVB>
 __global__ __launch_bounds__(256, 1) void gemm_planes_tn_kernel(TnArgs g) {
   constexpr int BK = 64, TM = 2, TN = 2, KS = BK / 16, NPL = 2, NS = 2;
   constexpr int PLANE_B = BK * 256;              // one plane of one operand tile: [64 m][128 cols] fp16
@@ -138,6 +142,32 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_tn_kernel(TnArgs g) {
   }
   const unsigned stage_bytes = (unsigned)(BK * ld * 2);
   const unsigned piece0 = lds0 + (isB ? OP_B : 0) + pl * PLANE_B;
+  // CONVB, B waves: the lane's column chunk j sits at a fixed place of the patch (tap, channel): tapoff; the patch's pixel row
+  // comes from the rowoff table, 16 values per lane and stage (rows 4 i + r_in), loaded TWO stages ahead by inline-asm global
+  // loads (invisible to the compiler's wait insertion; every iteration starts with vmcnt(0), which covers them)
+  unsigned tapoff = 0, ro[2][NPD];
+  const char* rbase = nullptr;
+  if constexpr (CONVB) {
+    if (isB) {
+      const int r_in = lane >> 4, pslot = lane & 15, lslot = pslot ^ (r_in << 2);
+      const int j = min(j0 + 8 * lslot, g.NJ - 8);
+      const int tap = j / g.cC, ch = j - tap * g.cC, kh = tap / g.ck, kw = tap - kh * g.ck;
+      tapoff = (unsigned)((((long)kh * g.cW + kw) * g.b_ld + ch) * 2 + (long)pl * g.b_plane * 2);
+      gbase = reinterpret_cast<const char*>(g.b);
+      rbase = reinterpret_cast<const char*>(g.rowoff + (long)st0 * BK) + r_in * 4;      // + 16 i per piece, + 256 per stage
+    }
+  }
+  auto load_ro = [&](auto SETc) __attribute__((always_inline)) {      // the 16 row offsets of the stage rbase points at
+    constexpr int set = decltype(SETc)::value;
+    if constexpr (CONVB) {
+      if (isB) {
+#pragma unroll
+        for (int i = 0; i < NPD; ++i)
+          asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(ro[set][i]) : "v"(rbase), "i"(16 * i) : "memory");
+        rbase += BK * 4;
+      }
+    }
+  };
   const char* fbase = reinterpret_cast<const char*>(g.fac + (long)split * g.fac_stride) + lane * 4;
   const unsigned fslot = lds0 + FAC_OFF + wave * 256;
 
@@ -203,17 +233,27 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_tn_kernel(TnArgs g) {
   bool first = true;
   auto next_stage = [&]() __attribute__((always_inline)) {
     if (!first) {
-      if (left > 0) gbase += stage_bytes;          // (behind the last stage the tile pointer stays: finite data, zero factors)
+      if (left > 0 && !(CONVB && isB)) gbase += stage_bytes;   // (behind the last stage the tile pointer stays: finite data, zero factors)
       if (fleft > 0) fbase += BK * 2;
     }
     first = false;
     --left; --fleft;
   };
   auto issue_one = [&](int buf, int i) __attribute__((always_inline)) {
-    if (i < NPD) tn_glds16(gbase + (size_t)voff[i], piece0 + buf * STAGE + i * 1024);
-    else tn_glds4(fbase, fslot + buf * STAGE);
+    if (i < NPD) {
+      if constexpr (CONVB) {
+        if (isB) { tn_glds16(gbase + (size_t)(ro[buf][i] + tapoff), piece0 + buf * STAGE + i * 1024); return; }
+      }
+      tn_glds16(gbase + (size_t)voff[i], piece0 + buf * STAGE + i * 1024);
+    } else tn_glds4(fbase, fslot + buf * STAGE);
   };
   // prologue: stages 0, 1 in flight; stage 0 -> fragment set 0
+  if constexpr (CONVB) {
+    load_ro(std::integral_constant<int, 0>{});
+    load_ro(std::integral_constant<int, 1>{});
+    tn_wait_vm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
   for (int st = 0; st < NS; ++st) {
     next_stage();
@@ -221,7 +261,12 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_tn_kernel(TnArgs g) {
     for (int i = 0; i < NP; ++i) issue_one(st, i);
   }
   next_stage();
-  tn_wait_vm<(NS - 1) * NP>();
+  if constexpr (CONVB) {
+    load_ro(std::integral_constant<int, 0>{});                 // stage 2's (issued by iteration 0, which starts with vmcnt(0))
+    tn_wait_vm<0>();
+  } else {
+    tn_wait_vm<(NS - 1) * NP>();
+  }
   __builtin_amdgcn_s_barrier();
   [&]<int... R>(std::integer_sequence<int, R...>) __attribute__((always_inline)) {
     (read_one(std::integral_constant<int, 0>{}, std::integral_constant<int, R>{}, std::integral_constant<int, 0>{}), ...);
@@ -283,7 +328,12 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_tn_kernel(TnArgs g) {
     tn_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    // (CONVB: this iteration issues stage t+2 with the row offsets of set t % 2, loaded during iteration t-1; the ones of stage
+    // t+3 are requested now, at the very start, into the other set: they have landed long before the iteration ends)
+    load_ro(std::integral_constant<int, 1 - set>{});
+    __builtin_amdgcn_sched_barrier(0);
     mfmas(mfmas, SET, std::integral_constant<int, TN_KB>{});
+    if constexpr (CONVB) { tn_wait_vm<NP>(); __builtin_amdgcn_sched_barrier(0); }
     next_stage();
     ++it;
   };
@@ -416,12 +466,13 @@ long genrl_gemm_h2_tn_ws_bytes(int NI, int NJ, int M) {
 /* C[i, j] (+)= sum_m A(m, i) B(m, j) for h2 planes A [2][M][a_ld] (columns i < NI) and B [2][M][b_ld] (columns j < NJ) with
  * per-row inverse scales a_inv[M], b_inv[M] -- the weight gradient dW = dY^T X on the planes the row kernels emit.
  * M % 64 == 0, a_ld % 64 == b_ld % 64 == 0, ws: genrl_gemm_h2_tn_ws_bytes(NI, NJ, M) bytes, 256-byte aligned. */
-int genrl_gemm_h2_tn(const uint16_t* a, long a_ld, long a_plane, const float* a_inv, const uint16_t* b, long b_ld, long b_plane,
-                     const float* b_inv, float* C, long ldc, int NI, int NJ, int M, int accumulate, void* ws, long ws_bytes,
-                     void* stream) {
+static int tn_impl(const uint16_t* a, long a_ld, long a_plane, const float* a_inv, const uint16_t* b, long b_ld, long b_plane,
+                   const float* b_inv, float* C, long ldc, int NI, int NJ, int M, int accumulate, void* ws, long ws_bytes,
+                   const unsigned* rowoff, int cW, int cC, int ck, void* stream) {
   GENRL_ENTER();
-  if (NI <= 0 || NJ <= 0 || M <= 0 || (M & 63) || (a_ld & 63) || (b_ld & 63) || a_ld < NI || b_ld < NJ || !a_inv || !b_inv || !ws)
-    return GENRL_EINVAL;
+  if (NI <= 0 || NJ <= 0 || M <= 0 || (M & 63) || (a_ld & 63) || a_ld < NI || !a_inv || !b_inv || !ws) return GENRL_EINVAL;
+  if (!rowoff && ((b_ld & 63) || b_ld < NJ)) return GENRL_EINVAL;
+  if (rowoff && ((cC & 7) || (b_ld & 7) || b_ld < cC || (NJ & 7) || NJ != ck * ck * cC)) return GENRL_EINVAL;
   if (ws_bytes < genrl_gemm_h2_tn_ws_bytes(NI, NJ, M) || (reinterpret_cast<uintptr_t>(ws) & 255)) return GENRL_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const TnPlan pl = tn_plan(NI, NJ, M);
@@ -435,13 +486,15 @@ int genrl_gemm_h2_tn(const uint16_t* a, long a_ld, long a_plane, const float* a_
   GENRL_CHECK_LAUNCH();
   const int ti = cdiv(NI, 128), tj = cdiv(NJ, 128);
   const int NJp = (NJ + 3) / 4 * 4;
-  TnArgs g{a, a_ld, a_plane, b, b_ld, b_plane, fac, pl.fac_stride, cref, nullptr, 0, 0, nullptr, NI, NJ, M, sps, 0, ti, tj};
+  TnArgs g{a, a_ld, a_plane, b, b_ld, b_plane, fac, pl.fac_stride, cref, nullptr, 0, 0, nullptr, NI, NJ, M, sps, 0, ti, tj,
+           rowoff, cW, cC, ck};
   if (nsplit == 1) {
     g.out = C; g.ldo = ldc; g.split_stride = 0; g.accumulate = accumulate;
   } else {
     g.out = part; g.ldo = NJp; g.split_stride = (long)NI * NJp; g.accumulate = 0;
   }
-  gemm_planes_tn_kernel<<<ti * tj * nsplit, 256, 0, s>>>(g);
+  if (rowoff) gemm_planes_tn_kernel<true><<<ti * tj * nsplit, 256, 0, s>>>(g);
+  else gemm_planes_tn_kernel<false><<<ti * tj * nsplit, 256, 0, s>>>(g);
   GENRL_CHECK_LAUNCH();
   if (nsplit > 1) {
     const long n4 = (long)NI * (NJ / 4);
@@ -450,6 +503,24 @@ int genrl_gemm_h2_tn(const uint16_t* a, long a_ld, long a_plane, const float* a_
     GENRL_CHECK_LAUNCH();
   }
   return GENRL_OK;
+}
+
+int genrl_gemm_h2_tn(const uint16_t* a, long a_ld, long a_plane, const float* a_inv, const uint16_t* b, long b_ld, long b_plane,
+                     const float* b_inv, float* C, long ldc, int NI, int NJ, int M, int accumulate, void* ws, long ws_bytes,
+                     void* stream) {
+  return tn_impl(a, a_ld, a_plane, a_inv, b, b_ld, b_plane, b_inv, C, ldc, NI, NJ, M, accumulate, ws, ws_bytes, nullptr, 0, 0, 0, stream);
+}
+
+/* The convolution weight gradient on planes:  C[i, j] (+)= sum_m A(m, i) patch(m, j),  j = (kh k + kw) Cc + c,  m = (image, oy, ox)
+ * -- genrl_gemm_h2_tn with its B operand gathered from the uniform-scale planes of an NHWC image [pixel][ld_img] by the DMA.
+ * rowoff[m] (uint32, M + 256 entries: the tail repeats the last value) = ((n H + 2 oy) W + 2 ox) * ld_img * 2, the byte offset of
+ * the patch's first pixel row; NJ = k k Cc, Cc % 8 == 0; img_inv: the image's (uniform) inverse scale per pixel row, >= M entries. */
+int genrl_gemm_h2_tn_conv(const uint16_t* a, long a_ld, long a_plane, const float* a_inv, const uint16_t* img, long ld_img,
+                          long plane_img, const float* img_inv, const unsigned* rowoff, int W, int Cc, int k, float* C, long ldc,
+                          int NI, int M, int accumulate, void* ws, long ws_bytes, void* stream) {
+  if (!rowoff || k <= 0) return GENRL_EINVAL;
+  return tn_impl(a, a_ld, a_plane, a_inv, img, ld_img, plane_img, img_inv, C, ldc, NI, k * k * Cc, M, accumulate, ws, ws_bytes, rowoff,
+                 W, Cc, k, stream);
 }
 
 }  // extern "C"

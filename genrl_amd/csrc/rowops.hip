@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void ln_act_fwd_grp_kernel(const float* __rest
                                                              const float* __restrict__ beta, float* __restrict__ y,
                                                              long ldy, float* __restrict__ mean_out,
                                                              float* __restrict__ rstd_out, int M, int N, float eps,
-                                                             int act) {
+                                                             int act, PlaneOut xo) {
   constexpr int RPW = 64 / GL;
   const int lane = threadIdx.x & 63, gl = lane % GL, gi = lane / GL;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
@@ -138,6 +138,16 @@ __global__ __launch_bounds__(256) void ln_act_fwd_grp_kernel(const float* __rest
   const bool cok = c < N;
   const float4 g4 = ld4z(gamma + c, cok), b4 = ld4z(beta + c, cok);
   const float invn = 1.0f / N;
+  // UNIFORM-scale plane copy of the output (xo.p != null): |x^| <= sqrt(N - 1) for every element of a normalised row, so
+  // |gamma x^ + beta| <= max|gamma| sqrt(N) + max|beta| =: bound, and |SiLU(z)| <= |z|: ONE power-of-two scale fits the whole
+  // tensor, known from the parameters alone (every lane group holds all of gamma / beta: same value everywhere), no overflow
+  // possible.  A uniform scale is what lets the conv products gather patches across pixel rows (csrc/gemm_planes.hip).
+  float u_inv = 0.f, u_sc = 0.f;
+  if (xo.p) {
+    const float gm = group_max<GL>(h2_amax4(g4)), bm = group_max<GL>(h2_amax4(b4));
+    u_inv = h2_inv_of(gm * sqrtf((float)N) + bm);
+    u_sc = h2_scale_of(u_inv);
+  }
   for (long r = wave * RPW + gi; r < M; r += nwaves * RPW) {
     const float4 v = ld4z(x + r * ldx + c, cok);
     const float mean = group_sum<GL>(v.x + v.y + v.z + v.w) * invn;
@@ -149,9 +159,11 @@ __global__ __launch_bounds__(256) void ln_act_fwd_grp_kernel(const float* __rest
                            d.w * rstd * g4.w + b4.w);
     if (act) z = make_float4(siluf_(z.x), siluf_(z.y), siluf_(z.z), siluf_(z.w));
     if (cok) *reinterpret_cast<float4*>(y + r * ldy + c) = z;
+    if (xo.p && cok) h2_store4(xo, r, c, z, u_sc);
     if (gl == 0) {
       mean_out[r] = mean;
       rstd_out[r] = rstd;
+      if (xo.p) xo.inv[r] = u_inv;
     }
   }
 }
@@ -165,9 +177,11 @@ __global__ __launch_bounds__(256) void ln_act_bwd_grp_kernel(const float* __rest
                                                              const float* __restrict__ mean_in,
                                                              const float* __restrict__ rstd_in, float* __restrict__ dx,
                                                              long lddx, float* __restrict__ part, int M, int N, int act,
-                                                             int np) {
+                                                             int np, float* __restrict__ amax_part) {
   constexpr int RPW = 64 / GL;
   __shared__ float4 sm[3][4][GL];
+  __shared__ float amx[4];
+  float am = 0.f;                                  // largest |dx| this thread has produced (amax_part != null)
   const int lane = threadIdx.x & 63, gl = lane % GL, gi = lane / GL, w = threadIdx.x >> 6;
   const long wave = (long)blockIdx.x * 4 + w, nwaves = (long)gridDim.x * 4;
   const int c = gl * 4;
@@ -193,9 +207,16 @@ __global__ __launch_bounds__(256) void ln_act_bwd_grp_kernel(const float* __rest
     const float4 o = make_float4(rstd * (dxh.x - s1 - xh.x * s2), rstd * (dxh.y - s1 - xh.y * s2),
                                  rstd * (dxh.z - s1 - xh.z * s2), rstd * (dxh.w - s1 - xh.w * s2));
     if (cok && dx) *reinterpret_cast<float4*>(dx + r * lddx + c) = o;
+    if (cok) am = fmaxf(am, h2_amax4(o));
     ag.x += dz.x * xh.x; ag.y += dz.y * xh.y; ag.z += dz.z * xh.z; ag.w += dz.w * xh.w;
     ab.x += dz.x; ab.y += dz.y; ab.z += dz.z; ab.w += dz.w;
     if (cok) { ac.x += o.x; ac.y += o.y; ac.z += o.z; ac.w += o.w; }
+  }
+  if (amax_part) {                                 // one partial maximum per workgroup (genrl_split_h2u reduces them)
+    am = wave_max(am);
+    if (lane == 0) amx[w] = am;
+    __syncthreads();
+    if (threadIdx.x == 0) amax_part[blockIdx.x] = fmaxf(fmaxf(amx[0], amx[1]), fmaxf(amx[2], amx[3]));
   }
   if (!part) return;
   // lanes with the same column (gl) across the RPW row groups of the wave, then the 4 waves through LDS
@@ -1168,13 +1189,63 @@ extern "C" {
 
 int genrl_split_h2(const float* x, long ldx, int R, int Cn, uint16_t* out, long ld_out, long plane, float* inv, int transpose,
                    void* stream);
+// ---- uniform-scale planes of an fp32 matrix: ONE power-of-two scale for all rows (the largest |x| of the tensor lands in
+// [2^14, 2^15)), inv[row] = 1 / scale in every row.  The conv products need it: a patch row spans several pixel rows, a
+// weight gradient sums over them.
+__global__ __launch_bounds__(256) void amax_partial_kernel(const float* __restrict__ x, long ldx, int R, int Cn,
+                                                           float* __restrict__ part) {
+  __shared__ float red[4];
+  const long n4 = (long)R * (Cn / 4);
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long r = i / (Cn / 4); const int c4 = (int)(i % (Cn / 4));
+    m = fmaxf(m, h2_amax4(*reinterpret_cast<const float4*>(x + r * ldx + 4 * c4)));
+  }
+  m = block_max_256(m, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = m;
+}
+__global__ __launch_bounds__(256) void split_h2_uniform_kernel(const float* __restrict__ x, long ldx, int R, int Cn,
+                                                               PlaneOut xo, const float* __restrict__ part, int nparts) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, part[i]);
+  const float inv = h2_inv_of(block_max_256(m, red)), sc = h2_scale_of(inv);
+  const int c4n = (int)(xo.ld / 4);                  // chunks of 4 columns per plane row, padding included (written as zeros)
+  const long n4 = (long)R * c4n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long r = i / c4n; const int c = 4 * (int)(i % c4n);
+    const float4 v = c < Cn ? *reinterpret_cast<const float4*>(x + r * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    h2_store4(xo, r, c, v, sc);
+    if (c == 0) xo.inv[r] = inv;
+  }
+}
+static int split_h2u_from_parts(const float* x, long ldx, int R, int Cn, const PlaneOut& xo, const float* part, int nparts,
+                                void* stream) {
+  if ((Cn & 3) || (ldx & 3) || (xo.ld & 3) || !aligned16(x)) return GENRL_EINVAL;
+  const long n4 = (long)R * (xo.ld / 4);
+  int nb = cdiv(n4, 256 * 4); nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+  split_h2_uniform_kernel<<<nb, 256, 0, (hipStream_t)stream>>>(x, ldx, R, Cn, xo, part, nparts);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}
+extern "C" int genrl_split_h2u(const float* x, long ldx, int R, int Cn, uint16_t* out, long ld_out, long plane, float* inv,
+                               float* ws, void* stream) {
+  GENRL_ENTER();
+  if (R <= 0 || Cn <= 0 || !out || !inv || !ws || (Cn & 3) || (ldx & 3) || (ld_out & 3) || ld_out < Cn || !aligned16(x)) return GENRL_EINVAL;
+  const long n4 = (long)R * (Cn / 4);
+  int nb = cdiv(n4, 256 * 8); nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+  amax_partial_kernel<<<nb, 256, 0, (hipStream_t)stream>>>(x, ldx, R, Cn, ws);
+  GENRL_CHECK_LAUNCH();
+  return split_h2u_from_parts(x, ldx, R, Cn, PlaneOut{out, ld_out, plane, inv}, ws, nb, stream);
+}
+
 // plane output of a kernel variant that cannot write planes itself: a second pass over its fp32 output
 static int split_after(const float* y, long ldy, int M, int N, const PlaneOut& xo, void* stream) {
   return genrl_split_h2(y, ldy, M, N, xo.p, xo.ld, xo.plane, xo.inv, 0, stream);
 }
 
 static int ln_act_fwd_impl(const float* x, long ldx, const float* gamma, const float* beta, float* y, long ldy,
-                     float* mean, float* rstd, int M, int N, float eps, int act, PlaneOut xo, void* stream) {
+                     float* mean, float* rstd, int M, int N, float eps, int act, PlaneOut xo, void* stream, bool uniform = false) {
   GENRL_ENTER();
   if (M <= 0) return GENRL_OK;
   if (xo.p && (!xo.inv || (xo.ld & 3) || xo.ld < N)) return GENRL_EINVAL;
@@ -1186,9 +1257,13 @@ static int ln_act_fwd_impl(const float* x, long ldx, const float* gamma, const f
   if (narrow) {
     const int gl = N <= 64 ? 16 : (N <= 128 ? 32 : 64);
     const int grid = (int)std::min<long>(cdiv(M, 4 * (64 / gl)), 2048);
-#define GO(GLV) hipLaunchKernelGGL((ln_act_fwd_grp_kernel<GLV>), dim3(grid), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, mean, rstd, M, N, eps, act)
+    const PlaneOut xu = uniform ? xo : PlaneOut{nullptr, 0, 0, nullptr};
+#define GO(GLV) hipLaunchKernelGGL((ln_act_fwd_grp_kernel<GLV>), dim3(grid), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, mean, rstd, M, N, eps, act, xu)
     if (gl == 16) GO(16); else if (gl == 32) GO(32); else GO(64);
 #undef GO
+    if (uniform) { GENRL_CHECK_LAUNCH(); return GENRL_OK; }
+  } else if (uniform) {
+    return GENRL_EINVAL;                           // (uniform planes: the channel-LayerNorm kernel only)
   } else if (fast && N <= 1024 && WAVE_LN) {
     const int grid = (int)std::min<long>(cdiv(M, 4), 4 * BLK_GRID);
     const int nv = cdiv(N, 256);
@@ -1222,6 +1297,14 @@ int genrl_ln_act_fwd_h2(const float* x, long ldx, const float* gamma, const floa
                         void* stream) {
   return ln_act_fwd_impl(x, ldx, gamma, beta, y, ldy, mean, rstd, M, N, eps, act, PlaneOut{yp, ldp, plane, inv}, stream);
 }
+/* the channel LayerNorm (rows of <= 256 floats) with a UNIFORM-scale plane copy of its output: one power-of-two scale for the
+ * whole tensor, derived from gamma / beta / N (inv[row] holds the same value in every row) */
+int genrl_ln_act_fwd_h2u(const float* x, long ldx, const float* gamma, const float* beta, float* y, long ldy,
+                         float* mean, float* rstd, int M, int N, float eps, int act, uint16_t* yp, long ldp, long plane, float* inv,
+                         void* stream) {
+  if (!yp || !inv) return GENRL_EINVAL;
+  return ln_act_fwd_impl(x, ldx, gamma, beta, y, ldy, mean, rstd, M, N, eps, act, PlaneOut{yp, ldp, plane, inv}, stream, true);
+}
 
 static inline int blk_grid_for(int M) { return M < BLK_GRID ? M : BLK_GRID; }
 
@@ -1236,9 +1319,10 @@ long genrl_ln_ws_floats(int M, int N) {
 static int ln_act_bwd_impl(const float* dy, long lddy, const float* x, long ldx, const float* gamma,
                      const float* beta, const float* mean, const float* rstd, float* dx, long lddx,
                      float* dgamma, float* dbeta, float* dcolsum, float* ws, int M, int N, int act,
-                     int accumulate_params, PlaneOut xo, void* stream) {
+                     int accumulate_params, PlaneOut xo, void* stream, float* amax_ws = nullptr) {
   GENRL_ENTER();
   if (M <= 0) return GENRL_OK;
+  if (amax_ws && !(N <= 256 && M >= 64 && NARROW_LN)) return GENRL_EINVAL;      // (uniform planes: the channel-LayerNorm kernel only)
   if (xo.p && (!xo.inv || (xo.ld & 3) || xo.ld < N || !dx)) return GENRL_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const bool fast = N > 256 && N <= 4096 && (N & 3) == 0 && (lddy & 3) == 0 && (ldx & 3) == 0 &&
@@ -1252,11 +1336,12 @@ static int ln_act_bwd_impl(const float* dy, long lddy, const float* x, long ldx,
     const int grid = (int)std::min<long>(cdiv(M, 4 * (64 / gl)), blk_grid_for(M));
     float* part = dgamma ? ws : nullptr;
     const int np = dcolsum ? 3 : 2;
-#define GO(GLV) hipLaunchKernelGGL((ln_act_bwd_grp_kernel<GLV>), dim3(grid), dim3(256), 0, s, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, part, M, N, act, np)
+#define GO(GLV) hipLaunchKernelGGL((ln_act_bwd_grp_kernel<GLV>), dim3(grid), dim3(256), 0, s, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, part, M, N, act, np, amax_ws)
     if (gl == 16) GO(16); else if (gl == 32) GO(32); else GO(64);
 #undef GO
     if (dgamma) reduce_params(ws, ws + (long)grid * np * N, dgamma, dbeta, grid, N, accumulate_params, s, dcolsum);
     GENRL_CHECK_LAUNCH();
+    if (amax_ws) return xo.p ? split_h2u_from_parts(dx, lddx, M, N, xo, amax_ws, grid, stream) : GENRL_EINVAL;
     return xo.p ? split_after(dx, lddx, M, N, xo, stream) : GENRL_OK;
   }
   if (fast && N <= 1024 && WAVE_LN) {
@@ -1316,6 +1401,17 @@ int genrl_ln_act_bwd_h2(const float* dy, long lddy, const float* x, long ldx, co
                         int accumulate_params, uint16_t* dxp, long ldp, long plane, float* inv, void* stream) {
   return ln_act_bwd_impl(dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, dgamma, dbeta, dcolsum, ws, M, N, act,
                          accumulate_params, PlaneOut{dxp, ldp, plane, inv}, stream);
+}
+
+/* the channel LayerNorm's backward (rows of <= 256 floats) with a UNIFORM-scale plane copy of dx: the kernel leaves one partial
+ * maximum per workgroup in amax_ws (>= 2048 floats), a second launch reduces them and splits dx with the tensor's one scale */
+int genrl_ln_act_bwd_h2u(const float* dy, long lddy, const float* x, long ldx, const float* gamma,
+                         const float* beta, const float* mean, const float* rstd, float* dx, long lddx,
+                         float* dgamma, float* dbeta, float* dcolsum, float* ws, int M, int N, int act,
+                         int accumulate_params, uint16_t* dxp, long ldp, long plane, float* inv, float* amax_ws, void* stream) {
+  if (!dxp || !inv || !amax_ws || !dx) return GENRL_EINVAL;
+  return ln_act_bwd_impl(dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, dgamma, dbeta, dcolsum, ws, M, N, act,
+                         accumulate_params, PlaneOut{dxp, ldp, plane, inv}, stream, amax_ws);
 }
 
 long genrl_colsum_ws_floats(int M, int N) { return (long)(chunks_for(M) + 16) * N; }

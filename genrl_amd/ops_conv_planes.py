@@ -1,0 +1,300 @@
+"""The stride-2 convolutions of the image encoder / decoder (agent/dreamer_utils.py:558-715) with their products on h2 planes.
+
+Same autograd node structure as ops._Conv2dS2 / ops._ConvT2dS2 (NHWC activations, channel-LayerNorm + SiLU inside the node, the
+scatter side as GEMM -> col2im), but every product that can runs on the fp16 matrix cores through the plane kernels:
+
+  forward conv / input gradient of the transposed conv   patch-gathering plane GEMM          genrl_gemm_h2_conv
+  forward transposed conv / input gradient of the conv    plain plane GEMM (rows = pixels)     genrl_gemm_h2      -> col2im
+  weight gradients (sum over pixels)                      transposing plane GEMM + gather      genrl_gemm_h2_tn_conv
+
+A patch row gathers from k x k pixel rows and a weight gradient sums over pixels, so the gathered / summed operands carry ONE scale
+for the whole tensor ("uniform" planes): activations get it from the channel-LayerNorm kernel itself (the scale its parameters
+guarantee, genrl_ln_act_fwd_h2u), gradients from the LayerNorm backward's partial maxima (genrl_ln_act_bwd_h2u), anything else
+from genrl_split_h2u.  Products whose shapes the plane kernels do not take (3-channel ends, pixel counts that are not a multiple of
+64, fewer than MIN_ROWS rows) stay on the fp32-operand kernels of ops.py -- decided per product."""
+import os
+import torch
+from torch.autograd import Function
+
+from ._lib import lib, check
+from . import planes
+from . import ops
+from .ops import _p, _f32, _grad_buf, _ws, sgemm, sgemm_conv, colsum
+
+_stream = ops._stream
+ENABLED = os.environ.get('GENRL_PLANES_CONV', '1') != '0'
+
+
+def min_rows():
+    """pixel rows from which a convolution product takes the plane kernels (GENRL_PLANES_CONV_MIN_ROWS overrides)"""
+    return int(os.environ.get('GENRL_PLANES_CONV_MIN_ROWS', '4096'))
+
+
+def active(x):
+    return ENABLED and planes.ENABLED and x.is_cuda
+
+
+_rowoff_cache = {}
+
+
+def _rowoff(Nimg, H, W, k, ld, dev):
+    """byte offset of the first pixel row of patch m = (image, oy, ox) in planes [pixel][ld]: ((n H + 2 oy) W + 2 ox) ld 2
+    (uint32 as int32 bits; M + 256 entries, the tail repeats the last value: the kernel's run-ahead reads there)"""
+    key = (Nimg, H, W, k, ld, str(dev))
+    t = _rowoff_cache.get(key)
+    if t is None:
+        Ho, Wo = (H - k) // 2 + 1, (W - k) // 2 + 1
+        n = torch.arange(Nimg, device=dev, dtype=torch.int64)[:, None, None]
+        oy = torch.arange(Ho, device=dev, dtype=torch.int64)[None, :, None]
+        ox = torch.arange(Wo, device=dev, dtype=torch.int64)[None, None, :]
+        off = (((n * H + 2 * oy) * W + 2 * ox) * ld * 2).reshape(-1)
+        assert int(off[-1]) + 2 * ld * (k * W + k) < 2 ** 32
+        off = torch.cat([off, off[-1:].expand(256)])
+        t = (off & 0xFFFFFFFF).to(torch.int64)
+        t = torch.where(t >= 2 ** 31, t - 2 ** 32, t).to(torch.int32).contiguous()
+        _rowoff_cache[key] = t
+    return t
+
+
+def _uniform_split(x2d):
+    """uniform-scale planes of an fp32 matrix (exact tensor maximum; two launches)"""
+    R, C = x2d.shape
+    P = planes.Planes(R, C, x2d.device)
+    ws = torch.empty(1024, device=x2d.device)
+    check(lib().genrl_split_h2u(_p(x2d), C, R, C, P.ptr(), P.ld, P.plane, P.inv_ptr(), _p(ws), _stream()), 'split_h2u')
+    return P
+
+
+def _ln_fwd(pre2d, gamma, beta, eps, want_planes):
+    """channel-LayerNorm + SiLU of the rows; -> (y, mean, rstd, uniform planes of y or None)"""
+    M, N = pre2d.shape
+    y = torch.empty_like(pre2d)
+    mean = torch.empty(M, device=pre2d.device); rstd = torch.empty(M, device=pre2d.device)
+    P = None
+    if want_planes and N <= 256 and N % 4 == 0 and M >= 64:
+        P = planes.Planes(M, N, pre2d.device)
+        check(lib().genrl_ln_act_fwd_h2u(_p(pre2d), N, _p(gamma), _p(beta), _p(y), N, _p(mean), _p(rstd), M, N, eps, 1,
+                                         P.ptr(), P.ld, P.plane, P.inv_ptr(), _stream()), 'ln_act_fwd_h2u')
+    else:
+        check(lib().genrl_ln_act_fwd(_p(pre2d), N, _p(gamma), _p(beta), _p(y), N, _p(mean), _p(rstd), M, N, eps, 1, _stream()),
+              'ln_act_fwd')
+        if want_planes and N % 4 == 0:
+            P = _uniform_split(y)
+    return y, mean, rstd, P
+
+
+def _ln_bwd(dy2d, pre2d, gamma, beta, mean, rstd, bias, want_planes):
+    """-> dpre, dgamma, dbeta, dbias (None where accumulated straight into the flat gradient buffers), uniform planes of dpre"""
+    M, N = pre2d.shape
+    dev = pre2d.device
+    dpre = torch.empty_like(pre2d)
+    tg, tb, tc = _grad_buf(gamma), _grad_buf(beta), _grad_buf(bias)
+    direct = tg is not None and tb is not None and tc is not None
+    if direct:
+        g0, g1, g2 = tg, tb, tc
+    else:
+        gb = torch.empty(3, N, device=dev)
+        g0, g1, g2 = gb[0], gb[1], gb[2]
+    ws = _ws(lib().genrl_ln_ws_floats(M, N), dev)
+    P = None
+    if want_planes and N <= 256 and N % 4 == 0 and M >= 64:
+        P = planes.Planes(M, N, dev)
+        amax = torch.empty(2048, device=dev)
+        check(lib().genrl_ln_act_bwd_h2u(_p(dy2d), N, _p(pre2d), N, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dpre), N, _p(g0), _p(g1),
+                                         _p(g2), _p(ws), M, N, 1, int(direct), P.ptr(), P.ld, P.plane, P.inv_ptr(), _p(amax), _stream()),
+              'ln_act_bwd_h2u')
+    else:
+        check(lib().genrl_ln_act_bwd(_p(dy2d), N, _p(pre2d), N, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dpre), N, _p(g0), _p(g1),
+                                     _p(g2), _p(ws), M, N, 1, int(direct), _stream()), 'ln_act_bwd')
+        if want_planes and N % 4 == 0:
+            P = _uniform_split(dpre)
+    return (dpre, None, None, None, P) if direct else (dpre, g0, g1, g2, P)
+
+
+def _gemm_conv(img_p, Nimg, H, W, C, k, Bp, out, ldc, bias, N):
+    """out[m, n] = sum_kk patch(m, kk) B[n, kk] (+ bias): the DMA gathers the patches from the uniform planes img_p"""
+    if planes.gemm_profile is not None:
+        e0 = torch.cuda.Event(enable_timing=True); e0.record()
+    check(lib().genrl_gemm_h2_conv(img_p.ptr(), img_p.ld, img_p.plane, img_p.inv_ptr(), Nimg, H, W, C, k, Bp.ptr(), Bp.ld, Bp.plane,
+                                   Bp.inv_ptr(), _p(out), ldc, _p(bias), N, 0, _stream()), 'gemm_h2_conv')
+    if planes.gemm_profile is not None:
+        e1 = torch.cuda.Event(enable_timing=True); e1.record()
+        Ho, Wo = (H - k) // 2 + 1, (W - k) // 2 + 1
+        planes.gemm_profile.append((Nimg * Ho * Wo, N, k * k * C, e0, e1, 'kk/conv1/h2/pipe4'))
+
+
+def _gemm_tn_conv(Ap, img_p, Nimg, H, W, C, k, out, ldc, NI, M):
+    """out[i, j] = sum_m A(m, i) patch(m, j): the convolution weight gradients (A: planes with M rows; patches from img_p)"""
+    if planes.gemm_profile is not None:
+        e0 = torch.cuda.Event(enable_timing=True); e0.record()
+    NJ = k * k * C
+    nb = lib().genrl_gemm_h2_tn_ws_bytes(NI, NJ, M)
+    ws = torch.empty(nb + 256, dtype=torch.uint8, device=out.device)
+    wp = (ws.data_ptr() + 255) // 256 * 256
+    ro = _rowoff(Nimg, H, W, k, img_p.ld, out.device)
+    assert ro.numel() == M + 256, (ro.numel(), M)
+    check(lib().genrl_gemm_h2_tn_conv(Ap.ptr(), Ap.ld, Ap.plane, Ap.inv_ptr(), img_p.ptr(), img_p.ld, img_p.plane, img_p.inv_ptr(),
+                                      _p(ro), W, C, k, _p(out), ldc, NI, M, 0, wp, nb, _stream()), 'gemm_h2_tn_conv')
+    if planes.gemm_profile is not None:
+        e1 = torch.cuda.Event(enable_timing=True); e1.record()
+        planes.gemm_profile.append((NI, NJ, M, e0, e1, 'rr/conv2/h2tn/pipe4'))
+
+
+KR_MIN_K = int(os.environ.get('GENRL_PLANES_KR_MIN_K', '512'))      # GEMM -> col2im products: with few input channels (K = C) a 128 x 128 tile is two K stages of prologue and a
+#                     64 KiB store -- the write-bound fp32-operand kernel is faster there (173056 x 1728 x 96: 0.55 vs 1.0 ms)
+
+
+def _gather_ok(M, C, k=1):
+    return M * k * k >= min_rows() and C % 8 == 0 and C >= 48
+
+
+class _Conv2dS2P(Function):
+    """ops._Conv2dS2 with plane products.  x: f32 NHWC (N,H,W,C) [xp: its uniform planes or None] or u8 NCHW frames;
+    Wp (Co, k*k*Ci) = weight permuted to (co, kh, kw, ci); channel-LayerNorm + SiLU fused; returns NHWC with ._planes set."""
+    @staticmethod
+    def forward(ctx, x, Wp, b, k, gamma, beta, eps, xp, holder):
+        u8 = x.dtype == torch.uint8
+        x = x.contiguous()
+        if u8:
+            Nimg, C, Hi, Wi = x.shape
+        else:
+            Nimg, Hi, Wi, C = x.shape
+        Co = Wp.shape[0]
+        Ho, Wo = (Hi - k) // 2 + 1, (Wi - k) // 2 + 1
+        M, K = Nimg * Ho * Wo, C * k * k
+        y = torch.empty(M, Co, device=x.device)
+        on_planes = (not u8) and xp is not None and _gather_ok(M, C)
+        if on_planes:
+            _gemm_conv(xp, Nimg, Hi, Wi, C, k, planes.split(Wp.detach()), y, Co, b, Co)
+        elif ops._implicit_conv(x, C):
+            sgemm_conv(x, K, 1, Wp, K, 1, y, Co, b, M, Co, K, 1, (Hi, Wi, C, k))
+        else:
+            cols = ops._im2col(x, Nimg, Hi, Wi, C, k, 2 if u8 else 0)
+            sgemm(cols, K, 1, Wp, K, 1, y, Co, b, M, Co, K)
+        out, mean, rstd, outp = _ln_fwd(y, gamma, beta, eps, want_planes=M >= min_rows())
+        holder.append(outp)
+        ctx.dims = (Nimg, Hi, Wi, C, k, u8)
+        ctx.bias = b
+        ctx.xp = xp if on_planes else None
+        ctx.save_for_backward(x, Wp, y, mean, rstd, gamma, beta)
+        return out.reshape(Nimg, Ho, Wo, Co)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, Wp, pre, mean, rstd, gamma, beta = ctx.saved_tensors
+        Nimg, Hi, Wi, C, k, u8 = ctx.dims
+        Co = Wp.shape[0]
+        K = C * k * k
+        Ho, Wo = (Hi - k) // 2 + 1, (Wi - k) // 2 + 1
+        M = Nimg * Ho * Wo
+        xp = ctx.xp
+        need_dx = (not u8) and ctx.needs_input_grad[0]
+        tn = xp is not None and ctx.needs_input_grad[1] and M % 64 == 0 and K % 8 == 0
+        kr = need_dx and M >= min_rows() and Co >= KR_MIN_K
+        dy2, dg, dbe, db, dyp = _ln_bwd(dy.reshape(M, Co).contiguous(), pre, gamma, beta, mean, rstd, ctx.bias, want_planes=tn or kr)
+        dx = dW = None
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty(Co, K, device=dy.device)
+            if tn and dyp is not None:
+                _gemm_tn_conv(dyp, xp, Nimg, Hi, Wi, C, k, dW, K, Co, M)
+            elif ops._implicit_conv(x, C) and Co % 4 == 0:
+                sgemm_conv(dy2, 1, Co, x, 1, K, dW, K, None, Co, K, M, 2, (Hi, Wi, C, k))
+            else:
+                cols = ops._im2col(x, Nimg, Hi, Wi, C, k, 2 if u8 else 0)
+                sgemm(dy2, 1, Co, cols, 1, K, dW, K, None, Co, K, M)
+                del cols
+        if need_dx:
+            dcols = torch.empty(M, K, device=dy.device)
+            if kr and dyp is not None:
+                planes.gemm(dyp, planes.split(Wp.detach(), transpose=True), dcols, K, None, M, K)      # dcols = dy W
+            else:
+                sgemm(dy2, Co, 1, Wp, 1, K, dcols, K, None, M, K, Co)
+            dx = ops._col2im(dcols, None, Nimg, Ho, Wo, C, k, Hi, Wi)
+        return dx, dW, db, None, dg, dbe, None, None, None
+
+
+class _ConvT2dS2P(Function):
+    """ops._ConvT2dS2 (with the fused channel-LayerNorm + SiLU) with plane products.  x NHWC (N,Hi,Wi,Ci), xp: planes of its rows
+    (uniform or per-row scales) or None; Wp (Ci, k*k*Co) = weight permuted to (ci, kh, kw, co)."""
+    @staticmethod
+    def forward(ctx, x, Wp, b, k, gamma, beta, eps, xp, holder):
+        x = _f32(x).contiguous()
+        Nimg, Hi, Wi, Ci = x.shape
+        Nw = Wp.shape[1]
+        Co = Nw // (k * k)
+        M = Nimg * Hi * Wi
+        cols = torch.empty(M, Nw, device=x.device)
+        if xp is None and M >= min_rows() // 4 and Ci % 4 == 0:
+            xp = planes.split(x.reshape(M, Ci))                      # (the first layer's input comes from a Linear)
+        on_planes = xp is not None and M * (k * k) >= min_rows()
+        if on_planes and Ci >= KR_MIN_K:
+            planes.gemm(xp, planes.split(Wp.detach(), transpose=True), cols, Nw, None, M, Nw)      # cols = x W
+        else:
+            sgemm(x, Ci, 1, Wp, 1, Nw, cols, Nw, None, M, Nw, Ci)
+        y = ops._col2im(cols, b, Nimg, Hi, Wi, Co, k)
+        Ho, Wo = y.shape[1], y.shape[2]
+        out, mean, rstd, outp = _ln_fwd(y.reshape(-1, Co), gamma, beta, eps, want_planes=Nimg * Ho * Wo >= min_rows())
+        holder.append(outp)
+        ctx.dims = (Nimg, Hi, Wi, Ci, Co, k)
+        ctx.bias = b
+        ctx.xp = xp if on_planes else None
+        ctx.save_for_backward(x, Wp, y, mean, rstd, gamma, beta)
+        return out.reshape(y.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, Wp, pre, mean, rstd, gamma, beta = ctx.saved_tensors
+        Nimg, Hi, Wi, Ci, Co, k = ctx.dims
+        Ho, Wo = 2 * (Hi - 1) + k, 2 * (Wi - 1) + k
+        M, Nw = Nimg * Hi * Wi, Co * k * k
+        xp = ctx.xp
+        gather = _gather_ok(M, Co, k) and Ci % 4 == 0
+        tn = gather and xp is not None and M % 64 == 0 and ctx.needs_input_grad[1]
+        dgr = gather and ctx.needs_input_grad[0]
+        dyv, dg, dbe, db, dyp = _ln_bwd(dy.contiguous().reshape(-1, Co), pre.reshape(-1, Co), gamma, beta, mean, rstd, ctx.bias,
+                                       want_planes=tn or dgr)
+        dyv = dyv.reshape(Nimg, Ho, Wo, Co)
+        implicit = ops._implicit_conv(dyv, Co) and Ci % 4 == 0
+        dcols = None
+        dx = dW = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, Ci, device=dy.device)
+            if dgr and dyp is not None:
+                _gemm_conv(dyp, Nimg, Ho, Wo, Co, k, planes.split(Wp.detach()), dx, Ci, None, Ci)      # dx = patches(dy) W^T
+            elif implicit:
+                sgemm_conv(dyv, Nw, 1, Wp, Nw, 1, dx, Ci, None, M, Ci, Nw, 1, (Ho, Wo, Co, k))
+            else:
+                dcols = ops._im2col(dyv, Nimg, Ho, Wo, Co, k, 0)
+                sgemm(dcols, Nw, 1, Wp, Nw, 1, dx, Ci, None, M, Ci, Nw)
+            dx = dx.reshape(Nimg, Hi, Wi, Ci)
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty(Ci, Nw, device=dy.device)
+            if tn and dyp is not None:
+                _gemm_tn_conv(xp, dyp, Nimg, Ho, Wo, Co, k, dW, Nw, Ci, M)                              # dW = x^T patches(dy)
+            elif implicit:
+                sgemm_conv(x, 1, Ci, dyv, 1, Nw, dW, Nw, None, Ci, Nw, M, 2, (Ho, Wo, Co, k))
+            else:
+                if dcols is None:
+                    dcols = ops._im2col(dyv, Nimg, Ho, Wo, Co, k, 0)
+                sgemm(x, 1, Ci, dcols, 1, Nw, dW, Nw, None, Ci, Nw, M)
+        return dx, dW, db, None, dg, dbe, None, None, None
+
+
+def conv2d_s2(x, W, b, ln):
+    """ops.conv2d_s2 with the fused channel-LayerNorm; the output carries ._planes (uniform planes of its pixel rows) for the
+    next layer when it was worth making them"""
+    Co, Ci, k, _ = W.shape
+    Wp = ops._PermuteWeight.apply(W).reshape(Co, k * k * Ci)
+    holder = []
+    y = _Conv2dS2P.apply(x, Wp, b, k, ln[0], ln[1], float(ln[2]), getattr(x, '_planes', None), holder)
+    y._planes = holder[0] if holder else None
+    return y
+
+
+def convT2d_s2(x, W, b, ln):
+    Ci, Co, k, _ = W.shape
+    Wp = ops._PermuteWeight.apply(W).reshape(Ci, k * k * Co)
+    holder = []
+    y = _ConvT2dS2P.apply(x, Wp, b, k, ln[0], ln[1], float(ln[2]), getattr(x, '_planes', None), holder)
+    y._planes = holder[0] if holder else None
+    return y

@@ -90,6 +90,21 @@ int genrl_gemm_h2_sample(const uint16_t* a0, long a0_ld, long a0_plane, const fl
                          long b0_plane, const float* b0_inv, int k0, float* C, long ldc, const float* bias, int M, int N,
                          const float* q, long ldq, float unimix, float* sample, long lds, uint16_t* sp, long sld, long splane,
                          float* sinv, void* stream);
+/* UNIFORM-scale h2 planes (one power-of-two scale for the whole tensor, inv[row] the same in every row): what the convolution
+ * products need -- a patch row gathers from several pixel rows, a weight gradient sums over them (csrc/gemm_planes*.hip).
+ * genrl_split_h2u: from an fp32 matrix, exact tensor maximum (two launches; ws >= 1024 floats).  genrl_ln_act_fwd_h2u: the channel
+ * LayerNorm (+SiLU, rows of <= 256 floats, agent/dreamer_utils.py:1031-1040) emits them itself with the scale its parameters
+ * guarantee (|gamma x^ + beta| <= max|gamma| sqrt(N) + max|beta|).  genrl_ln_act_bwd_h2u: its backward leaves one partial maximum
+ * of dx per workgroup in amax_ws (>= 2048 floats), a second launch splits dx with the tensor's scale. */
+int genrl_split_h2u(const float* x, long ldx, int R, int Cn, uint16_t* out, long ld_out, long plane, float* inv, float* ws,
+                    void* stream);
+int genrl_ln_act_fwd_h2u(const float* x, long ldx, const float* gamma, const float* beta, float* y, long ldy, float* mean,
+                         float* rstd, int M, int N, float eps, int act, uint16_t* yp, long ldp, long plane, float* inv,
+                         void* stream);
+int genrl_ln_act_bwd_h2u(const float* dy, long lddy, const float* x, long ldx, const float* gamma, const float* beta,
+                         const float* mean, const float* rstd, float* dx, long lddx, float* dgamma, float* dbeta, float* dcolsum,
+                         float* ws, int M, int N, int act, int accumulate_params, uint16_t* dxp, long ldp, long plane, float* inv,
+                         float* amax_ws, void* stream);
 /* State-resident GRU scan, forward (csrc/scan_coop.hip): the recurrence of EnsembleRSSM.observe / VideoSSM.update
  * (agent/dreamer_utils.py:362-371,771-785) over T steps in ONE persistent launch -- D/4 workgroups, each with its 12 columns of
  * the recurrent weight block W_h (rows 0 .. 3D-1, columns 0 .. D-1, row stride ldw) resident in LDS for the whole sequence, the
@@ -107,6 +122,14 @@ int genrl_grid_barrier_bench(float* ws, int n, int G, void* stream);
 int genrl_gru_scan_coop(float* pre, const float* Wh, long ldw, const float* gamma, const float* beta, const float* h0,
                         const float* mask, float* out, float* hm, float* mean, float* rstd, float* ws, int T, int B, int D,
                         float eps, int variant, void* stream);
+/* The stride-2 convolution product on planes: C[m, n] (+)= sum_kk patch(m, kk) B[n, kk] (+ bias), the patch matrix of an NHWC image
+ * (agent/dreamer_utils.py:604-621 forward; :686-706 input gradient of the transposed convolutions) gathered by the operand DMA
+ * itself -- m = (image, oy, ox), kk = (kh k + kw) Cc + c, 16-byte chunks = 8 channels of one pixel.  img: UNIFORM-scale planes
+ * [Nimg H W][ld_img] with img_inv the same in every row (genrl_ln_act_fwd_h2u / genrl_split_h2u); Cc % 8 == 0, Cc >= 48;
+ * B: planes [N][b_ld] of the (N, k k Cc) weight matrix, b_ld = k k Cc rounded up to 64 (zero padded). */
+int genrl_gemm_h2_conv(const uint16_t* img, long ld_img, long plane_img, const float* img_inv, int Nimg, int H, int W, int Cc, int k,
+                       const uint16_t* b, long b_ld, long b_plane, const float* b_inv, float* C, long ldc, const float* bias, int N,
+                       int accumulate, void* stream);
 /* Weight-gradient product on the SAME planes (csrc/gemm_planes_tn.hip):  C[i, j] (+)= sum_m A(m, i) B(m, j) for h2 planes
  * A [2][M][a_ld] (columns i < NI) and B [2][M][b_ld] (columns j < NJ) with per-row inverse scales a_inv[M], b_inv[M] -- dW = dY^T X
  * (agent/dreamer_utils.py:739-747 backward) read against the planes' storage order through the transposing LDS read
@@ -117,6 +140,14 @@ long genrl_gemm_h2_tn_ws_bytes(int NI, int NJ, int M);
 int genrl_gemm_h2_tn(const uint16_t* a, long a_ld, long a_plane, const float* a_inv, const uint16_t* b, long b_ld, long b_plane,
                      const float* b_inv, float* C, long ldc, int NI, int NJ, int M, int accumulate, void* ws, long ws_bytes,
                      void* stream);
+/* The convolution weight gradient on planes: genrl_gemm_h2_tn with B(m, j) = the stride-2 patch matrix of an NHWC image held as
+ * uniform-scale planes [pixel][ld_img], gathered by the operand DMA: j = (kh k + kw) Cc + c (NJ = k k Cc columns), m = (image, oy, ox).
+ * rowoff (uint32, M + 256 entries, the tail repeating the last value): ((n H + 2 oy) W + 2 ox) * ld_img * 2 -- the byte offset of the
+ * patch's first pixel row; img_inv: the image's uniform inverse scale per pixel row (>= M entries).  ws as genrl_gemm_h2_tn's for
+ * (NI, k k Cc, M).  (agent/dreamer_utils.py:604-621 weight gradient; with A = the input planes and the image = dY: :686-706.) */
+int genrl_gemm_h2_tn_conv(const uint16_t* a, long a_ld, long a_plane, const float* a_inv, const uint16_t* img, long ld_img,
+                          long plane_img, const float* img_inv, const unsigned* rowoff, int W, int Cc, int k, float* C, long ldc,
+                          int NI, int M, int accumulate, void* ws, long ws_bytes, void* stream);
 /* the same for n matrices in one launch set (row splits: one launch; transposed splits: two) -- all weights of an optimiser group
  * after its step.  Descriptors are read on the host at call time. */
 typedef struct {

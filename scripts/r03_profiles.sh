@@ -1,0 +1,34 @@
+#!/bin/bash
+# round-3 judged artefacts (written under gpurun_out/r03/; copy into profiles/ afterwards)
+cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r03; mkdir -p $O
+B="python bench.py --no-fp32-mode --no-kernel-profile --no-cpu-baseline --no-traffic"
+# (1) clean kernel stats of the default arithmetic, graph replay, no spin kernel, no fp32 leg
+rm -rf /tmp/k1; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/k1 -o p -- $B --steps 6 --warmup 3 > $O/bench_default.json 2> /dev/null
+cp /tmp/k1/p_kernel_stats.csv $O/kernel_stats_default.csv 2>/dev/null
+python scripts/kernel_table.py /tmp/k1/p_kernel_trace.csv 4 > $O/kernel_table_default.txt 2>&1
+python scripts/native_count.py /tmp/k1/p_kernel_trace.csv > $O/launch_classes.txt 2>&1
+# (2) the same with fp32 MFMAs throughout
+rm -rf /tmp/k2; GENRL_GEMM_MODE=0 GENRL_PLANES=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/k2 -o p -- $B --steps 6 --warmup 3 > $O/bench_fp32mfma.json 2> /dev/null
+cp /tmp/k2/p_kernel_stats.csv $O/kernel_stats_fp32mfma.csv 2>/dev/null
+python scripts/kernel_table.py /tmp/k2/p_kernel_trace.csv 4 > $O/kernel_table_fp32mfma.txt 2>&1
+# (3) feature A/B on this one box (ms per step, 20 steps each)
+ms() { python -c "import json,sys; print(round(json.loads(sys.stdin.read())['ms_per_step'], 2))"; }
+{
+echo "default:                          $($B --steps 20 --warmup 5 2>/dev/null | ms)"
+echo "GENRL_PLANES_CONV=0:              $(GENRL_PLANES_CONV=0 $B --steps 20 --warmup 5 2>/dev/null | ms)"
+echo "GENRL_PLANES_WGRAD=0:             $(GENRL_PLANES_WGRAD=0 $B --steps 20 --warmup 5 2>/dev/null | ms)"
+echo "both off (round 2's products):    $(GENRL_PLANES_CONV=0 GENRL_PLANES_WGRAD=0 $B --steps 20 --warmup 5 2>/dev/null | ms)"
+echo "GENRL_PLANES_LINEAR=0:            $(GENRL_PLANES_LINEAR=0 $B --steps 20 --warmup 5 2>/dev/null | ms)"
+echo "default again:                    $($B --steps 20 --warmup 5 2>/dev/null | ms)"
+} > $O/feature_ab.txt 2>&1
+# (4) per-rank batch table, connector side stream ON and OFF
+for b in 32 16 8 4; do
+  echo "B=$b overlap on: $($B --batch $b --steps 30 2>/dev/null | ms)   no-overlap: $($B --batch $b --steps 30 --no-overlap 2>/dev/null | ms)"
+done > $O/batch_table.txt 2>&1
+# (5) per-phase kernels of one eager single-stream step
+timeout 300 bash scripts/phase_prof.sh 32 14 > $O/phase_b32.txt 2>&1
+timeout 300 bash scripts/phase_prof.sh 4 14 > $O/phase_b4.txt 2>&1
+# (6) micro-benchmarks
+timeout 200 python scripts/tn_bench.py > $O/tn_bench.txt 2>&1
+timeout 200 python scripts/planes_bench.py > $O/planes_bench.txt 2>&1

@@ -19,3 +19,6 @@ os.environ.setdefault('GENRL_PLANES_MIN_ROWS', '0')
 # likewise the weight gradients on plane operands (genrl_gemm_h2_tn, from 2048 rows up by default): every product with a whole
 # number of 64-row stages takes it in the suite
 os.environ.setdefault('GENRL_TN_MIN_ROWS', '64')
+# ... and the convolution products on plane operands (genrl_amd/ops_conv_planes.py, from 4096 pixel rows up by default)
+os.environ.setdefault('GENRL_PLANES_CONV_MIN_ROWS', '0')
+os.environ.setdefault('GENRL_PLANES_KR_MIN_K', '0')

@@ -1,0 +1,97 @@
+"""The encoder / decoder convolutions with their products on h2 planes (genrl_amd/ops_conv_planes.py: patch-gathering plane GEMM,
+transposing plane GEMM with gather for the weight gradients, uniform-scale planes from the channel-LayerNorm kernels) against
+torch's fp32 conv2d / conv_transpose2d + LayerNorm + SiLU: outputs and every gradient, chains of layers (so that planes flow from
+one layer's LayerNorm into the next layer's gather), the shapes of the 64 x 64 encoder / decoder at small batch, odd sizes that fall
+back per product."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def g(s):
+    return torch.Generator().manual_seed(s)
+
+
+def _check(hip_fn, ref_fn, inputs, rtol, atol):
+    cpu = [t.clone().double().requires_grad_(True) for t in inputs]
+    dev = [t.clone().cuda().requires_grad_(True) for t in inputs]
+    r, h = ref_fn(*cpu), hip_fn(*dev)
+    np.testing.assert_allclose(h.detach().cpu().numpy(), r.detach().float().numpy(), rtol=rtol, atol=atol, err_msg='out')
+    w = torch.randn(r.shape, generator=g(99))
+    (r * w.double()).sum().backward(); (h * w.cuda()).sum().backward()
+    for i, (a, b) in enumerate(zip(cpu, dev)):
+        scale = max(1e-6, a.grad.abs().max().item())
+        err = (b.grad.cpu().double() - a.grad).abs().max().item() / scale
+        assert err <= 5e-5, (i, err)
+
+
+def _ln_silu(y, ga, be):
+    return F.silu(F.layer_norm(y, (y.shape[-1],), ga, be, 1e-3))
+
+
+@pytest.mark.parametrize('N,Hi,C0,C1,C2', [(8, 31, 48, 96, 192), (64, 14, 96, 192, 384), (3, 31, 48, 96, 192), (16, 31, 56, 48, 64)])
+def test_encoder_chain_on_planes(N, Hi, C0, C1, C2):
+    """two stride-2 k4 convolutions + channel-LN + SiLU: the second layer gathers its patches from the uniform planes the first
+    layer's LayerNorm wrote; N = 3: pixel counts that are no multiple of 64 (weight gradients fall back to the fp32 kernels)"""
+    from genrl_amd import ops, ops_conv_planes as cp, planes
+    x = torch.randn(N, Hi, Hi, C0, generator=g(1))
+    W1 = torch.randn(C1, C0, 4, 4, generator=g(2)) / (C0 * 16) ** .5; b1 = 0.1 * torch.randn(C1, generator=g(3))
+    W2 = torch.randn(C2, C1, 4, 4, generator=g(4)) / (C1 * 16) ** .5; b2 = 0.1 * torch.randn(C2, generator=g(5))
+    g1, e1 = 1 + 0.1 * torch.randn(C1, generator=g(6)), 0.1 * torch.randn(C1, generator=g(7))
+    g2, e2 = 1 + 0.1 * torch.randn(C2, generator=g(8)), 0.1 * torch.randn(C2, generator=g(9))
+
+    def ref(x, W1, b1, g1, e1, W2, b2, g2, e2):
+        y = _ln_silu(F.conv2d(x.permute(0, 3, 1, 2), W1, b1, stride=2).permute(0, 2, 3, 1), g1, e1)
+        return _ln_silu(F.conv2d(y.permute(0, 3, 1, 2), W2, b2, stride=2).permute(0, 2, 3, 1), g2, e2)
+
+    def hip(x, W1, b1, g1, e1, W2, b2, g2, e2):
+        xin = x * 1.0
+        xin._planes = cp._uniform_split(xin.detach().reshape(-1, C0))            # (as a previous layer would have left them)
+        y = cp.conv2d_s2(xin, W1, b1, (g1, e1, 1e-3))
+        assert y._planes is not None
+        return cp.conv2d_s2(y, W2, b2, (g2, e2, 1e-3))
+    _check(hip, ref, [x, W1, b1, g1, e1, W2, b2, g2, e2], rtol=3e-4, atol=3e-4)
+
+
+@pytest.mark.parametrize('N,Hi,C0,C1,C2,k1,k2', [(64, 1, 1536, 192, 96, 5, 5), (64, 5, 192, 96, 48, 5, 6), (5, 5, 192, 96, 48, 5, 6),
+                                                 (128, 5, 64, 48, 56, 5, 6)])
+def test_decoder_chain_on_planes(N, Hi, C0, C1, C2, k1, k2):
+    """two stride-2 transposed convolutions + channel-LN + SiLU: forward on planes of the input rows, the input gradient gathers
+    patches of dY from uniform planes, the weight gradient sums x^T patches(dY) over the input pixels"""
+    from genrl_amd import ops_conv_planes as cp
+    x = torch.randn(N, Hi, Hi, C0, generator=g(1))
+    W1 = torch.randn(C0, C1, k1, k1, generator=g(2)) / (C0 * k1) ** .5; b1 = 0.1 * torch.randn(C1, generator=g(3))
+    W2 = torch.randn(C1, C2, k2, k2, generator=g(4)) / (C1 * k2) ** .5; b2 = 0.1 * torch.randn(C2, generator=g(5))
+    g1, e1 = 1 + 0.1 * torch.randn(C1, generator=g(6)), 0.1 * torch.randn(C1, generator=g(7))
+    g2, e2 = 1 + 0.1 * torch.randn(C2, generator=g(8)), 0.1 * torch.randn(C2, generator=g(9))
+
+    def ref(x, W1, b1, g1, e1, W2, b2, g2, e2):
+        y = _ln_silu(F.conv_transpose2d(x.permute(0, 3, 1, 2), W1, b1, stride=2).permute(0, 2, 3, 1), g1, e1)
+        return _ln_silu(F.conv_transpose2d(y.permute(0, 3, 1, 2), W2, b2, stride=2).permute(0, 2, 3, 1), g2, e2)
+
+    def hip(x, W1, b1, g1, e1, W2, b2, g2, e2):
+        y = cp.convT2d_s2(x * 1.0, W1, b1, (g1, e1, 1e-3))
+        return cp.convT2d_s2(y, W2, b2, (g2, e2, 1e-3))
+    _check(hip, ref, [x, W1, b1, g1, e1, W2, b2, g2, e2], rtol=3e-4, atol=3e-4)
+
+
+def test_uniform_planes_of_the_channel_layernorm():
+    """genrl_ln_act_fwd_h2u: one scale for the whole tensor, from the parameters alone; the planes reproduce the fp32 output to
+    2^-22 of the scale's range; genrl_split_h2u: the exact-maximum variant"""
+    from genrl_amd import ops_conv_planes as cp, planes
+    pre = torch.randn(5000, 96, generator=g(1)).cuda() * 3
+    ga = (1 + 0.2 * torch.randn(96, generator=g(2))).cuda(); be = (0.3 * torch.randn(96, generator=g(3))).cuda()
+    y, mean, rstd, P = cp._ln_fwd(pre, ga, be, 1e-3, True)
+    ref = F.silu(F.layer_norm(pre, (96,), ga, be, 1e-3))
+    assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5)
+    assert (P.inv == P.inv[0]).all() and P.ld == 128 and (P.t[:, :, 96:] == 0).all()
+    bound = ga.abs().max() * 96 ** 0.5 + be.abs().max()
+    assert float(P.inv[0]) * 2 ** 14 <= float(bound) < float(P.inv[0]) * 2 ** 15
+    assert ((P.float() - y).abs() <= 2.0 ** -21 * float(bound)).all() and ((P.float() - y).abs() <= 2.0 ** -22 * y.abs() + 2.0 ** -37 * float(bound)).all()
+    x = torch.randn(777, 48, generator=g(4)).cuda() * 1e-5
+    U = cp._uniform_split(x)
+    assert (U.inv == U.inv[0]).all() and float(x.abs().max()) / float(U.inv[0]) < 2 ** 15 and float(x.abs().max()) / float(U.inv[0]) >= 2 ** 14
+    assert ((U.float() - x).abs() <= 2.0 ** -22 * x.abs() + 2.0 ** -37 * float(x.abs().max())).all()
