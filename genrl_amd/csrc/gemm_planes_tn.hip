@@ -385,29 +385,42 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_tn_kernel(TnArgs g) {
 }
 
 // f[r] = inv_a[m] inv_b[m] / cref (fp16, a power of two <= 1; m = r0 + r) and cref = the largest inv_a inv_b of each split's m
-// range, one workgroup per split; the split's vector is fac_stride long and ZERO behind its rows (the K loop's padding stage
+// range, one workgroup per split (inv_a, inv_b: exact powers of two, 16-byte aligned arrays); the split's vector is fac_stride long and ZERO behind its rows (the K loop's padding stage
 // and the 128-factor DMA of the last stage read there)
 __global__ __launch_bounds__(256) void tn_factors_kernel(const float* __restrict__ ia, const float* __restrict__ ib, int M,
                                                          int rows_per_split, long fac_stride, u16* __restrict__ fac,
                                                          float* __restrict__ cref) {
-  __shared__ double red[4];
+  __shared__ int red[4];
   const int r0 = blockIdx.x * rows_per_split, r1 = min(M, r0 + rows_per_split);
-  // (in double: the product of two inverse scales can leave fp32's range -- an all-zero gradient row carries inv = 2^-123 --
-  // and neither the maximum nor the quotient may turn into 0, Inf or NaN on the way; the quotient is an exact power of two <= 1
-  // that the fp16 conversion flushes gradually)
-  double mx = 0.0;
-  for (int r = r0 + threadIdx.x; r < r1; r += 256) mx = fmax(mx, (double)ia[r] * (double)ib[r]);
+  // The inverse scales are exact powers of two (h2_inv_of): their product is handled by its EXPONENT -- the product itself can
+  // leave fp32's range (an all-zero gradient row carries inv = 2^-123), and neither the maximum nor the quotient may turn into 0,
+  // Inf or NaN on the way.  e = E(ia) + E(ib) (biased exponent fields; the value is 2^(e - 254)).
+  auto efield = [](float v) { return (int)((__builtin_bit_cast(unsigned, v) >> 23) & 255u); };
+  int emax = 0;
+  for (int r = r0 + 4 * threadIdx.x; r < r1; r += 1024) {            // (r0, r1 multiples of 64: whole float4s)
+    const float4 a = *reinterpret_cast<const float4*>(ia + r), b = *reinterpret_cast<const float4*>(ib + r);
+    emax = max(max(max(efield(a.x) + efield(b.x), efield(a.y) + efield(b.y)), max(efield(a.z) + efield(b.z), efield(a.w) + efield(b.w))), emax);
+  }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  for (int o = 32; o > 0; o >>= 1) emax = max(emax, __shfl_xor(emax, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = emax;
   __syncthreads();
-  mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-  if (!(mx > 0.0)) mx = 1.0;
-  if (threadIdx.x == 0) cref[blockIdx.x] = (float)mx;             // (a reference below fp32's range: the products it scales are 0)
+  emax = max(max(red[0], red[1]), max(red[2], red[3]));
+  if (threadIdx.x == 0) {            // cref = 2^(emax - 254), clamped into fp32 (below its range the products it scales are 0 anyway)
+    const int e = min(max(emax - 254, -149), 127);
+    cref[blockIdx.x] = ldexpf(1.0f, e);
+  }
+  // f = 2^(e - emax) as fp16 bits: normal for e - emax >= -14, subnormal down to -24, 0 below
+  auto f16_pow2 = [](int d) -> unsigned { return d >= -14 ? (unsigned)(d + 15) << 10 : (d >= -24 ? 1u << (d + 24) : 0u); };
   u16* f = fac + (long)blockIdx.x * fac_stride;
-  for (int r = threadIdx.x; r < fac_stride; r += 256) {
-    const _Float16 v = r0 + r < r1 ? (_Float16)(float)(((double)ia[r0 + r] * (double)ib[r0 + r]) / mx) : (_Float16)0.f;
-    f[r] = __builtin_bit_cast(u16, v);
+  for (int r = 4 * threadIdx.x; r < fac_stride; r += 1024) {          // (fac_stride % 64 == 0)
+    unsigned lo = 0, hi = 0;
+    if (r0 + r < r1) {
+      const float4 a = *reinterpret_cast<const float4*>(ia + r0 + r), b = *reinterpret_cast<const float4*>(ib + r0 + r);
+      lo = f16_pow2(efield(a.x) + efield(b.x) - emax) | (f16_pow2(efield(a.y) + efield(b.y) - emax) << 16);
+      hi = f16_pow2(efield(a.z) + efield(b.z) - emax) | (f16_pow2(efield(a.w) + efield(b.w) - emax) << 16);
+    }
+    *reinterpret_cast<uint2*>(f + r) = make_uint2(lo, hi);
   }
 }
 
@@ -474,6 +487,7 @@ static int tn_impl(const uint16_t* a, long a_ld, long a_plane, const float* a_in
   if (!rowoff && ((b_ld & 63) || b_ld < NJ)) return GENRL_EINVAL;
   if (rowoff && ((cC & 7) || (b_ld & 7) || b_ld < cC || (NJ & 7) || NJ != ck * ck * cC)) return GENRL_EINVAL;
   if (ws_bytes < genrl_gemm_h2_tn_ws_bytes(NI, NJ, M) || (reinterpret_cast<uintptr_t>(ws) & 255)) return GENRL_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(a_inv) | reinterpret_cast<uintptr_t>(b_inv)) & 15) return GENRL_EINVAL;      // (float4 reads of the scales)
   hipStream_t s = (hipStream_t)stream;
   const TnPlan pl = tn_plan(NI, NJ, M);
   const int nsplit = pl.nsplit, sps = pl.sps;

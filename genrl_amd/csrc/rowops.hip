@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void ln_act_fwd_grp_kernel(const float* __rest
                            d.w * rstd * g4.w + b4.w);
     if (act) z = make_float4(siluf_(z.x), siluf_(z.y), siluf_(z.z), siluf_(z.w));
     if (cok) *reinterpret_cast<float4*>(y + r * ldy + c) = z;
-    if (xo.p && cok) h2_store4(xo, r, c, z, u_sc);
+    if (xo.p && c < xo.ld) h2_store4(xo, r, c, cok ? z : make_float4(0.f, 0.f, 0.f, 0.f), u_sc);     // (padding columns: zeros)
     if (gl == 0) {
       mean_out[r] = mean;
       rstd_out[r] = rstd;

@@ -59,7 +59,7 @@ def _rowoff(Nimg, H, W, k, ld, dev):
 def _uniform_split(x2d):
     """uniform-scale planes of an fp32 matrix (exact tensor maximum; two launches)"""
     R, C = x2d.shape
-    P = planes.Planes(R, C, x2d.device)
+    P = planes.Planes(R, C, x2d.device, zero=False)
     ws = torch.empty(1024, device=x2d.device)
     check(lib().genrl_split_h2u(_p(x2d), C, R, C, P.ptr(), P.ld, P.plane, P.inv_ptr(), _p(ws), _stream()), 'split_h2u')
     return P
@@ -72,7 +72,7 @@ def _ln_fwd(pre2d, gamma, beta, eps, want_planes):
     mean = torch.empty(M, device=pre2d.device); rstd = torch.empty(M, device=pre2d.device)
     P = None
     if want_planes and N <= 256 and N % 4 == 0 and M >= 64:
-        P = planes.Planes(M, N, pre2d.device)
+        P = planes.Planes(M, N, pre2d.device, zero=False)
         check(lib().genrl_ln_act_fwd_h2u(_p(pre2d), N, _p(gamma), _p(beta), _p(y), N, _p(mean), _p(rstd), M, N, eps, 1,
                                          P.ptr(), P.ld, P.plane, P.inv_ptr(), _stream()), 'ln_act_fwd_h2u')
     else:
@@ -98,7 +98,7 @@ def _ln_bwd(dy2d, pre2d, gamma, beta, mean, rstd, bias, want_planes):
     ws = _ws(lib().genrl_ln_ws_floats(M, N), dev)
     P = None
     if want_planes and N <= 256 and N % 4 == 0 and M >= 64:
-        P = planes.Planes(M, N, dev)
+        P = planes.Planes(M, N, dev, zero=False)
         amax = torch.empty(2048, device=dev)
         check(lib().genrl_ln_act_bwd_h2u(_p(dy2d), N, _p(pre2d), N, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dpre), N, _p(g0), _p(g1),
                                          _p(g2), _p(ws), M, N, 1, int(direct), P.ptr(), P.ld, P.plane, P.inv_ptr(), _p(amax), _stream()),

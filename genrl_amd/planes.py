@@ -31,10 +31,11 @@ class Planes:
     """planes of a (rows x cols) matrix; .t int16 [2, rows, ld] (fp16 bits), .inv fp32 [rows]"""
     __slots__ = ('t', 'inv', 'rows', 'cols', 'ld', 'plane')
 
-    def __init__(self, rows, cols, dev):
+    def __init__(self, rows, cols, dev, zero=True):
         self.rows, self.cols, self.ld = rows, cols, r64(cols)
-        # padding columns must hold zeros (0 x garbage may be NaN): zero-filled once when there are any
-        mk = torch.zeros if self.ld != cols else torch.empty
+        # padding columns must hold zeros (0 x garbage may be NaN): zero-filled once when there are any -- unless the
+        # producer writes the padding itself (zero=False: the channel-LayerNorm and uniform-split kernels do)
+        mk = torch.zeros if (self.ld != cols and zero) else torch.empty
         self.t = mk(2, rows, self.ld, dtype=torch.int16, device=dev)
         self.inv = torch.empty(rows, device=dev)
         self.plane = rows * self.ld
@@ -182,6 +183,7 @@ def gemm_tn(A, B, C, ldc, NI, NJ, M, accumulate=False, a_row0=0, b_row0=0, c_off
     the row kernels emit for the forward / dgrad products (genrl_gemm_h2_tn: transposing LDS reads, the row scales folded
     into the fragments).  A, B: Planes handles with >= M rows from their first row; M % 64 == 0."""
     assert M % 64 == 0 and a_row0 + M <= A.rows and b_row0 + M <= B.rows and NI <= A.ld and NJ <= B.ld, (M, A.rows, B.rows)
+    assert a_row0 % 4 == 0 and b_row0 % 4 == 0            # (the scales are read 16 bytes at a time)
     if gemm_profile is not None:
         e0 = torch.cuda.Event(enable_timing=True); e0.record()
     nb = lib().genrl_gemm_h2_tn_ws_bytes(NI, NJ, M)
