@@ -336,11 +336,11 @@ def main():
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * dt / args.steps,
                'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
                'dtype': ('f32' if (ops.F32_MODE == 'f32' and not planes.ENABLED) else
-                         'f32 (storage, accumulation, every non-GEMM kernel and the fp32-MFMA GEMMs; the forward / dgrad products '
-                         'of the imagination rollout and of the Dense+LN+SiLU chains from 512 rows up take fp32 operands pre-split '
-                         'into two fp16 planes of the row-scaled value (22 mantissa bits + fp32 accumulation of 3 fp16-MFMA '
-                         'products), the remaining 128x128-tile GEMMs split each fp32 operand exactly into 3 bf16 terms in registers '
-                         '(6 bf16-MFMA products).  Error vs float64: same order as the fp32 MFMAs\' -- measured 0.4-2x theirs for '
+                         'f32 (storage, accumulation, every non-GEMM kernel and the fp32-MFMA GEMMs; the forward / dgrad / weight-gradient '
+                         'products of the imagination rollout, of the Dense+LN+SiLU chains from 512 rows up and of the encoder / decoder '
+                         'convolutions take fp32 operands pre-split into two fp16 planes of the scaled value (22 mantissa bits + fp32 '
+                         'accumulation of 3 fp16-MFMA products), any remaining 128x128-tile GEMM splits each fp32 operand exactly into 3 bf16 '
+                         'terms in registers (6 bf16-MFMA products).  Error vs float64: same order as the fp32 MFMAs\' -- measured 0.4-2x theirs for '
                          'the fp16 planes (operand representation 2^-23 relative; profiles/*planes_bench*), at or below theirs for '
                          'the exact 3-term bf16 split; GENRL_GEMM_MODE=0 GENRL_PLANES=0 = fp32 MFMAs throughout, timed beside as '
                          'fp32_mfma_mode)') if args.precision == 32
@@ -416,7 +416,8 @@ def main():
             d.update(gflop_per_step=d.pop('flop') / 1e9, ms_per_step=d.pop('ms'), launches_per_step=d.pop('launches'))
             if name == 'fp32_mfma':
                 d.update(achieved=eq, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=eq / PEAK_F32_MFMA_TFLOPS,
-                         kernel='sgemm_rr_kernel<BF=0> 64x64 / 96-wide conv tiles, sgemm_tall_kernel (gemm.hip): v_mfma_f32_16x16x4_f32')
+                         kernel='sgemm_rr_kernel<BF=0> 64x64 / 96-wide tiles (write-bound GEMM -> col2im products, 1 k-row weight '
+                                'gradients), sgemm_tall_kernel (3-channel image ends) (gemm.hip): v_mfma_f32_16x16x4_f32')
             elif name == 'bf16_split':
                 d.update(achieved=6 * eq, peak=PEAK_BF16_MFMA_TFLOPS, unit='TFLOP/s (bf16 MFMA work executed = 6 x 2MNK)',
                          frac=6 * eq / PEAK_BF16_MFMA_TFLOPS, fp32_equivalent_achieved=eq,
@@ -430,7 +431,9 @@ def main():
                          frac=3 * eq / PEAK_BF16_MFMA_TFLOPS, fp32_equivalent_achieved=eq,
                          fp32_equivalent_frac_of_fp32_peak=eq / PEAK_F32_MFMA_TFLOPS,
                          kernel='gemm_planes_kernel<FMT=1> (gemm_planes.hip: operands pre-split into two fp16 planes of the row-scaled '
-                                'value, LDS-DMA): 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate',
+                                'value, LDS-DMA; <CONV>: stride-2 patches gathered by the DMA) and gemm_planes_tn_kernel (gemm_planes_tn.hip: '
+                                'weight gradients on the same planes, transposing LDS reads): 3 x v_mfma_f32_32x32x16_f16 per product, '
+                                'fp32 accumulate',
                          note='operand ingest (L2 -> LDS DMA, 4 bytes per element per tile pass) bounds these launches, not the '
                               'matrix pipe (DESIGN 4a)')
             else:
@@ -444,7 +447,7 @@ def main():
         traffic, tsrc = (None, 'skipped (--no-traffic)') if (args.no_traffic or world > 1) else measure_traffic()
         if traffic is None:
             why = tsrc
-            for fn in ('r02_pmc.json', 'r01_pmc.json'):
+            for fn in ('r03_pmc.json', 'r02_pmc.json', 'r01_pmc.json'):
                 try:
                     pm = json.load(open(os.path.join(ROOT, 'profiles', fn)))
                     gk = [v for k_, v in pm.items() if k_.startswith('sgemm_') or k_.startswith('gemm_planes') or k_.startswith('gemm_x3')]
