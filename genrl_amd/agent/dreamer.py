@@ -267,7 +267,7 @@ class WorldModel(Module):  # ref :120-321
         # DESIGN par.6)
         fork = (getattr(self.cfg, 'overlap_detached', False) and self.rssm.single_obs_posterior
                 and self.cfg.decoder_inputs == 'stoch' and self.grad_heads == ['decoder']
-                and common.Optimizer.grad_reduce is None)
+                and common.Optimizer.grad_reduce is None and os.environ.get('GENRL_FORK_PRIOR', '1') != '0')
         self.rssm.fork_prior = fork
         post, prior = self.rssm.observe(embed, data['action'], data['is_first'], state)
         self.rssm.fork_prior = False
@@ -441,7 +441,8 @@ class ActorCritic(Module):  # ref :323-462
         metrics = {}
         hor = self.cfg.imag_horizon
         self._target_critic.requires_grad_(False)
-        overlap = getattr(self.cfg, 'overlap_detached', False) and common.Optimizer.grad_reduce is None
+        overlap = (getattr(self.cfg, 'overlap_detached', False) and common.Optimizer.grad_reduce is None
+                   and os.environ.get('GENRL_FORK_CRITIC', '1') != '0')
         with common.RequiresGrad(self.actor):
             seq = world_model.imagine(self.actor, start, is_terminal, hor)
             self._rollout_actor_raw = getattr(world_model, '_last_actor_raw', None)

@@ -92,7 +92,7 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 
 // TM x TN 32x32 blocks per wave (2x2 waves per workgroup); BK = 64 (TM*TN == 1) or 32; NACC class accumulators;
 // FMT 0: x3 (three bf16 planes, six products), 1: h2 (two fp16 planes of the row-scaled value, three products); NS LDS stages
-template <int TM, int TN, int BK, int NACC, int FMT, int NS, bool FOLD = true, bool CONV = false>
+template <int TM, int TN, int BK, int NACC, int FMT, int NS, bool FOLD = true, bool CONV = false, int PF = 0>
 __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneSeg s1, float* __restrict__ C, long ldc,
                                                          const float* __restrict__ bias, int M, int N, int accumulate,
                                                          int tiles_m, int tiles_n, int xcd_m, SampleEpi smp, ConvGather cg) {
@@ -107,7 +107,14 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
   constexpr int NPA = APIECES / 2, NPB = BPIECES / 2;  // pieces per wave (waves 0,1: A; waves 2,3: B)
   constexpr int NPMAX = NPA > NPB ? NPA : NPB;
   constexpr int KS = BK / 16;                          // MFMA k-steps per stage
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
+  // PF > 0: every stage's DMAs are preceded by an L2 PREFETCH of the stage PF further on -- one 4-byte LDS-DMA per 128-byte line
+  // (NPF wave-instructions per wave) into a 1 KiB dummy area.  The ring bounds the bytes in flight per CU (NS x 32 KiB); when the
+  // operands are cold in this XCD's L2 (inside the step they always are: the activations were written by the previous launch, the
+  // weights were last read a rollout step ago) the product runs at (ring bytes) / (fabric latency), and the prefetch moves that
+  // latency off the ring without taking LDS.
+  static_assert(PF == 0 || (BK == 64 && !CONV), "prefetch: 128-byte tile rows, plain operands");
+  constexpr int NPF = PF ? TM : 0;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE + (PF ? 1024 : 0)];
 
   // XCD-aware tile order (workgroup b runs on XCD b % 8; each XCD gets a compact sub-block of the tile grid)
   int bid = blockIdx.x, tile_m, tile_n;
@@ -142,11 +149,20 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
   // stage) + voff[i] (per lane: plane, tile row, swizzled chunk; constant over the K loop)
   const char* gbase;
   unsigned voff[NPMAX];
+  unsigned pfoff[NPF ? NPF : 1];                       // prefetch: line (plane, tile row) of this lane, k offset 0
   auto setup = [&](const PlaneSeg& s) __attribute__((always_inline)) {
     const u16* P = isB ? s.b : s.a;
     const long ld = isB ? s.b_ld : s.a_ld, plane = isB ? s.b_plane : s.a_plane;
     const int rows_total = isB ? N : M, r0 = isB ? n0 : m0;
     gbase = reinterpret_cast<const char*>(P);
+    if constexpr (PF > 0) {
+#pragma unroll
+      for (int i = 0; i < NPF; ++i) {
+        const int L = ((wave & 1) * NPF + i) * 64 + lane;             // 2 rows_t lines per operand and stage
+        const int p = L / rows_t, row = L % rows_t;
+        pfoff[i] = (unsigned)((p * plane + (long)min(r0 + row, rows_total - 1) * ld) * 2);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NPMAX; ++i) {
       const int q = (wave & 1) * npieces + i;
@@ -283,6 +299,15 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
     first = false;
     --seg_left; --left;
   };
+  auto prefetch = [&]() __attribute__((always_inline)) {           // behind next_stage(): gbase = the stage issued next
+    if constexpr (PF > 0) {
+      const int ahead = min(PF, max(seg_left, 0)) * (BK * 2);        // (stays inside the segment's rows)
+#pragma unroll
+      for (int i = 0; i < NPF; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + (size_t)pfoff[i] + ahead),
+                                         (__attribute__((address_space(3))) void*)(uintptr_t)(lds0 + NS * STAGE + wave * 256), 4, 0, 0);
+    }
+  };
   auto issue_one = [&](int buf, int i) __attribute__((always_inline)) {
     if constexpr (CONV) {
       if (!isB) { glds16(gbase + (size_t)(voff[i] + koff[i & 1]), piece0 + buf * STAGE + i * 1024); return; }
@@ -293,11 +318,12 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
 #pragma unroll
   for (int st = 0; st < NS; ++st) {
     next_stage();
+    if (st) prefetch();
 #pragma unroll
     for (int i = 0; i < NP; ++i) issue_one(st, i);
   }
   next_stage();                        // books stage NS (issued by iteration 0)
-  wait_vm<(NS - 1) * NP>();
+  wait_vm<(NS - 1) * (NP + NPF)>();
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int r = 0; r < NR; ++r) read_one(0, r, 0);
@@ -342,11 +368,12 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
     __builtin_amdgcn_sched_barrier(0);
     // stage t+1 landed (own DMAs; stages t+2 .. stay in flight); all fragment reads of stage t have returned
 #if PLANES_ABL != 5      /* ablation 5: no barrier either */
-    wait_vm<(NS - 2) * NP>();
+    wait_vm<(NS - 2) * (NP + NPF)>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #endif
     __builtin_amdgcn_sched_barrier(0);
+    prefetch();
 #pragma unroll
     for (int m = KB; m < NM; ++m) {
       mfma_one(set, m);
@@ -711,6 +738,8 @@ __global__ __launch_bounds__(256) void split_h2_t_batch_kernel(SplitBatch b) {
   }
 }
 
+int g_planes_nosplit = 0;        // experiments: 1 = no row split against wave quantisation (GENRL_PLANES_NOSPLIT)
+int g_planes_variant = 0;        // experiments (scripts/cold_bench.py): ring depth / prefetch distance variants
 int g_planes_force_tile = 0;     // 0 auto, 1: 64x64, 2: 128x128 (experiments)
 
 }  // namespace
@@ -718,6 +747,7 @@ int g_planes_force_tile = 0;     // 0 auto, 1: 64x64, 2: 128x128 (experiments)
 extern "C" {
 
 int genrl_planes_force_tile(int t) { const int p = g_planes_force_tile; g_planes_force_tile = t; return p; }
+int genrl_planes_variant(int v) { const int p = g_planes_variant; g_planes_variant = v; return p; }
 
 /* x (R x Cn fp32, row stride ldx) -> three bf16 planes [R][ld_out] (or [Cn][ld_out] when transpose), zero padded */
 int genrl_split_x3(const float* x, long ldx, int R, int Cn, uint16_t* out, long ld_out, long plane, int transpose,
@@ -834,6 +864,22 @@ static int gemm_h2_impl(const uint16_t* a0, long a0_ld, long a0_plane, const flo
   const long t64 = (long)cdiv(M, 64) * cdiv(N, 64);
   // (128x128 tiles for the 1024x3072 GRU products -- 192 tiles -- measured neutral in the step: 29.65 vs 29.72 ms)
   const bool big = smp.q ? false : (g_planes_force_tile ? g_planes_force_tile == 2 : t64 >= 2048);
+  static const bool nosplit_env = getenv("GENRL_PLANES_NOSPLIT") != nullptr;
+  if (big && !g_planes_force_tile && !g_planes_nosplit && !nosplit_env) {
+    // wave quantisation: one 128x128 tile per CU at a time, so 1088 tiles (17 x 1024 rows, N = 1024) take five rounds of
+    // the 256 CUs -- 206 us against 146 for the 1024 tiles of 16384 rows.  When the last, partial round is small and made of
+    // whole row panels, those rows go to a second launch (64x64 tiles for 1024 rows: ~14 us).
+    const int tm = cdiv(M, 128), tn = cdiv(N, 128), total = tm * tn, r = total % 256;
+    if (total > 256 && r && r <= 128 && r % tn == 0 && (M & 127) == 0) {
+      const int M1 = (tm - r / tn) * 128, M2 = M - M1;
+      int rc = gemm_h2_impl(a0, a0_ld, a0_plane, a0_inv, b0, b0_ld, b0_plane, b0_inv, k0, a1, a1_ld, a1_plane, a1_inv, b1, b1_ld, b1_plane,
+                            b1_inv, k1, C, ldc, bias, M1, N, accumulate, stream, smp);
+      if (rc != GENRL_OK) return rc;
+      return gemm_h2_impl(a0 + (long)M1 * a0_ld, a0_ld, a0_plane, a0_inv ? a0_inv + M1 : nullptr, b0, b0_ld, b0_plane, b0_inv, k0,
+                          a1 ? a1 + (long)M1 * a1_ld : nullptr, a1_ld, a1_plane, a1_inv ? a1_inv + M1 : nullptr, b1, b1_ld, b1_plane, b1_inv, k1,
+                          C + (long)M1 * ldc, ldc, bias, M2, N, accumulate, stream, smp);
+    }
+  }
   if (big) {
     // 128x128 tiles, BK 64, two 64 KiB stages (136 us on 16384x1024x1024 against 146 with BK 32 / four stages; the
     // boundary rescale of a second segment does not fit this tile's register budget: two launches, the second accumulating)
@@ -847,6 +893,12 @@ static int gemm_h2_impl(const uint16_t* a0, long a0_ld, long a0_plane, const flo
       if (bk32)
         gemm_planes_kernel<2, 2, 32, 2, 1, 4, false><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
                                                                                            xcd_split(tm, tn), SampleEpi{}, ConvGather{});
+      else if (g_planes_variant == 1 || g_planes_variant == 6)
+        gemm_planes_kernel<2, 2, 64, 2, 1, 2, false, false, 2><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
+                                                                                           xcd_split(tm, tn), SampleEpi{}, ConvGather{});
+      else if (g_planes_variant == 2 || g_planes_variant == 3)
+        gemm_planes_kernel<2, 2, 64, 2, 1, 2, false, false, 4><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
+                                                                                           xcd_split(tm, tn), SampleEpi{}, ConvGather{});
       else
         gemm_planes_kernel<2, 2, 64, 2, 1, 2, false><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
                                                                                            xcd_split(tm, tn), SampleEpi{}, ConvGather{});
@@ -856,8 +908,18 @@ static int gemm_h2_impl(const uint16_t* a0, long a0_ld, long a0_plane, const flo
     const int tm = cdiv(M, 64), tn = cdiv(N, 64);
     // three 32 KiB stages (96 KiB): a fourth stage measured +0.6 ms on the whole step (28.86 vs 28.2 ms) -- with 128 KiB
     // taken, the other streams' small kernels (32 KiB weight-streaming workgroups) cannot share a CU with this one
-    gemm_planes_kernel<1, 1, 64, 3, 1, 3><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, s1, C, ldc, bias, M, N, accumulate, tm, tn,
-                                                                                xcd_split(tm, tn), smp, ConvGather{});
+#define L64(NS_, PF_) gemm_planes_kernel<1, 1, 64, 3, 1, NS_, true, false, PF_><<<tm * tn, 256, 0, (hipStream_t)stream>>>( \
+    s0, s1, C, ldc, bias, M, N, accumulate, tm, tn, xcd_split(tm, tn), smp, ConvGather{})
+    switch (g_planes_variant) {
+      case 1: L64(3, 3); break;
+      case 2: L64(3, 6); break;
+      case 3: L64(3, 10); break;
+      case 4: L64(4, 0); break;
+      case 5: L64(5, 0); break;
+      case 6: L64(2, 6); break;
+      default: L64(3, 0);
+    }
+#undef L64
   }
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;

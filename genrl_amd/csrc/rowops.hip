@@ -1323,7 +1323,7 @@ static int ln_act_bwd_impl(const float* dy, long lddy, const float* x, long ldx,
   GENRL_ENTER();
   if (M <= 0) return GENRL_OK;
   if (amax_ws && !(N <= 256 && M >= 64 && NARROW_LN)) return GENRL_EINVAL;      // (uniform planes: the channel-LayerNorm kernel only)
-  if (xo.p && (!xo.inv || (xo.ld & 3) || xo.ld < N || !dx)) return GENRL_EINVAL;
+  if (xo.p && (!xo.inv || (xo.ld & 3) || xo.ld < N)) return GENRL_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const bool fast = N > 256 && N <= 4096 && (N & 3) == 0 && (lddy & 3) == 0 && (ldx & 3) == 0 &&
                     (!dx || ((lddx & 3) == 0 && aligned16(dx))) && aligned16(dy) && aligned16(x) &&
@@ -1331,6 +1331,7 @@ static int ln_act_bwd_impl(const float* dy, long lddy, const float* x, long ldx,
   const bool narrow = N <= 256 && (N & 3) == 0 && (lddy & 3) == 0 && (ldx & 3) == 0 &&
                       (!dx || ((lddx & 3) == 0 && aligned16(dx))) && aligned16(dy) && aligned16(x) && aligned16(gamma) &&
                       aligned16(beta) && (!dgamma || aligned16(ws)) && M >= 64 && (dgamma || !dcolsum) && NARROW_LN;
+  if (xo.p && !dx && !(fast && !narrow)) return GENRL_EINVAL;   // (planes without the fp32 copy: the kernels that write planes themselves)
   if (narrow) {
     const int gl = N <= 64 ? 16 : (N <= 128 ? 32 : 64);
     const int grid = (int)std::min<long>(cdiv(M, 4 * (64 / gl)), blk_grid_for(M));

@@ -299,7 +299,12 @@ class _DenseLNActPlanes(Function):
         dev = dy.device
         b = ctx.bias
         dy2 = dy.reshape(M, N).contiguous()
-        dpre = torch.empty_like(pre)
+        ip = ctx.in_planes
+        use_tn = ip is not None and planes.tn_ok(M, N, K1, K) and (not ctx.has2 or K2 % 4 == 0)
+        # the fp32 copy of the pre-activation gradient has one reader, the fp32-operand weight-gradient kernel: with that product
+        # on planes (genrl_gemm_h2_tn) the LayerNorm backward writes planes only (a quarter of its traffic less)
+        planes_only = 256 < N <= 4096 and N % 4 == 0          # (the LayerNorm kernels that write planes themselves)
+        dpre = torch.empty_like(pre) if ((ctx.needs_input_grad[2] and not use_tn) or not planes_only) else None
         dpre_p = planes.Planes(M, N, dev)
         need_p = ctx.needs_input_grad[2] or ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         tg, tb, tc = _grad_buf(gamma), _grad_buf(beta), (_grad_buf(b) if b is not None else None)
@@ -312,7 +317,7 @@ class _DenseLNActPlanes(Function):
         else:
             g0 = g1 = g2 = None; acc_p = 0
         ws = _ws(lib().genrl_ln_ws_floats(M, N), dev) if need_p else None
-        _ln_bwd(_p(dy2), _p(pre), gamma, beta, _p(mean), _p(rstd), _p(dpre), M, N, dpre_p, 0, g0, g1, g2, ws, acc_p)
+        _ln_bwd(_p(dy2), _p(pre), gamma, beta, _p(mean), _p(rstd), _p(dpre) if dpre is not None else None, M, N, dpre_p, 0, g0, g1, g2, ws, acc_p)
         d1 = d2 = dW = None
         if ctx.needs_input_grad[0]:
             d1 = torch.empty(M, K1, device=dev)
@@ -327,8 +332,7 @@ class _DenseLNActPlanes(Function):
             acc = tgt is not None
             if not acc:
                 dW = tgt = torch.empty(N, K, device=dev)
-            ip = ctx.in_planes
-            if ip is not None and planes.tn_ok(M, N, K1, K) and (not ctx.has2 or K2 % 4 == 0):
+            if use_tn:
                 planes.gemm_tn(dpre_p, ip[0][0], tgt, K, N, K1, M, accumulate=acc, b_row0=ip[0][1])
                 if ctx.has2:
                     planes.gemm_tn(dpre_p, ip[1][0], tgt, K, N, K2, M, accumulate=acc, b_row0=ip[1][1], c_off=K1)

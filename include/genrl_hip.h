@@ -162,11 +162,13 @@ int genrl_gemm_x3(const uint16_t* a0, long a0_ld, long a0_plane, const uint16_t*
                   const uint16_t* a1, long a1_ld, long a1_plane, const uint16_t* b1, long b1_ld, long b1_plane, int k1,
                   float* C, long ldc, const float* bias, int M, int N, int accumulate, void* stream);
 int genrl_planes_force_tile(int t);      /* experiments: 0 auto, 1 64x64 tiles, 2 128x128 tiles (both formats) */
+int genrl_planes_variant(int v);         /* experiments: ring depth / L2 prefetch distance of the plane kernels (scripts/cold_bench.py) */
 
 /* Row kernels with an additional h2-plane output (the operand of the next genrl_gemm_h2): same arithmetic and fp32
  * outputs as the entry points without the suffix (documented below), plus planes [.][ldp] `plane` elements apart and
  * inv[row] (the row maximum is taken over the kernel's output row).  ldp % 4 == 0, ldp >= row length; columns beyond the
- * row length are left untouched (callers zero them once). */
+ * row length are left untouched (callers zero them once).  genrl_ln_act_bwd_h2 with 256 < N <= 4096 accepts dx == NULL: planes
+ * only (the fp32 copy has no reader when dgrad AND weight gradient run on planes). */
 int genrl_ln_act_fwd_h2(const float* x, long ldx, const float* gamma, const float* beta, float* y, long ldy, float* mean,
                         float* rstd, int M, int N, float eps, int act, uint16_t* yp, long ldp, long plane, float* inv,
                         void* stream);

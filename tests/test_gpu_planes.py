@@ -179,6 +179,49 @@ def test_row_kernels_emit_planes(env, M, N):
                                 P.inv_ptr(0), st), 'lnb_h2')
     assert torch.equal(d0, d1)
     _planes_equal_split(planes, P, d1, row0=0)
+    # planes only (dx == NULL, the kernels that write planes themselves: 256 < N <= 4096): same planes, same parameter partials
+    if 256 < N <= 4096:
+        P2 = planes.Planes(M, N, 'cuda')
+        ws = torch.empty(L.genrl_ln_ws_floats(M, N), device='cuda')
+        ga, gb = torch.empty(2, N, device='cuda'), torch.empty(2, N, device='cuda')
+        for k, (dxp, PP) in enumerate([(d1.data_ptr(), P), (None, P2)]):
+            check(L.genrl_ln_act_bwd_h2(dy.data_ptr(), N, x.data_ptr(), N, gam.data_ptr(), bet.data_ptr(), mean.data_ptr(),
+                                        rstd.data_ptr(), dxp, N, ga[k].data_ptr(), gb[k].data_ptr(), None, ws.data_ptr(), M, N, 1, 0,
+                                        PP.ptr(0), PP.ld, PP.plane, PP.inv_ptr(0), st), 'lnb_h2')
+        assert torch.equal(P2.t[:, :M], P.t[:, :M]) and torch.equal(P2.inv[:M], P.inv[:M])
+        assert torch.equal(ga[0], ga[1]) and torch.equal(gb[0], gb[1])
+    else:       # the lane-group / generic variants split their fp32 output in a second pass: dx is required
+        assert L.genrl_ln_act_bwd_h2(dy.data_ptr(), N, x.data_ptr(), N, gam.data_ptr(), bet.data_ptr(), mean.data_ptr(),
+                                     rstd.data_ptr(), None, N, None, None, None, None, M, N, 1, 0, P.ptr(0), P.ld, P.plane,
+                                     P.inv_ptr(0), st) == 1
+
+
+def test_gemm_h2_row_split_against_wave_quantisation(env):
+    """17 x 1024 rows (the imagined trajectory incl. its start row) x 1024 columns = 1088 128x128 tiles = 4.25 rounds of the
+    256 CUs: the last 1024 rows run as a second launch (64x64 tiles).  Same result as the unsplit product, also with two
+    operand segments, a bias and accumulation."""
+    planes, ops, L, check = env
+    g = torch.Generator(device='cuda').manual_seed(17)
+    M, N, K0, K1 = 17408, 1024, 128, 64
+    A0 = torch.randn(M, K0, device='cuda', generator=g); A1 = torch.randn(M, K1, device='cuda', generator=g) * 30
+    W = torch.randn(N, K0 + K1, device='cuda', generator=g) * 0.1
+    bias = torch.randn(N, device='cuda', generator=g)
+    C0 = torch.randn(M, N, device='cuda', generator=g)
+    a0, a1, w0, w1 = planes.split(A0), planes.split(A1), planes.split(W[:, :K0]), planes.split(W[:, K0:])
+    out = []
+    for force in (0, 2):                          # 0: the default policy (split); 2: one launch of 128x128 tiles
+        C = C0.clone()
+        prev = L.genrl_planes_force_tile(force)
+        try:
+            planes.gemm(a0, w0, C, N, bias, M, N, accumulate=True, A1=a1, B1=w1)
+        finally:
+            L.genrl_planes_force_tile(prev)
+        out.append(C)
+    ref = C0.double() + bias.double() + A0.double() @ W[:, :K0].double().t() + A1.double() @ W[:, K0:].double().t()
+    scale = (A0.double().abs() @ W[:, :K0].double().abs().t() + A1.double().abs() @ W[:, K0:].double().abs().t()).mean().item()
+    for C in out:
+        assert ((C.double() - ref).abs().max().item() / scale) < 1e-6
+    assert torch.equal(out[0][:16384], out[1][:16384])          # the first launch is the same kernel on the same tiles
 
 
 @pytest.mark.parametrize('R,D', [(50, 32), (130, 1024)])
