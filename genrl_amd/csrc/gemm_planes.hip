@@ -107,11 +107,11 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
   constexpr int NPA = APIECES / 2, NPB = BPIECES / 2;  // pieces per wave (waves 0,1: A; waves 2,3: B)
   constexpr int NPMAX = NPA > NPB ? NPA : NPB;
   constexpr int KS = BK / 16;                          // MFMA k-steps per stage
-  // PF > 0: every stage's DMAs are preceded by an L2 PREFETCH of the stage PF further on -- one 4-byte LDS-DMA per 128-byte line
-  // (NPF wave-instructions per wave) into a 1 KiB dummy area.  The ring bounds the bytes in flight per CU (NS x 32 KiB); when the
-  // operands are cold in this XCD's L2 (inside the step they always are: the activations were written by the previous launch, the
-  // weights were last read a rollout step ago) the product runs at (ring bytes) / (fabric latency), and the prefetch moves that
-  // latency off the ring without taking LDS.
+  // PF > 0 (experiment, -DPLANES_EXPERIMENTS): every stage's DMAs are preceded by an L2 PREFETCH of the stage PF further on -- one
+  // 4-byte LDS-DMA per 128-byte line (NPF wave-instructions per wave) into a 1 KiB dummy area -- to test whether the K loop waits on
+  // L2 misses (operands are never L2-resident at a kernel's start).  It does not: 1024^3 takes 14.1-15.7 us with the prefetch against
+  // 12.2-13.4 without, on warm and on cold operands alike, and rings of 4 / 5 stages change nothing either (scripts/cold_bench.py,
+  // profiles/r03_inshape.txt).  The loop runs at the L2 -> LDS delivery rate of this access pattern (~17 TB/s over the chip).
   static_assert(PF == 0 || (BK == 64 && !CONV), "prefetch: 128-byte tile rows, plain operands");
   constexpr int NPF = PF ? TM : 0;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE + (PF ? 1024 : 0)];
@@ -902,12 +902,14 @@ static int gemm_h2_impl(const uint16_t* a0, long a0_ld, long a0_plane, const flo
       if (bk32)
         gemm_planes_kernel<2, 2, 32, 2, 1, 4, false><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
                                                                                            xcd_split(tm, tn), SampleEpi{}, ConvGather{});
+#ifdef PLANES_EXPERIMENTS
       else if (g_planes_variant == 1 || g_planes_variant == 6)
         gemm_planes_kernel<2, 2, 64, 2, 1, 2, false, false, 2><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
                                                                                            xcd_split(tm, tn), SampleEpi{}, ConvGather{});
       else if (g_planes_variant == 2 || g_planes_variant == 3)
         gemm_planes_kernel<2, 2, 64, 2, 1, 2, false, false, 4><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
                                                                                            xcd_split(tm, tn), SampleEpi{}, ConvGather{});
+#endif
       else
         gemm_planes_kernel<2, 2, 64, 2, 1, 2, false><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
                                                                                            xcd_split(tm, tn), SampleEpi{}, ConvGather{});
@@ -920,6 +922,7 @@ static int gemm_h2_impl(const uint16_t* a0, long a0_ld, long a0_plane, const flo
     log_launch("h2/64", M, N, k0 + k1);
 #define L64(NS_, PF_) gemm_planes_kernel<1, 1, 64, 3, 1, NS_, true, false, PF_><<<tm * tn, 256, 0, (hipStream_t)stream>>>( \
     s0, s1, C, ldc, bias, M, N, accumulate, tm, tn, xcd_split(tm, tn), smp, ConvGather{})
+#ifdef PLANES_EXPERIMENTS      /* ring depth / L2 prefetch variants for scripts/cold_bench.py (hipcc -DPLANES_EXPERIMENTS) */
     switch (g_planes_variant) {
       case 1: L64(3, 3); break;
       case 2: L64(3, 6); break;
@@ -929,6 +932,9 @@ static int gemm_h2_impl(const uint16_t* a0, long a0_ld, long a0_plane, const flo
       case 6: L64(2, 6); break;
       default: L64(3, 0);
     }
+#else
+    L64(3, 0);
+#endif
 #undef L64
   }
   GENRL_CHECK_LAUNCH();

@@ -1,7 +1,8 @@
 """The plane GEMM with operands COLD in the per-XCD L2s, as it meets them inside the step: a rotation over `nset` distinct
 (A, W, C) sets (activations written by a producer launch right before the product, weights last read nset launches ago) against
 the same launch repeated back to back (operands L2-resident).  Variants of genrl_planes_variant: ring depth, L2 prefetch
-distance.  GPU box only: python scripts/cold_bench.py"""
+distance -- compiled in by scripts/build_exp.sh (the shipped library holds 'ring 3' only and ignores the switch).
+GPU box only: scripts/build_exp.sh && GENRL_HIP_SO=gpurun_exp.so python scripts/cold_bench.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
