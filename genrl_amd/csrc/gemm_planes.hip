@@ -114,7 +114,11 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
   // profiles/r03_inshape.txt).  The loop runs at the L2 -> LDS delivery rate of this access pattern (~17 TB/s over the chip).
   static_assert(PF == 0 || (BK == 64 && !CONV), "prefetch: 128-byte tile rows, plain operands");
   constexpr int NPF = PF ? TM : 0;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE + (PF ? 1024 : 0)];
+  // h2: the epilogue's factors -- inverse row scales of both operands, bias -- are fetched by three LDS-DMAs per 64 rows / columns
+  // BEFORE the first stage (older than every stage DMA: the counted waits and the first barrier cover them), instead of as global
+  // loads behind the last MFMA, where their latency was exposed once per workgroup
+  constexpr int EPI = FMT == 1 ? 4 * (BM + 2 * BN) : 0, EPI_AT = NS * STAGE + (PF ? 1024 : 0);
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[EPI_AT + EPI];
 
   // XCD-aware tile order (workgroup b runs on XCD b % 8; each XCD gets a compact sub-block of the tile grid)
   int bid = blockIdx.x, tile_m, tile_n;
@@ -258,6 +262,20 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
 #endif
   };
 
+  const float* const ainv_l = s1.k ? s1.a_inv : s0.a_inv;       // (the epilogue undoes the scaling of the LAST segment)
+  const float* const binv_l = s1.k ? s1.b_inv : s0.b_inv;
+  if constexpr (FMT == 1) {
+    const float* src = wave == 0 ? ainv_l : (wave == 1 ? binv_l : (wave == 2 ? bias : nullptr));
+    const int base = wave == 0 ? m0 : n0, lim = (wave == 0 ? M : N) - 1, cnt = (wave == 0 ? BM : BN) / 64;
+    const unsigned dst = lds0 + EPI_AT + (wave == 0 ? 0 : (wave == 1 ? 4 * BM : 4 * (BM + BN)));
+    if (src) {
+#pragma unroll
+      for (int j = 0; j < (BM > BN ? BM : BN) / 64; ++j)
+        if (j < cnt)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + min(base + 64 * j + lane, lim)),
+                                           (__attribute__((address_space(3))) void*)(uintptr_t)(dst + 256 * j), 4, 0, 0);
+    }
+  }
   const int nk0 = s0.k / BK, nk = nk0 + s1.k / BK;
   static_assert(NPA == NPB, "square wave grids only (one DMA count per wave)");
   constexpr int NP = NPA;
@@ -412,14 +430,22 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
   wait_vm<0>();                       // no DMA may be in flight into this workgroup's LDS when it exits
 
   // ---- epilogue: lane (l32, h32), register v of block (i, j) = C[m = l32][n = 8 (v/4) + 4 h32 + v%4]
-  const float* ainv = s1.k ? s1.a_inv : s0.a_inv;
-  const float* binv = s1.k ? s1.b_inv : s0.b_inv;
+  const float* ainv = ainv_l;
+  const float* binv = binv_l;
+  auto epi_f = [&](int idx) __attribute__((always_inline)) -> float {
+    return *reinterpret_cast<const __attribute__((address_space(3))) float*>((uintptr_t)(lds0 + EPI_AT + 4 * idx));
+  };
+  auto epi_f4 = [&](int idx) __attribute__((always_inline)) -> float4 {
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    const f32x4_ t = *reinterpret_cast<const __attribute__((address_space(3))) f32x4_*>((uintptr_t)(lds0 + EPI_AT + 4 * idx));
+    return make_float4(t[0], t[1], t[2], t[3]);
+  };
   const bool vec_c = ((ldc & 3) == 0) && (((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int row = m0 + (wm * TM + i) * 32 + l32;
     if (row >= M) continue;
-    const float ra = ainv ? ainv[row] : 1.f;
+    const float ra = ainv ? (FMT == 1 ? epi_f((wm * TM + i) * 32 + l32) : ainv[row]) : 1.f;
     float lg[16];                         // (sampling epilogue: the lane's 16 logits of the row, TM == TN == 1)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -428,6 +454,12 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
         const int col = n0 + (wn * TN + j) * 32 + 8 * gq + 4 * h32;
         if (col >= N) continue;
         float o[4];
+        float cbv[4] = {1.f, 1.f, 1.f, 1.f}, bsv[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (FMT == 1) {          // (columns beyond N: the clamped last column's values, never stored)
+          const int ci = (wn * TN + j) * 32 + 8 * gq + 4 * h32;
+          if (binv) { const float4 t = epi_f4(BM + ci); cbv[0] = t.x; cbv[1] = t.y; cbv[2] = t.z; cbv[3] = t.w; }
+          if (bias) { const float4 t = epi_f4(BM + BN + ci); bsv[0] = t.x; bsv[1] = t.y; bsv[2] = t.z; bsv[3] = t.w; }
+        }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           if constexpr (FMT == 0) {
@@ -438,13 +470,14 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
           } else {        // low class (residuals are stored x 2^11) first, then the h*h sum; undo the row scalings
             const float lo = NACC == 3 ? acc[0][i][j][4 * gq + v] + acc[2][i][j][4 * gq + v] : acc[0][i][j][4 * gq + v];
             const float x = lo * (1.f / 2048.f) + acc[1][i][j][4 * gq + v];
-            const int cc = min(col + v, N - 1);
-            o[v] = x * ra * (binv ? binv[cc] : 1.f);
+            o[v] = x * ra * cbv[v];
           }
         }
         float* c = C + (long)row * ldc + col;
         if (vec_c && col + 3 < N) {
-          if (bias) {
+          if constexpr (FMT == 1) {
+            o[0] += bsv[0]; o[1] += bsv[1]; o[2] += bsv[2]; o[3] += bsv[3];
+          } else if (bias) {
             const float4 bv = *reinterpret_cast<const float4*>(bias + col);
             o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
           }
@@ -461,7 +494,7 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
 #pragma unroll
           for (int v = 0; v < 4; ++v)
             if (col + v < N) {
-              float val = o[v] + (bias ? bias[col + v] : 0.f);
+              float val = o[v] + (FMT == 1 ? bsv[v] : (bias ? bias[col + v] : 0.f));
               if (accumulate) val += c[v];
               c[v] = val;
             }

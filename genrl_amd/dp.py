@@ -30,6 +30,10 @@ def init(backend=None):
             backend = os.environ.get('GENRL_DP_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
+            # a HIP error met by the process group's watchdog thread (it polls completion events; HIP refuses the query of an event
+            # whose stream has gone into capture -- graph.GraphedStep drains the watchdog's list before every capture so that this
+            # does not happen) must not abort the run: log it, do not rethrow
+            os.environ.setdefault('TORCH_NCCL_RETHROW_CUDA_ERRORS', '0')
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 

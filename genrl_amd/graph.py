@@ -103,7 +103,21 @@ class GraphedStep:
         for g, d in zip(self._groups_captured, self._step_delta):
             g.step -= d
 
+    @staticmethod
+    def _drain_backend():
+        """RCCL: the process group's watchdog thread polls the completion event of every EAGER collective still on its list
+        (hipEventQuery, every 100 ms); HIP refuses that query -- 'operation not permitted on an event last recorded in a capturing
+        stream', which the watchdog turns into an abort of the process -- once the stream the event was recorded on is capturing.
+        Collectives issued during a capture are not put on that list, so it is enough to let the list run empty before a capture
+        begins: everything finished on the device, then two polling periods for the watchdog to reap it."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl':
+            import time
+            torch.cuda.synchronize()
+            time.sleep(0.25)
+
     def _begin(self):
+        self._drain_backend()
         self._g = torch.cuda.CUDAGraph()
         # thread_local: collectives started at a cut may still be progressing on the backend's own threads (gloo's workers,
         # the RCCL watchdog) while the next graph is being captured; only THIS thread's calls belong to the capture
