@@ -1,6 +1,6 @@
 """The plane GEMM with operands COLD in the per-XCD L2s, as it meets them inside the step: a rotation over `nset` distinct
 (A, W, C) sets (activations written by a producer launch right before the product, weights last read nset launches ago) against
-the same launch repeated back to back (operands L2-resident).  Variants of genrl_planes_variant: ring depth, L2 prefetch
+the same launch repeated back to back (operands L2-resident).  Variants of genrl_planes_variant: ring depth (2, 4; five stages no longer fit beside the epilogue factors), L2 prefetch
 distance -- compiled in by scripts/build_exp.sh (the shipped library holds 'ring 3' only and ignores the switch).
 GPU box only: scripts/build_exp.sh && GENRL_HIP_SO=gpurun_exp.so python scripts/cold_bench.py"""
 import sys, os
@@ -12,7 +12,7 @@ from x3_bench import dev
 from small_m import graph_time
 
 VARIANTS = {0: 'ring 3', 1: 'ring 3 + prefetch 3 (128-tile: ring 2 + prefetch 2)', 2: 'ring 3 + prefetch 6 (128: +4)', 3: 'ring 3 + prefetch 10 (128: +4)',
-            4: 'ring 4', 5: 'ring 5', 6: 'ring 2 + prefetch 6 (128: +2)'}
+            4: 'ring 4', 6: 'ring 2 + prefetch 6 (128: +2)'}
 
 
 def run(M, N, K, nset, with_producer):
