@@ -693,10 +693,12 @@ class Optimizer:
         group = self._group_for(live)
         group.rebind()
         ops.direct_grads = True        # weight-gradient kernels accumulate straight into the flat gradient buffers
+        ops.defer_begin()              # ... and the LayerNorm backward passes leave their parameter-gradient partials unreduced
         try:
             loss.backward(gradient=_one_like(loss))       # (a cached seed: torch would fill a fresh ones tensor per call)
         finally:
             ops.direct_grads = False
+            ops.defer_flush()          # one launch sums them all (the backward pass's streams have been joined by autograd)
         ops.wgrad_stream.join()
         if Optimizer.grad_hook is not None:
             Optimizer.grad_hook(self._name, live)

@@ -4,6 +4,7 @@
 // All are HBM/L2-bound: one 64-lane wave owns one row, lanes stride the row so every global
 // access is a coalesced 256-B segment, reductions are wavefront shuffles (no LDS).
 #include "common.h"
+#include "genrl_hip.h"
 #include <algorithm>
 
 #include <cstdlib>
@@ -322,6 +323,39 @@ static inline void reduce_cols(const float* part, float* tmp, float* out, int nc
                        (float*)nullptr, nchunk, N, 1, accumulate);
   } else {
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, part, out, nchunk, (long)N, accumulate);
+  }
+}
+// ---- MANY partial-row sets in one launch (the LayerNorm parameter gradients of a whole backward pass, deferred by the host:
+// genrl_reduce_params_batch): descriptors by value in the kernel arguments (<= 24 per launch), a workgroup finds its set by a scan
+// of the prefix table; per set the arithmetic and the summation order of reduce_chunks2m_kernel (nchunk <= REDUCE2M_MAX)
+struct ReduceEntry {
+  const float* part; float* out0; float* out1; float* out2;
+  int nchunk, N, np, accumulate;
+};
+struct ReduceBatch {
+  int n;
+  int blk0[25];
+  ReduceEntry e[24];
+};
+__global__ __launch_bounds__(256) void reduce_params_batch_kernel(ReduceBatch b) {
+  __shared__ float sm[4][64];
+  int i = 0;
+  while (i + 1 < b.n && (int)blockIdx.x >= b.blk0[i + 1]) ++i;
+  const ReduceEntry& e = b.e[i];
+  const int j = ((int)blockIdx.x - b.blk0[i]) * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  const long stride = (long)e.np * e.N;
+  float s = 0.f;
+  if (j < e.np * e.N) {
+#pragma unroll 4
+    for (int c = sub; c < e.nchunk; c += 4) s += e.part[(long)c * stride + j];
+  }
+  sm[sub][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sub == 0 && j < e.np * e.N) {
+    const int l = threadIdx.x;
+    const float t = sm[0][l] + sm[1][l] + sm[2][l] + sm[3][l];
+    float* o = j < e.N ? e.out0 + j : (j < 2 * e.N ? e.out1 + (j - e.N) : e.out2 + (j - 2 * e.N));
+    *o = e.accumulate ? *o + t : t;
   }
 }
 // helper: part[nchunk][2N] -> (out0 | out1); `tmp` must hold 16*2N floats when nchunk > 16
@@ -1314,6 +1348,42 @@ long genrl_ln_ws_floats(int M, int N) {
   return (long)((a > b ? a : b) + 16) * 3 * N;
 }
 
+/* number of partial rows genrl_ln_act_bwd[_h2] leaves in ws for an (M x N) call with dgamma != NULL (each np * N floats, np = 3 with
+ * dcolsum else 2), or 0 when the shape takes a kernel without per-workgroup partials (then accumulate_params & 4 is refused) */
+int genrl_ln_bwd_parts(int M, int N) {
+  if (M <= 0 || (N & 3)) return 0;
+  if (N <= 256) {
+    if (!(M >= 64 && NARROW_LN)) return 0;
+    const int gl = N <= 64 ? 16 : (N <= 128 ? 32 : 64);
+    return (int)std::min<long>(cdiv(M, 4 * (64 / gl)), blk_grid_for(M));
+  }
+  if (N > 4096) return 0;
+  if (N <= 1024 && WAVE_LN) return blk_grid_for(cdiv(M, 4));
+  return blk_grid_for(M);
+}
+
+/* n deferred reductions in ceil(n / 24) launches: out0 | out1 | out2 [N] (+)= sum over the nchunk partial rows part[c][np][N] */
+int genrl_reduce_params_batch(const genrl_reduce_desc* d, int n, void* stream) {
+  GENRL_ENTER();
+  if (n < 0 || (n && !d)) return GENRL_EINVAL;
+  for (int i = 0; i < n; ++i)
+    if (!d[i].part || !d[i].out0 || !d[i].out1 || d[i].nchunk <= 0 || d[i].nchunk > REDUCE2M_MAX || d[i].N <= 0 ||
+        (d[i].np != 2 && d[i].np != 3) || (d[i].np == 3 && !d[i].out2))
+      return GENRL_EINVAL;
+  for (int i0 = 0; i0 < n; i0 += 24) {
+    ReduceBatch b{};
+    b.n = std::min(24, n - i0);
+    for (int k = 0; k < b.n; ++k) {
+      const genrl_reduce_desc& e = d[i0 + k];
+      b.e[k] = ReduceEntry{e.part, e.out0, e.out1, e.out2, e.nchunk, e.N, e.np, e.accumulate};
+      b.blk0[k + 1] = b.blk0[k] + cdiv(e.np * e.N, 64);
+    }
+    reduce_params_batch_kernel<<<b.blk0[b.n], 256, 0, (hipStream_t)stream>>>(b);
+    GENRL_CHECK_LAUNCH();
+  }
+  return GENRL_OK;
+}
+
 // dcolsum (optional, needs dgamma/dbeta too): column sums of dx, i.e. the bias gradient of the Linear
 // layer in front of this LayerNorm.
 static int ln_act_bwd_impl(const float* dy, long lddy, const float* x, long ldx, const float* gamma,
@@ -1332,6 +1402,11 @@ static int ln_act_bwd_impl(const float* dy, long lddy, const float* x, long ldx,
                       (!dx || ((lddx & 3) == 0 && aligned16(dx))) && aligned16(dy) && aligned16(x) && aligned16(gamma) &&
                       aligned16(beta) && (!dgamma || aligned16(ws)) && M >= 64 && (dgamma || !dcolsum) && NARROW_LN;
   if (xo.p && !dx && !(fast && !narrow)) return GENRL_EINVAL;   // (planes without the fp32 copy: the kernels that write planes themselves)
+  // accumulate_params & 4: the caller reduces the partial rows itself, later and together with others (genrl_reduce_params_batch;
+  // genrl_ln_bwd_parts says how many rows there are) -- only the kernels that leave per-workgroup partials can do that
+  const bool defer = (accumulate_params & 4) != 0;
+  accumulate_params &= 1;
+  if (defer && (!dgamma || !(fast || narrow))) return GENRL_EINVAL;
   if (narrow) {
     const int gl = N <= 64 ? 16 : (N <= 128 ? 32 : 64);
     const int grid = (int)std::min<long>(cdiv(M, 4 * (64 / gl)), blk_grid_for(M));
@@ -1340,7 +1415,7 @@ static int ln_act_bwd_impl(const float* dy, long lddy, const float* x, long ldx,
 #define GO(GLV) hipLaunchKernelGGL((ln_act_bwd_grp_kernel<GLV>), dim3(grid), dim3(256), 0, s, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, part, M, N, act, np, amax_ws)
     if (gl == 16) GO(16); else if (gl == 32) GO(32); else GO(64);
 #undef GO
-    if (dgamma) reduce_params(ws, ws + (long)grid * np * N, dgamma, dbeta, grid, N, accumulate_params, s, dcolsum);
+    if (dgamma && !defer) reduce_params(ws, ws + (long)grid * np * N, dgamma, dbeta, grid, N, accumulate_params, s, dcolsum);
     GENRL_CHECK_LAUNCH();
     if (amax_ws) return xo.p ? split_h2u_from_parts(dx, lddx, M, N, xo, amax_ws, grid, stream) : GENRL_EINVAL;
     return xo.p ? split_after(dx, lddx, M, N, xo, stream) : GENRL_OK;
@@ -1353,7 +1428,7 @@ static int ln_act_bwd_impl(const float* dy, long lddy, const float* x, long ldx,
 #define GO(NV) hipLaunchKernelGGL((ln_act_bwd_wave_kernel<NV>), dim3(grid), dim3(256), 0, s, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, part, M, N, act, np, xo)
     if (nv == 2) GO(2); else if (nv == 3) GO(3); else GO(4);
 #undef GO
-    if (dgamma) reduce_params(ws, ws + (long)grid * np * N, dgamma, dbeta, grid, N, accumulate_params, s, dcolsum);
+    if (dgamma && !defer) reduce_params(ws, ws + (long)grid * np * N, dgamma, dbeta, grid, N, accumulate_params, s, dcolsum);
     GENRL_CHECK_LAUNCH();
     return GENRL_OK;
   }
@@ -1365,7 +1440,7 @@ static int ln_act_bwd_impl(const float* dy, long lddy, const float* x, long ldx,
 #define GO(NV) hipLaunchKernelGGL((ln_act_bwd_blk_kernel<NV>), dim3(grid), dim3(256), 0, s, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, part, M, N, act, np, xo)
     if (nv == 1) GO(1); else if (nv == 2) GO(2); else if (nv == 3) GO(3); else GO(4);
 #undef GO
-    if (dgamma) reduce_params(ws, ws + (long)grid * np * N, dgamma, dbeta, grid, N, accumulate_params, s, dcolsum);
+    if (dgamma && !defer) reduce_params(ws, ws + (long)grid * np * N, dgamma, dbeta, grid, N, accumulate_params, s, dcolsum);
     GENRL_CHECK_LAUNCH();
     return GENRL_OK;
   }

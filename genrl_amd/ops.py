@@ -2,6 +2,7 @@
 streams and the autograd graph; every flop of the hot path runs in the hand-written kernels.
 No CPU fallback: calling an op with a non-CUDA tensor raises."""
 import os
+import ctypes
 import torch
 from torch.autograd import Function
 
@@ -54,6 +55,61 @@ def _f32(t):
 
 
 direct_grads = False      # True only while Optimizer.__call__ runs loss.backward() (agent/dreamer_utils.Optimizer)
+
+# ---- deferred LayerNorm parameter-gradient reductions.  A LayerNorm backward leaves per-workgroup partial rows of (dgamma, dbeta
+# [, column sums of dx]) and sums them with a second launch; under the Optimizer -- where the sums are ADDED into the flat gradient
+# buffers and nobody reads them before the backward pass is over -- that second launch is skipped (accumulate_params & 4) and all
+# of a pass's partial sets are summed by one launch per 24 at its end (genrl_reduce_params_batch: same arithmetic, same order per
+# set; ~40 launches fewer per iteration).
+_deferred = None          # list of (ws tensor, parts, N, np, g0, g1, g2) while Optimizer.__call__ runs loss.backward()
+DEFER_REDUCTIONS = os.environ.get('GENRL_DEFER_REDUCTIONS', '1') != '0'
+
+
+def defer_begin():
+    global _deferred
+    _deferred = [] if DEFER_REDUCTIONS else None
+
+
+def defer_reduce(M, N, ws, g0, g1, g2=None):
+    """-> 4 (the flag for accumulate_params) when the reduction of this call's partial rows is taken over by defer_flush, else 0"""
+    if _deferred is None:
+        return 0
+    parts = lib().genrl_ln_bwd_parts(M, N)
+    if parts <= 0:
+        return 0
+    _deferred.append((ws, parts, N, 3 if g2 is not None else 2, g0, g1, g2))
+    return 4
+
+
+class _ReduceDesc(ctypes.Structure):          # genrl_reduce_desc (include/genrl_hip.h)
+    _fields_ = [('part', ctypes.c_void_p), ('out0', ctypes.c_void_p), ('out1', ctypes.c_void_p), ('out2', ctypes.c_void_p),
+                ('nchunk', ctypes.c_int), ('N', ctypes.c_int), ('np', ctypes.c_int), ('accumulate', ctypes.c_int)]
+
+
+def defer_flush():
+    """sum every partial set registered since defer_begin into its gradient buffers (on the current stream) and stop deferring"""
+    global _deferred
+    items, _deferred = _deferred, None
+    if not items:
+        return
+    # a parameter set used more than once in the pass (a shared layer) has several partial sets adding into the SAME buffers:
+    # those go into successive launches (within one launch every output has exactly one writer), in registration order
+    rounds = []
+    for it in items:
+        key = it[4].data_ptr()
+        for r in rounds:
+            if key not in r[0]:
+                break
+        else:
+            r = (set(), [])
+            rounds.append(r)
+        r[0].add(key); r[1].append(it)
+    for _, its in rounds:
+        arr = (_ReduceDesc * len(its))()
+        for d, (ws, parts, N, np_, g0, g1, g2) in zip(arr, its):
+            d.part, d.out0, d.out1, d.out2 = ws.data_ptr(), g0.data_ptr(), g1.data_ptr(), (g2.data_ptr() if g2 is not None else None)
+            d.nchunk, d.N, d.np, d.accumulate = parts, N, np_, 1
+        check(lib().genrl_reduce_params_batch(arr, len(its), _stream()), 'reduce_params_batch')
 
 
 def _grad_buf(p):
@@ -871,6 +927,8 @@ class ActorTape:
                 gb = torch.empty(3, U, device=dev)
                 g0, g1, g2, acc_p = gb[0], gb[1], gb[2], 0
             ws = _ws(lib().genrl_ln_ws_floats(M, U), dev)
+            if direct:
+                acc_p |= defer_reduce(M, U, ws, g0, g1, g2)
             check(lib().genrl_ln_act_bwd(_p(dy), U, _p(self.pre[l]), U, _p(gamma), _p(beta), _p(self.mean[l]),
                                          _p(self.rstd[l]), _p(dpre), U, _p(g0), _p(g1), _p(g2), _p(ws), M, U, 1, acc_p,
                                          _stream()), 'ln_act_bwd')
@@ -1102,8 +1160,9 @@ def _ln_bwd_rows(dy2d, pre2d, gamma, beta, mean, rstd, bias=None):
         gb = torch.empty(3, N, device=pre2d.device)
         g0, g1, g2 = gb[0], gb[1], gb[2]
     ws = _ws(lib().genrl_ln_ws_floats(M, N), pre2d.device)
+    acc_p = int(direct) | (defer_reduce(M, N, ws, g0, g1, g2) if direct else 0)
     check(lib().genrl_ln_act_bwd(_p(dy2d), N, _p(pre2d), N, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dpre), N,
-                                 _p(g0), _p(g1), _p(g2), _p(ws), M, N, 1, int(direct), _stream()), 'ln_act_bwd')
+                                 _p(g0), _p(g1), _p(g2), _p(ws), M, N, 1, acc_p, _stream()), 'ln_act_bwd')
     return (dpre, None, None, None) if direct else (dpre, g0, g1, g2)
 
 
@@ -1622,6 +1681,8 @@ class _DenseLNAct(Function):
         else:
             g0 = g1 = g2 = None; acc_p = 0
         ws = _ws(lib().genrl_ln_ws_floats(M, N), dev) if need_p else None
+        if direct:
+            acc_p |= defer_reduce(M, N, ws, g0, g1, g2)
         check(lib().genrl_ln_act_bwd(_p(dy2), N, _p(pre), N, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dpre), N,
                                      _p(g0), _p(g1), _p(g2), _p(ws), M, N, 1, acc_p, _stream()), 'ln_act_bwd')
         d1 = d2 = dW = None

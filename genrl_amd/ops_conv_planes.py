@@ -96,16 +96,17 @@ def _ln_bwd(dy2d, pre2d, gamma, beta, mean, rstd, bias, want_planes):
         gb = torch.empty(3, N, device=dev)
         g0, g1, g2 = gb[0], gb[1], gb[2]
     ws = _ws(lib().genrl_ln_ws_floats(M, N), dev)
+    acc_p = int(direct) | (ops.defer_reduce(M, N, ws, g0, g1, g2) if direct else 0)
     P = None
     if want_planes and N <= 256 and N % 4 == 0 and M >= 64:
         P = planes.Planes(M, N, dev, zero=False)
         amax = torch.empty(2048, device=dev)
         check(lib().genrl_ln_act_bwd_h2u(_p(dy2d), N, _p(pre2d), N, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dpre), N, _p(g0), _p(g1),
-                                         _p(g2), _p(ws), M, N, 1, int(direct), P.ptr(), P.ld, P.plane, P.inv_ptr(), _p(amax), _stream()),
+                                         _p(g2), _p(ws), M, N, 1, acc_p, P.ptr(), P.ld, P.plane, P.inv_ptr(), _p(amax), _stream()),
               'ln_act_bwd_h2u')
     else:
         check(lib().genrl_ln_act_bwd(_p(dy2d), N, _p(pre2d), N, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dpre), N, _p(g0), _p(g1),
-                                     _p(g2), _p(ws), M, N, 1, int(direct), _stream()), 'ln_act_bwd')
+                                     _p(g2), _p(ws), M, N, 1, acc_p, _stream()), 'ln_act_bwd')
         if want_planes and N % 4 == 0:
             P = _uniform_split(dpre)
     return (dpre, None, None, None, P) if direct else (dpre, g0, g1, g2, P)

@@ -95,6 +95,8 @@ class ActorTapePlanes(ops.ActorTape):
                 gb = torch.empty(3, U, device=dev)
                 g0, g1, g2, acc_p = gb[0], gb[1], gb[2], 0
             ws = _ws(lib().genrl_ln_ws_floats(M, U), dev)
+            if direct:
+                acc_p |= ops.defer_reduce(M, U, ws, g0, g1, g2)
             _ln_bwd(_p(dy), _p(self.pre[l]), gamma, beta, _p(self.mean[l]), _p(self.rstd[l]), _p(dpre), M, U, dpre_p, 0,
                     g0, g1, g2, ws, acc_p)
             tw = _grad_buf(W)
@@ -317,6 +319,8 @@ class _DenseLNActPlanes(Function):
         else:
             g0 = g1 = g2 = None; acc_p = 0
         ws = _ws(lib().genrl_ln_ws_floats(M, N), dev) if need_p else None
+        if direct:
+            acc_p |= ops.defer_reduce(M, N, ws, g0, g1, g2)
         _ln_bwd(_p(dy2), _p(pre), gamma, beta, _p(mean), _p(rstd), _p(dpre) if dpre is not None else None, M, N, dpre_p, 0, g0, g1, g2, ws, acc_p)
         d1 = d2 = dW = None
         if ctx.needs_input_grad[0]:

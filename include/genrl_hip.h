@@ -172,6 +172,16 @@ int genrl_planes_variant(int v);         /* experiments: ring depth / L2 prefetc
 int genrl_ln_act_fwd_h2(const float* x, long ldx, const float* gamma, const float* beta, float* y, long ldy, float* mean,
                         float* rstd, int M, int N, float eps, int act, uint16_t* yp, long ldp, long plane, float* inv,
                         void* stream);
+/* Deferred parameter-gradient reductions of the LayerNorm backward: with accumulate_params & 4 genrl_ln_act_bwd / _h2 / _h2u leave
+ * their per-workgroup partial rows in ws (genrl_ln_bwd_parts(M, N) rows of np * N floats, np = 3 with dcolsum else 2; 0 = this shape
+ * has no such kernel and the flag is refused) and the caller sums MANY of them in one launch per 24 at the end of the backward pass
+ * (same arithmetic and order as the immediate reduction; ws must stay untouched until then). */
+typedef struct {
+  const float* part; float* out0; float* out1; float* out2;   /* out2 NULL unless np == 3 */
+  int nchunk, N, np, accumulate;
+} genrl_reduce_desc;
+int genrl_ln_bwd_parts(int M, int N);
+int genrl_reduce_params_batch(const genrl_reduce_desc* descs, int n, void* stream);
 int genrl_ln_act_bwd_h2(const float* dy, long lddy, const float* x, long ldx, const float* gamma, const float* beta,
                         const float* mean, const float* rstd, float* dx, long lddx, float* dgamma, float* dbeta,
                         float* dcolsum, float* ws, int M, int N, int act, int accumulate_params, uint16_t* dxp, long ldp,

@@ -409,3 +409,53 @@ def test_sgemm_thin_products(ops, M, N, K):
             C2 = torch.empty(M, N, device='cuda')
             ops.sgemm(a, ars, aks, b, brs, bks, C2, N, None, M, N, K)
             assert torch.equal(C2.cpu().double(), want), (ars, aks, brs, bks)
+
+
+@pytest.mark.parametrize('M,N', [(1024, 1024), (300, 96), (4100, 512), (70, 3072), (4, 1024)])
+def test_deferred_ln_parameter_reductions_match_the_immediate_ones(ops, M, N):
+    """accumulate_params & 4: the LayerNorm backward leaves its per-workgroup partial rows, genrl_reduce_params_batch sums
+    many sets in one launch -- bit-identical to the immediate reduction; two sets adding into the SAME buffers (a shared
+    layer) are summed in successive launches by ops.defer_flush."""
+    from genrl_amd._lib import lib, check
+    L = lib()
+    gen = torch.Generator(device='cuda').manual_seed(M + N)
+    st = torch.cuda.current_stream().cuda_stream
+    parts = L.genrl_ln_bwd_parts(M, N)
+    assert parts > 0
+    sets = []
+    for k in range(3):
+        x = torch.randn(M, N, device='cuda', generator=gen); dy = torch.randn(M, N, device='cuda', generator=gen)
+        gam = torch.randn(N, device='cuda', generator=gen); bet = torch.randn(N, device='cuda', generator=gen)
+        mean, rstd = x.mean(1), 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)
+        sets.append((x, dy, gam, bet, mean.contiguous(), rstd.contiguous()))
+    g0 = torch.randn(2, 3, N, device='cuda', generator=gen)          # [set 0 / sets 1+2 share][dgamma, dbeta, colsum]
+    ref, got = g0.clone(), g0.clone()
+    dx_ref = []
+    for k, (x, dy, gam, bet, mean, rstd) in enumerate(sets):         # immediate, accumulating
+        o = ref[min(k, 1)]
+        dx = torch.empty_like(x); ws = torch.empty(L.genrl_ln_ws_floats(M, N), device='cuda')
+        check(L.genrl_ln_act_bwd(dy.data_ptr(), N, x.data_ptr(), N, gam.data_ptr(), bet.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                 dx.data_ptr(), N, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), ws.data_ptr(), M, N, 1, 1, st), 'ln_bwd')
+        dx_ref.append(dx)
+    ops.DEFER_REDUCTIONS, prev = True, ops.DEFER_REDUCTIONS
+    try:
+        ops.defer_begin()
+        for k, (x, dy, gam, bet, mean, rstd) in enumerate(sets):
+            o = got[min(k, 1)]
+            dx = torch.empty_like(x); ws = torch.empty(L.genrl_ln_ws_floats(M, N), device='cuda')
+            flag = ops.defer_reduce(M, N, ws, o[0], o[1], o[2])
+            assert flag == 4
+            check(L.genrl_ln_act_bwd(dy.data_ptr(), N, x.data_ptr(), N, gam.data_ptr(), bet.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                     dx.data_ptr(), N, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), ws.data_ptr(), M, N, 1, 1 | flag, st),
+                  'ln_bwd')
+            assert torch.equal(dx, dx_ref[k])
+        assert torch.equal(got, g0)                                   # nothing added yet
+        ops.defer_flush()
+    finally:
+        ops.DEFER_REDUCTIONS = prev
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], ref[0])                               # one set: the same sum in the same order
+    # two sets into one buffer: (g + s1) + s2 both ways
+    assert torch.equal(got[1], ref[1])
+    # shapes without per-workgroup partials refuse the flag
+    assert L.genrl_ln_bwd_parts(8, 32) == 0
