@@ -92,12 +92,7 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 
 // TM x TN 32x32 blocks per wave (2x2 waves per workgroup); BK = 64 (TM*TN == 1) or 32; NACC class accumulators;
 // FMT 0: x3 (three bf16 planes, six products), 1: h2 (two fp16 planes of the row-scaled value, three products); NS LDS stages
-// PERSIST (experiment, -DPLANES_EXPERIMENTS + GENRL_PLANES_PERSIST=1): the launch has one workgroup per CU and each walks the tiles
-// b, b + gridDim.x, ...; the next tile's first NS stages (and its epilogue factors) are put in flight BEFORE the current tile's
-// epilogue, so that the stores of one tile overlap with the operand fill of the next.  Measured on 16384 x 1024 x 1024 (four tiles
-// per CU): 120.4 vs 122.5 us back to back, 129 vs 127 us on cold operands, no difference in the step -- the time a tile spends
-// outside its K loop is its 64 KiB of C stores (64 MB per launch, all CUs at once), not the fill latency.  Not shipped.
-template <int TM, int TN, int BK, int NACC, int FMT, int NS, bool FOLD = true, bool CONV = false, int PF = 0, bool PERSIST = false>
+template <int TM, int TN, int BK, int NACC, int FMT, int NS, bool FOLD = true, bool CONV = false, int PF = 0>
 __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneSeg s1, float* __restrict__ C, long ldc,
                                                          const float* __restrict__ bias, int M, int N, int accumulate,
                                                          int tiles_m, int tiles_n, int xcd_m, SampleEpi smp, ConvGather cg) {
@@ -123,15 +118,13 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
   // BEFORE the first stage (older than every stage DMA: the counted waits and the first barrier cover them), instead of as global
   // loads behind the last MFMA, where their latency was exposed once per workgroup
   constexpr int EPI = FMT == 1 ? 4 * (BM + 2 * BN) : 0, EPI_AT = NS * STAGE + (PF ? 1024 : 0);
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[EPI_AT + (PERSIST ? 2 : 1) * EPI];
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[EPI_AT + EPI];
 
-  // XCD-aware tile order (workgroup b runs on XCD b % 8; each XCD gets a compact sub-block of the tile grid).  PERSIST: b is the
-  // virtual index blockIdx.x + round * gridDim.x (gridDim.x % 8 == 0, so a workgroup stays inside its XCD's sub-block)
-  const int ntiles = tiles_m * tiles_n;
-  int m0, n0;
-  auto decode_tile = [&](int b) __attribute__((always_inline)) {
-    int tile_m, tile_n;
-    const int x = b % 8, i = b / 8;
+  // XCD-aware tile order (workgroup b runs on XCD b % 8; each XCD gets a compact sub-block of the tile grid)
+  int bid = blockIdx.x, tile_m, tile_n;
+  {
+    const int ntiles = tiles_m * tiles_n;
+    const int x = bid % 8, i = bid / 8;
     if (xcd_m > 0) {
       const int sub_m = tiles_m / xcd_m, sub_n = tiles_n / (8 / xcd_m);
       const int xm = x / (8 / xcd_m), xn = x % (8 / xcd_m);
@@ -139,14 +132,12 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
       tile_n = xn * sub_n + i % sub_n;
     } else {
       const int q = ntiles / 8, r = ntiles % 8;
-      const int bb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-      tile_m = bb / tiles_n;
-      tile_n = bb % tiles_n;
+      bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+      tile_m = bid / tiles_n;
+      tile_n = bid % tiles_n;
     }
-    m0 = tile_m * BM; n0 = tile_n * BN;
-  };
-  int vb = blockIdx.x;
-  decode_tile(vb);
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -189,8 +180,8 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
   // depends on the tile row through (row >> 1) & 7 = 4 (i & 1) + (r_in >> 1)): two running states, advanced by 64 k per stage
   unsigned koff[2] = {0u, 0u};                      // byte offset of the chunk inside the patch: ((kh W + kw) ld + ch) * 2
   int kch[2] = {0, 0}, kkw[2] = {0, 0}, kkk[2] = {0, 0};
-  auto conv_setup = [&]() __attribute__((always_inline)) {
-    if constexpr (CONV) {
+  if constexpr (CONV) {
+    if (!isB) {
       const long ld = s0.a_ld, plane = s0.a_plane;
       gbase = reinterpret_cast<const char*>(s0.a);
 #pragma unroll
@@ -211,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
         koff[par] = (unsigned)((((long)kh * cg.W + kw) * ld + ch) * 2);
       }
     }
-  };
+  }
   const unsigned piece0 = lds0 + (isB ? A_BYTES : 0) + (wave & 1) * npieces * 1024;
   // ---- fragment side
   const int l32 = lane & 31, h32 = lane >> 5;
@@ -273,24 +264,22 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
 
   const float* const ainv_l = s1.k ? s1.a_inv : s0.a_inv;       // (the epilogue undoes the scaling of the LAST segment)
   const float* const binv_l = s1.k ? s1.b_inv : s0.b_inv;
-  int epar = 0;                       // EPI buffer of the tile whose stages are in flight / being multiplied
-  auto epi_fetch = [&]() __attribute__((always_inline)) {
-    if constexpr (FMT == 1) {
-      const float* src = wave == 0 ? ainv_l : (wave == 1 ? binv_l : (wave == 2 ? bias : nullptr));
-      const int base = wave == 0 ? m0 : n0, lim = (wave == 0 ? M : N) - 1, cnt = (wave == 0 ? BM : BN) / 64;
-      const unsigned dst = lds0 + EPI_AT + epar * EPI + (wave == 0 ? 0 : (wave == 1 ? 4 * BM : 4 * (BM + BN)));
-      if (src) {
+  if constexpr (FMT == 1) {
+    const float* src = wave == 0 ? ainv_l : (wave == 1 ? binv_l : (wave == 2 ? bias : nullptr));
+    const int base = wave == 0 ? m0 : n0, lim = (wave == 0 ? M : N) - 1, cnt = (wave == 0 ? BM : BN) / 64;
+    const unsigned dst = lds0 + EPI_AT + (wave == 0 ? 0 : (wave == 1 ? 4 * BM : 4 * (BM + BN)));
+    if (src) {
 #pragma unroll
-        for (int j = 0; j < (BM > BN ? BM : BN) / 64; ++j)
-          if (j < cnt)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + min(base + 64 * j + lane, lim)),
-                                             (__attribute__((address_space(3))) void*)(uintptr_t)(dst + 256 * j), 4, 0, 0);
-      }
+      for (int j = 0; j < (BM > BN ? BM : BN) / 64; ++j)
+        if (j < cnt)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + min(base + 64 * j + lane, lim)),
+                                           (__attribute__((address_space(3))) void*)(uintptr_t)(dst + 256 * j), 4, 0, 0);
     }
-  };
+  }
   const int nk0 = s0.k / BK, nk = nk0 + s1.k / BK;
   static_assert(NPA == NPB, "square wave grids only (one DMA count per wave)");
   constexpr int NP = NPA;
+  if (!(CONV && !isB)) setup(s0);
   int seg_left = nk0, left = nk;      // stages of the current segment / of the product still to be issued
   // Every stage slot is issued unconditionally (one basic block per iteration, uniform vmcnt counts): once the
   // product's stages are used up the pointers stop advancing and the DMAs re-read the last stage into buffers that
@@ -343,32 +332,24 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
     }
     glds16(gbase + (size_t)voff[i], piece0 + buf * STAGE + i * 1024);
   };
-  // a tile's start: operand addresses, epilogue factors, then stages 0 .. NS-1 in flight
-  auto tile_start = [&]() __attribute__((always_inline)) {
-    if (CONV && !isB) conv_setup(); else setup(s0);
-    seg_left = nk0; left = nk; first = true;
-    epi_fetch();
+  // prologue: stages 0 .. NS-1 in flight; stage 0 -> fragment set 0
 #pragma unroll
-    for (int st = 0; st < NS; ++st) {
-      next_stage();
-      if (st) prefetch();
+  for (int st = 0; st < NS; ++st) {
+    next_stage();
+    if (st) prefetch();
 #pragma unroll
-      for (int i = 0; i < NP; ++i) issue_one(st, i);
-    }
-    next_stage();                        // books stage NS (issued by iteration 0)
-  };
-  tile_start();
+    for (int i = 0; i < NP; ++i) issue_one(st, i);
+  }
+  next_stage();                        // books stage NS (issued by iteration 0)
   wait_vm<(NS - 1) * (NP + NPF)>();
-  int it = 0;                          // stage whose MFMAs are issued next
-for (;;) {                             // ---- one tile per pass (PERSIST: several)
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int r = 0; r < NR; ++r) read_one(0, r, 0);
-  it = 0;
 
   // h2, two segments: the operands of segment 1 carry other row scales than those of segment 0 -- when the MFMA stream
   // crosses the boundary the accumulators are multiplied by (scale of segment 0) / (scale of segment 1), an exact power of
   // two per element, and the epilogue undoes the scaling of the last segment only
+  int it = 0;                          // stage whose MFMAs are issued next
   auto fold = [&]() __attribute__((always_inline)) {
     if constexpr (FMT == 1) {
 #pragma unroll
@@ -446,32 +427,23 @@ for (;;) {                             // ---- one tile per pass (PERSIST: sever
   };
   while (it + PERIOD <= nk) run(run, std::integral_constant<int, 0>{}, false);
   run(run, std::integral_constant<int, 0>{}, true);
-  wait_vm<0>();                       // no DMA may be in flight into this workgroup's LDS when it exits / refills the ring
-  // PERSIST: every useful fragment read of this tile completed before the last iteration's barrier and each wave refills only
-  // its own pieces, so the ring can take the next tile's first stages now; they land while this tile is being stored
-  const int em0 = m0, en0 = n0, epi_cur = epar;
-  bool has_next = false;
-  if constexpr (PERSIST) {
-    vb += gridDim.x;
-    has_next = vb < ntiles;
-    if (has_next) { decode_tile(vb); epar ^= 1; tile_start(); }
-  }
+  wait_vm<0>();                       // no DMA may be in flight into this workgroup's LDS when it exits
 
   // ---- epilogue: lane (l32, h32), register v of block (i, j) = C[m = l32][n = 8 (v/4) + 4 h32 + v%4]
   const float* ainv = ainv_l;
   const float* binv = binv_l;
   auto epi_f = [&](int idx) __attribute__((always_inline)) -> float {
-    return *reinterpret_cast<const __attribute__((address_space(3))) float*>((uintptr_t)(lds0 + EPI_AT + epi_cur * EPI + 4 * idx));
+    return *reinterpret_cast<const __attribute__((address_space(3))) float*>((uintptr_t)(lds0 + EPI_AT + 4 * idx));
   };
   auto epi_f4 = [&](int idx) __attribute__((always_inline)) -> float4 {
     typedef float f32x4_ __attribute__((ext_vector_type(4)));
-    const f32x4_ t = *reinterpret_cast<const __attribute__((address_space(3))) f32x4_*>((uintptr_t)(lds0 + EPI_AT + epi_cur * EPI + 4 * idx));
+    const f32x4_ t = *reinterpret_cast<const __attribute__((address_space(3))) f32x4_*>((uintptr_t)(lds0 + EPI_AT + 4 * idx));
     return make_float4(t[0], t[1], t[2], t[3]);
   };
   const bool vec_c = ((ldc & 3) == 0) && (((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int row = em0 + (wm * TM + i) * 32 + l32;
+    const int row = m0 + (wm * TM + i) * 32 + l32;
     if (row >= M) continue;
     const float ra = ainv ? (FMT == 1 ? epi_f((wm * TM + i) * 32 + l32) : ainv[row]) : 1.f;
     float lg[16];                         // (sampling epilogue: the lane's 16 logits of the row, TM == TN == 1)
@@ -479,7 +451,7 @@ for (;;) {                             // ---- one tile per pass (PERSIST: sever
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        const int col = en0 + (wn * TN + j) * 32 + 8 * gq + 4 * h32;
+        const int col = n0 + (wn * TN + j) * 32 + 8 * gq + 4 * h32;
         if (col >= N) continue;
         float o[4];
         float cbv[4] = {1.f, 1.f, 1.f, 1.f}, bsv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -530,7 +502,7 @@ for (;;) {                             // ---- one tile per pass (PERSIST: sever
       }
     if constexpr (TM * TN == 1 && FMT == 1) {
       if (smp.q) {          // (host side guarantees: N % 32 == 0, vector path, no accumulate surprises)
-        const int c0 = en0 + wn * 32;                       // first column of this block = of its class group
+        const int c0 = n0 + wn * 32;                       // first column of this block = of its class group
         float m = lg[0];
 #pragma unroll
         for (int v = 1; v < 16; ++v) m = fmaxf(m, lg[v]);
@@ -580,19 +552,6 @@ for (;;) {                             // ---- one tile per pass (PERSIST: sever
       }
     }
   }
-  if (!has_next) break;
-  // the next tile: fresh accumulators; its first stages (issued before the stores above, which share the vmcnt counter with
-  // them) and the stores have all been acknowledged at vmcnt(0)
-#pragma unroll
-  for (int c = 0; c < NACC; ++c)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.f;
-  wait_vm<0>();
-}                                      // ---- tile loop
 }
 
 // ---- fp32 -> x3 planes (three bf16 terms, exact) -------------------------------------------------------------------------------------------
@@ -818,14 +777,6 @@ static void log_launch(const char* tile, int M, int N, int K) {
   static FILE* f = getenv("GENRL_GEMM_LOG") ? fopen(getenv("GENRL_GEMM_LOG"), "w") : nullptr;
   if (f) { fprintf(f, "%s %d %d %d\n", tile, M, N, K); fflush(f); }
 }
-#ifdef PLANES_EXPERIMENTS
-// PERSIST launches (GENRL_PLANES_PERSIST=1): one workgroup per CU (the count is a multiple of 8 on every gfx950 part: 8 XCDs)
-static int num_cus() {
-  static const int n = [] { int dev = 0, v = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 && v % 8 == 0 ? v : 256; }();
-  return n;
-}
-static bool persist_on() { static const bool on = getenv("GENRL_PLANES_PERSIST") && getenv("GENRL_PLANES_PERSIST")[0] == '1'; return on; }
-#endif
 int g_planes_nosplit = 0;        // experiments: 1 = no row split against wave quantisation (GENRL_PLANES_NOSPLIT)
 int g_planes_variant = 0;        // experiments (scripts/cold_bench.py): ring depth / prefetch distance variants
 int g_planes_force_tile = 0;     // 0 auto, 1: 64x64, 2: 128x128 (experiments)
@@ -992,11 +943,6 @@ static int gemm_h2_impl(const uint16_t* a0, long a0_ld, long a0_plane, const flo
         gemm_planes_kernel<2, 2, 64, 2, 1, 2, false, false, 4><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
                                                                                            xcd_split(tm, tn), SampleEpi{}, ConvGather{});
 #endif
-#ifdef PLANES_EXPERIMENTS
-      else if (persist_on() && tm * tn > num_cus())
-        gemm_planes_kernel<2, 2, 64, 2, 1, 2, false, false, 0, true><<<num_cus(), 256, 0, (hipStream_t)stream>>>(
-            sg, none, C, ldc, bs, M, N, acc, tm, tn, xcd_split(tm, tn), SampleEpi{}, ConvGather{});
-#endif
       else
         gemm_planes_kernel<2, 2, 64, 2, 1, 2, false><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
                                                                                            xcd_split(tm, tn), SampleEpi{}, ConvGather{});
@@ -1045,15 +991,9 @@ int genrl_gemm_h2_conv(const uint16_t* img, long ld_img, long plane_img, const f
   const PlaneSeg none{nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, nullptr};
   const int tm = cdiv(M, 128), tn = cdiv(N, 128);
   log_launch("h2/conv128", M, N, (int)b_ld);
-#ifdef PLANES_EXPERIMENTS
-  if (persist_on() && tm * tn > num_cus())
-    gemm_planes_kernel<2, 2, 64, 2, 1, 2, false, true, 0, true><<<num_cus(), 256, 0, (hipStream_t)stream>>>(
-        s0, none, C, ldc, bias, M, N, accumulate, tm, tn, xcd_split(tm, tn), SampleEpi{}, ConvGather{H, W, Cc, k, Ho, Wo, K});
-  else
-#endif
-    gemm_planes_kernel<2, 2, 64, 2, 1, 2, false, true><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, none, C, ldc, bias, M, N, accumulate, tm, tn,
-                                                                                             xcd_split(tm, tn), SampleEpi{},
-                                                                                             ConvGather{H, W, Cc, k, Ho, Wo, K});
+  gemm_planes_kernel<2, 2, 64, 2, 1, 2, false, true><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, none, C, ldc, bias, M, N, accumulate, tm, tn,
+                                                                                           xcd_split(tm, tn), SampleEpi{},
+                                                                                           ConvGather{H, W, Cc, k, Ho, Wo, K});
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }

@@ -20,6 +20,8 @@ echo "GENRL_PLANES_CONV=0:              $(GENRL_PLANES_CONV=0 $B --steps 20 --wa
 echo "GENRL_PLANES_WGRAD=0:             $(GENRL_PLANES_WGRAD=0 $B --steps 20 --warmup 5 2>/dev/null | ms)"
 echo "both off (round 2's products):    $(GENRL_PLANES_CONV=0 GENRL_PLANES_WGRAD=0 $B --steps 20 --warmup 5 2>/dev/null | ms)"
 echo "GENRL_PLANES_LINEAR=0:            $(GENRL_PLANES_LINEAR=0 $B --steps 20 --warmup 5 2>/dev/null | ms)"
+echo "GENRL_DEFER_REDUCTIONS=0:         $(GENRL_DEFER_REDUCTIONS=0 $B --steps 20 --warmup 5 2>/dev/null | ms)"
+echo "GENRL_PLANES_NOSPLIT=1:           $(GENRL_PLANES_NOSPLIT=1 $B --steps 20 --warmup 5 2>/dev/null | ms)"
 echo "default again:                    $($B --steps 20 --warmup 5 2>/dev/null | ms)"
 } > $O/feature_ab.txt 2>&1
 # (4) per-rank batch table, connector side stream ON and OFF
@@ -32,3 +34,7 @@ timeout 300 bash scripts/phase_prof.sh 4 14 > $O/phase_b4.txt 2>&1
 # (6) micro-benchmarks
 timeout 200 python scripts/tn_bench.py > $O/tn_bench.txt 2>&1
 timeout 200 python scripts/planes_bench.py > $O/planes_bench.txt 2>&1
+# (7) in-step time of the plane GEMM per shape; PMC passes; the full default bench line
+timeout 300 bash scripts/inshape.sh > $O/inshape.txt 2>&1
+timeout 600 bash scripts/pmc.sh > $O/pmc.txt 2>&1; cp gpurun_out/pmc/pmc_summary.json $O/pmc.json 2>/dev/null
+timeout 900 python bench.py > $O/bench_full.json 2> $O/bench_full.err
