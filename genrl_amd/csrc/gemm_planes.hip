@@ -33,8 +33,9 @@
 // * up to two (A, B) operand segments per launch (K = K0 + K1): y = [x1, x2] W^T without a concatenation and
 //   without a second read-modify-write pass over C.
 // Tiles: 64x64 (BK 64; wave tile 32x32) for the M ~ 1024 products of the imagination rollout -- 256 tiles, one per CU;
-// 128x128 (wave tile 64x64) from 2048 64-tiles up.  h2: three 32 KiB stages (64x64), two 64 KiB stages of BK 64 (128x128);
-// x3: three 48 KiB stages.
+// 128x128 (wave tile 64x64) from 2048 64-tiles up.  h2: three 32 KiB stages (64x64); 128x128: gemm_planes_hl_kernel below (four
+// 32 KiB HALF stages, the h planes and the l planes of a 64-k block alternating; the two-whole-stages instantiation of this kernel
+// stays behind GENRL_PLANES_HL=0); x3: three 48 KiB stages.
 #include "common.h"
 #include "genrl_hip.h"
 #include <type_traits>
@@ -83,9 +84,12 @@ __device__ __forceinline__ float pow2_ratio(float a, float b) {
   return __builtin_bit_cast(float, (unsigned)e << 23);
 }
 
+#ifndef PLANES_DMA_AUX
+#define PLANES_DMA_AUX 0      /* cache policy bits of the operand DMAs (experiments: 2 = nt) */
+#endif
 __device__ __forceinline__ void glds16(const void* g, unsigned lds_byte_addr) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)(uintptr_t)lds_byte_addr, 16, 0, 0);
+                                   (__attribute__((address_space(3))) void*)(uintptr_t)lds_byte_addr, 16, 0, PLANES_DMA_AUX);
 }
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
@@ -554,6 +558,283 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
   }
 }
 
+// ---- 128x128 tile, h2 operands, PLANE-ALTERNATING half stages -------------------------------------------------------------------------
+// gemm_planes_kernel<2,2,64,2,1,2> keeps two 64 KiB stages (both planes of a 64-k block of A and B) in LDS: the DMA of stage t + 2 can
+// only be issued once stage t's buffer is retired and has ONE stage time (~1.45 us of MFMAs) to land -- less than its latency + transfer
+// (~1.7 us): ablations on 16384 x 1024 x 1024 give 93 us for the MFMA stream alone, 114 with the DMAs, 122 with everything.  Here the
+// ring holds FOUR half stages of 32 KiB -- the h planes of a 64-k block, then its l planes: 128-byte row segments as before -- so a DMA
+// has three half-iterations (~2.2 us) to land, in the same 128 KiB.  Half-iteration u = 2b (h planes of block b landed): the 16 h*h
+// MFMAs; u = 2b + 1 (l planes): the 32 h*l and l*h MFMAs.  Fragments: two h sets (alternating per block) and one l set, 64 registers
+// each (the kernel above holds two whole stages = 256); the reads of half stage u + 1 and the DMAs of half stage u + 4 go out
+// between the MFMAs of half-iteration u, one barrier per half-iteration.  One segment, FOLD-free, epilogue as above.
+#ifndef HL_KBH
+#define HL_KBH 2
+#endif
+#ifndef HL_KBL
+#define HL_KBL 2
+#endif
+template <bool CONV>
+__global__ __launch_bounds__(256, 1) void gemm_planes_hl_kernel(PlaneSeg s0, float* __restrict__ C, long ldc, const float* __restrict__ bias,
+                                                                int M, int N, int accumulate, int tiles_m, int tiles_n, int xcd_m,
+                                                                ConvGather cg) {
+  constexpr int BM = 128, BN = 128, ROWB = 128, HALF = (BM + BN) * ROWB, NS = 4, NP = 8, KS = 4;
+  constexpr int EPI = 4 * (BM + 2 * BN), EPI_AT = NS * HALF;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[EPI_AT + EPI];
+  int tile_m, tile_n;
+  {
+    int bid = blockIdx.x;
+    const int ntiles = tiles_m * tiles_n;
+    const int x = bid % 8, i = bid / 8;
+    if (xcd_m > 0) {
+      const int sub_m = tiles_m / xcd_m, sub_n = tiles_n / (8 / xcd_m);
+      const int xm = x / (8 / xcd_m), xn = x % (8 / xcd_m);
+      tile_m = xm * sub_m + i / sub_n;
+      tile_n = xn * sub_n + i % sub_n;
+    } else {
+      const int q = ntiles / 8, r = ntiles % 8;
+      bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+      tile_m = bid / tiles_n;
+      tile_n = bid % tiles_n;
+    }
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned lds0 = (unsigned)(uintptr_t)lds;
+  // ---- DMA side: waves 0, 1 bring A's 16 pieces (8 rows x 128 bytes each) of a half stage, waves 2, 3 B's
+  const bool isB = wave >= 2;
+  const int r_in = lane >> 3, slot = lane & 7;
+  const char* gbase = reinterpret_cast<const char*>(isB ? s0.b : s0.a);     // (advances: + plane for the l half, + 128 - plane for the next block)
+  const long plane_bytes = (isB ? s0.b_plane : s0.a_plane) * 2;
+  unsigned voff[NP];
+  unsigned koff[2] = {0u, 0u};
+  int kch[2] = {0, 0}, kkw[2] = {0, 0}, kkk[2] = {0, 0};
+  if (CONV && !isB) {
+    const long ld = s0.a_ld;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int row = ((wave & 1) * NP + i) * 8 + r_in;
+      const int m = min(m0 + row, M - 1);
+      const int n_img = m / (cg.Ho * cg.Wo), rem = m - n_img * (cg.Ho * cg.Wo);
+      const int oy = rem / cg.Wo, ox = rem - oy * cg.Wo;
+      voff[i] = (unsigned)((((long)(n_img * cg.H + 2 * oy) * cg.W + 2 * ox) * ld) * 2);
+    }
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int f = (4 * par + (r_in >> 1)) & 7;
+      const int kk = 8 * (slot ^ f);
+      const int tap = kk / cg.C, ch = kk - tap * cg.C, kh = tap / cg.k, kw = tap - kh * cg.k;
+      kkk[par] = kk; kch[par] = ch; kkw[par] = kw;
+      koff[par] = (unsigned)((((long)kh * cg.W + kw) * ld + ch) * 2);
+    }
+  } else {
+    const long ld = isB ? s0.b_ld : s0.a_ld;
+    const int rows_total = isB ? N : M, r0 = isB ? n0 : m0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int row = ((wave & 1) * NP + i) * 8 + r_in;
+      const int f = (row >> 1) & 7;
+      voff[i] = (unsigned)(((long)min(r0 + row, rows_total - 1) * ld) * 2 + ((slot ^ f) << 4));
+    }
+  }
+  const unsigned piece0 = lds0 + (isB ? BM * ROWB : 0) + (wave & 1) * NP * 1024;
+  // ---- fragment side (as above: 32x32 blocks, lane (l32, h32), swizzled 16-byte chunks)
+  const int l32 = lane & 31, h32 = lane >> 5;
+  const int f_rd = (l32 >> 1) & 7;
+  unsigned a_s[KS], b_s[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const unsigned xo = (unsigned)(((2 * s + h32) ^ f_rd) << 4);
+    a_s[s] = lds0 + (wm * 64 + l32) * ROWB + xo;
+    b_s[s] = lds0 + BM * ROWB + (wn * 64 + l32) * ROWB + xo;
+  }
+  f32x16 acc[2][2][2];                 // [0: low class (h*l + l*h, x 2^11) | 1: h*h][i][j]
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.f;
+  u32x4 Hf[2][KS][4], Lf[KS][4];       // [k-step][block: 0, 1 = A rows, 2, 3 = B rows]
+  auto ldfrag = [&](unsigned addr) __attribute__((always_inline)) -> u32x4 {
+    return *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((uintptr_t)addr);
+  };
+  // r-th fragment read (of 16) of the half stage in buffer `buf`
+  auto read_one = [&](u32x4 (&dst)[KS][4], int r, int buf) __attribute__((always_inline)) {
+    const int s = r >> 2, blk = r & 3;
+    dst[s][blk] = blk < 2 ? ldfrag(a_s[s] + blk * 32 * ROWB + buf * HALF) : ldfrag(b_s[s] + (blk - 2) * 32 * ROWB + buf * HALF);
+  };
+  auto mma = [&](f32x16& c, const u32x4& bfr, const u32x4& afr) __attribute__((always_inline)) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, bfr), __builtin_bit_cast(f16x8_t, afr), c, 0, 0, 0);
+  };
+  // epilogue factors ahead of everything else (see the kernel above)
+  {
+    const float* src = wave == 0 ? s0.a_inv : (wave == 1 ? s0.b_inv : (wave == 2 ? bias : nullptr));
+    const int base = wave == 0 ? m0 : n0, lim = (wave == 0 ? M : N) - 1;
+    const unsigned dst = lds0 + EPI_AT + (wave == 0 ? 0 : (wave == 1 ? 4 * BM : 4 * (BM + BN)));
+    if (src) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + min(base + 64 * j + lane, lim)),
+                                         (__attribute__((address_space(3))) void*)(uintptr_t)(dst + 256 * j), 4, 0, 0);
+    }
+  }
+  const int nu = 2 * (s0.k / 64);      // half stages of the product
+  int issued = 0;                      // half stages booked so far (the pointer stops once all are: later slots re-read the last one)
+  auto next_half = [&]() __attribute__((always_inline)) {      // called before a half stage's DMAs are issued
+    if (issued > 0 && issued < nu) {
+      if (issued & 1) gbase += plane_bytes;                    // -> the l planes of the same block
+      else {
+        gbase += 128 - plane_bytes;                            // -> the h planes of the next block
+        if constexpr (CONV) {
+          if (!isB) {
+            gbase -= 128;                                      // (the gather moves by its own chunk states)
+            const unsigned ld2 = (unsigned)(s0.a_ld * 2);
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+              if (kkk[par] + 64 + 8 <= cg.K) {
+                kkk[par] += 64;
+                int ch = kch[par] + 64, kw = kkw[par];
+                unsigned off = koff[par] + 128u;
+#pragma unroll
+                for (int rep = 0; rep < 2; ++rep)
+                  if (ch >= cg.C) {
+                    ch -= cg.C; off -= (unsigned)(cg.C * 2);
+                    ++kw; off += ld2;
+                    if (kw == cg.k) { kw = 0; off += (unsigned)(cg.W - cg.k) * ld2; }
+                  }
+                kch[par] = ch; kkw[par] = kw; koff[par] = off;
+              }
+            }
+          }
+        }
+      }
+    }
+    ++issued;
+  };
+  auto issue_one = [&](int buf, int i) __attribute__((always_inline)) {
+    if constexpr (CONV) {
+      if (!isB) { glds16(gbase + (size_t)(voff[i] + koff[i & 1]), piece0 + buf * HALF + i * 1024); return; }
+    }
+    glds16(gbase + (size_t)voff[i], piece0 + buf * HALF + i * 1024);
+  };
+#pragma unroll
+  for (int st = 0; st < NS; ++st) {
+    next_half();
+#pragma unroll
+    for (int i = 0; i < NP; ++i) issue_one(st, i);
+  }
+  next_half();                         // books half stage NS (issued by half-iteration 0)
+  wait_vm<(NS - 1) * NP>();
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) read_one(Hf[0], r, 0);
+
+  int u = 0;
+  // half-iteration with u % 4 == U: MFMAs of half stage u from registers; behind the barrier the reads of half stage u + 1 (buffer
+  // (U + 1) % 4) and the DMAs of half stage u + 4 (buffer U, just retired), two or one per MFMA
+  auto half_iter = [&](auto UC) __attribute__((always_inline)) {
+    constexpr int U = decltype(UC)::value;
+    constexpr bool LPH = (U & 1) != 0;              // l planes have landed: h*l and l*h; else h*h
+    constexpr int HS = U >> 1;                      // h set of this block
+    constexpr int NM = LPH ? 32 : 16, KB = LPH ? HL_KBL : HL_KBH, NSIDE = 16 + NP;      // KB MFMAs are issued ahead of the barrier
+    constexpr int PER = (NSIDE + (NM - KB) - 1) / (NM - KB);
+    static_assert((NSIDE + PER - 1) / PER <= NM - KB, "not enough MFMAs to carry the side operations");
+    auto mfma_one = [&](int m) __attribute__((always_inline)) {
+      if constexpr (!LPH) {                         // m = s * 4 + i * 2 + j
+        const int s = m >> 2, i = (m >> 1) & 1, j = m & 1;
+        mma(acc[1][i][j], Hf[HS][s][2 + j], Hf[HS][s][i]);
+      } else {                                      // m = s * 8 + t * 4 + i * 2 + j; t 0: l(A) * h(B), 1: h(A) * l(B)
+        const int s = m >> 3, t = (m >> 2) & 1, i = (m >> 1) & 1, j = m & 1;
+        if (t == 0) mma(acc[0][i][j], Hf[HS][s][2 + j], Lf[s][i]);
+        else mma(acc[0][i][j], Lf[s][2 + j], Hf[HS][s][i]);
+      }
+    };
+#pragma unroll
+    for (int m = 0; m < KB; ++m) mfma_one(m);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_vm<(NS - 2) * NP>();                       // half stage u + 1 landed (own DMAs)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = KB; m < NM; ++m) {
+      mfma_one(m);
+#pragma unroll
+      for (int o = (m - KB) * PER; o < (m - KB + 1) * PER; ++o) {
+        if (o >= NSIDE) continue;
+        if (o % 3 == 2) {
+          issue_one(U, o / 3);
+        } else {
+          const int r = o - o / 3;
+          if constexpr (LPH) read_one(Hf[1 - HS], r, (U + 1) % NS);      // h planes of the next block
+          else read_one(Lf, r, (U + 1) % NS);                              // l planes of this block
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    next_half();
+    ++u;
+  };
+  while (u + 4 <= nu) {
+    half_iter(std::integral_constant<int, 0>{});
+    half_iter(std::integral_constant<int, 1>{});
+    half_iter(std::integral_constant<int, 2>{});
+    half_iter(std::integral_constant<int, 3>{});
+  }
+  if (u < nu) {                        // (nu is even: one more block)
+    half_iter(std::integral_constant<int, 0>{});
+    half_iter(std::integral_constant<int, 1>{});
+  }
+  wait_vm<0>();
+
+  // ---- epilogue (as above, TM = TN = 2, NACC = 2)
+  auto epi_f = [&](int idx) __attribute__((always_inline)) -> float {
+    return *reinterpret_cast<const __attribute__((address_space(3))) float*>((uintptr_t)(lds0 + EPI_AT + 4 * idx));
+  };
+  auto epi_f4 = [&](int idx) __attribute__((always_inline)) -> float4 {
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    const f32x4_ t = *reinterpret_cast<const __attribute__((address_space(3))) f32x4_*>((uintptr_t)(lds0 + EPI_AT + 4 * idx));
+    return make_float4(t[0], t[1], t[2], t[3]);
+  };
+  const bool vec_c = ((ldc & 3) == 0) && (((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = m0 + (wm * 2 + i) * 32 + l32;
+    if (row >= M) continue;
+    const float ra = s0.a_inv ? epi_f((wm * 2 + i) * 32 + l32) : 1.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int ci = (wn * 2 + j) * 32 + 8 * gq + 4 * h32, col = n0 + ci;
+        if (col >= N) continue;
+        float cbv[4] = {1.f, 1.f, 1.f, 1.f}, bsv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (s0.b_inv) { const float4 t = epi_f4(BM + ci); cbv[0] = t.x; cbv[1] = t.y; cbv[2] = t.z; cbv[3] = t.w; }
+        if (bias) { const float4 t = epi_f4(BM + BN + ci); bsv[0] = t.x; bsv[1] = t.y; bsv[2] = t.z; bsv[3] = t.w; }
+        float o[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          o[v] = (acc[0][i][j][4 * gq + v] * (1.f / 2048.f) + acc[1][i][j][4 * gq + v]) * ra * cbv[v] + bsv[v];
+        float* c = C + (long)row * ldc + col;
+        if (vec_c && col + 3 < N) {
+          if (accumulate) {
+            const float4 cv = *reinterpret_cast<const float4*>(c);
+            o[0] += cv.x; o[1] += cv.y; o[2] += cv.z; o[3] += cv.w;
+          }
+          *reinterpret_cast<float4*>(c) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            if (col + v < N) c[v] = accumulate ? c[v] + o[v] : o[v];
+        }
+      }
+  }
+}
+
 // ---- fp32 -> x3 planes (three bf16 terms, exact) -------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned bf16_rne(float x) {      // bits of the nearest-even bf16 (finite inputs)
   const unsigned u = __builtin_bit_cast(unsigned, x);
@@ -777,6 +1058,8 @@ static void log_launch(const char* tile, int M, int N, int K) {
   static FILE* f = getenv("GENRL_GEMM_LOG") ? fopen(getenv("GENRL_GEMM_LOG"), "w") : nullptr;
   if (f) { fprintf(f, "%s %d %d %d\n", tile, M, N, K); fflush(f); }
 }
+// the 128x128 products on the plane-alternating kernel (gemm_planes_hl_kernel); GENRL_PLANES_HL=0: the two-whole-stages kernel
+static bool hl_on() { static const bool on = !getenv("GENRL_PLANES_HL") || getenv("GENRL_PLANES_HL")[0] != '0'; return on; }
 int g_planes_nosplit = 0;        // experiments: 1 = no row split against wave quantisation (GENRL_PLANES_NOSPLIT)
 int g_planes_variant = 0;        // experiments (scripts/cold_bench.py): ring depth / prefetch distance variants
 int g_planes_force_tile = 0;     // 0 auto, 1: 64x64, 2: 128x128 (experiments)
@@ -943,6 +1226,8 @@ static int gemm_h2_impl(const uint16_t* a0, long a0_ld, long a0_plane, const flo
         gemm_planes_kernel<2, 2, 64, 2, 1, 2, false, false, 4><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
                                                                                            xcd_split(tm, tn), SampleEpi{}, ConvGather{});
 #endif
+      else if (hl_on())
+        gemm_planes_hl_kernel<false><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, C, ldc, bs, M, N, acc, tm, tn, xcd_split(tm, tn), ConvGather{});
       else
         gemm_planes_kernel<2, 2, 64, 2, 1, 2, false><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
                                                                                            xcd_split(tm, tn), SampleEpi{}, ConvGather{});
@@ -991,9 +1276,13 @@ int genrl_gemm_h2_conv(const uint16_t* img, long ld_img, long plane_img, const f
   const PlaneSeg none{nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, nullptr};
   const int tm = cdiv(M, 128), tn = cdiv(N, 128);
   log_launch("h2/conv128", M, N, (int)b_ld);
-  gemm_planes_kernel<2, 2, 64, 2, 1, 2, false, true><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, none, C, ldc, bias, M, N, accumulate, tm, tn,
-                                                                                           xcd_split(tm, tn), SampleEpi{},
-                                                                                           ConvGather{H, W, Cc, k, Ho, Wo, K});
+  if (hl_on())
+    gemm_planes_hl_kernel<true><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, C, ldc, bias, M, N, accumulate, tm, tn, xcd_split(tm, tn),
+                                                                          ConvGather{H, W, Cc, k, Ho, Wo, K});
+  else
+    gemm_planes_kernel<2, 2, 64, 2, 1, 2, false, true><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, none, C, ldc, bias, M, N, accumulate, tm, tn,
+                                                                                             xcd_split(tm, tn), SampleEpi{},
+                                                                                             ConvGather{H, W, Cc, k, Ho, Wo, K});
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }
