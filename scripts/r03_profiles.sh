@@ -21,6 +21,7 @@ echo "GENRL_PLANES_WGRAD=0:             $(GENRL_PLANES_WGRAD=0 $B --steps 20 --w
 echo "both off (round 2's products):    $(GENRL_PLANES_CONV=0 GENRL_PLANES_WGRAD=0 $B --steps 20 --warmup 5 2>/dev/null | ms)"
 echo "GENRL_PLANES_LINEAR=0:            $(GENRL_PLANES_LINEAR=0 $B --steps 20 --warmup 5 2>/dev/null | ms)"
 echo "GENRL_DEFER_REDUCTIONS=0:         $(GENRL_DEFER_REDUCTIONS=0 $B --steps 20 --warmup 5 2>/dev/null | ms)"
+echo "GENRL_PLANES_HL=0:                $(GENRL_PLANES_HL=0 $B --steps 20 --warmup 5 2>/dev/null | ms)"
 echo "GENRL_PLANES_NOSPLIT=1:           $(GENRL_PLANES_NOSPLIT=1 $B --steps 20 --warmup 5 2>/dev/null | ms)"
 echo "default again:                    $($B --steps 20 --warmup 5 2>/dev/null | ms)"
 } > $O/feature_ab.txt 2>&1
