@@ -430,12 +430,12 @@ def main():
                 d.update(achieved=3 * eq, peak=PEAK_BF16_MFMA_TFLOPS, unit='TFLOP/s (fp16 MFMA work executed = 3 x 2MNK)',
                          frac=3 * eq / PEAK_BF16_MFMA_TFLOPS, fp32_equivalent_achieved=eq,
                          fp32_equivalent_frac_of_fp32_peak=eq / PEAK_F32_MFMA_TFLOPS,
-                         kernel='gemm_planes_kernel<FMT=1> (gemm_planes.hip: operands pre-split into two fp16 planes of the row-scaled '
-                                'value, LDS-DMA; <CONV>: stride-2 patches gathered by the DMA) and gemm_planes_tn_kernel (gemm_planes_tn.hip: '
-                                'weight gradients on the same planes, transposing LDS reads): 3 x v_mfma_f32_32x32x16_f16 per product, '
-                                'fp32 accumulate',
-                         note='operand ingest (L2 -> LDS DMA, 4 bytes per element per tile pass) bounds these launches, not the '
-                              'matrix pipe (DESIGN 4a)')
+                         kernel='gemm_planes_kernel<FMT=1> (64x64 tiles) / gemm_planes_hl_kernel (128x128 tiles, plane-alternating half '
+                                'stages; <CONV>: stride-2 patches gathered by the DMA) (gemm_planes.hip: operands pre-split into two fp16 '
+                                'planes of the row-scaled value, LDS-DMA) and gemm_planes_tn_kernel (gemm_planes_tn.hip: weight gradients on '
+                                'the same planes, transposing LDS reads): 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate',
+                         note='64x64 tile: the LDS port (DMA writes + fragment reads) bounds the K loop; 128x128 tile: 113 us on '
+                              '16384x1024x1024 against 93 us for its MFMA stream alone at the clock the part sustains (DESIGN 4d)')
             else:
                 d.update(achieved=eq, peak=PEAK_BF16_MFMA_TFLOPS, unit='TFLOP/s', frac=eq / PEAK_BF16_MFMA_TFLOPS,
                          kernel='sgemm_rr_kernel<BF=1>: bf16-rounded operands (precision 16)')
