@@ -882,18 +882,37 @@ __global__ __launch_bounds__(256) void ln_act_bwd_wave_kernel(const float* dy, l
     ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     ax[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+  // a wave walks its rows with the NEXT row's loads already in flight (this kernel holds ~200 registers: two waves per SIMD, so the
+  // load latency of a row is not hidden by other waves -- 16 k-row calls ran at 2.8 TB/s before)
+  const long stride = (long)gridDim.x * 4;
+  float4 nx[NV], nd[NV];
+  float nmean = 0.f, nrstd = 0.f;
+  auto fetch = [&](long row) __attribute__((always_inline)) {
     const float4* xr = reinterpret_cast<const float4*>(x + row * ldx);
     const float4* dr = reinterpret_cast<const float4*>(dy + row * lddy);
-    const float mean = mean_in[row], rstd = rstd_in[row];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int j = lane + 64 * i;
+      if (j < nv) { nx[i] = xr[j]; nd[i] = dr[j]; }
+    }
+    nmean = mean_in[row]; nrstd = rstd_in[row];
+  };
+  const long row0 = (long)blockIdx.x * 4 + wave;
+  if (row0 < M) fetch(row0);
+  for (long row = row0; row < M; row += stride) {
+    float4 xc[NV], dc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { xc[i] = nx[i]; dc[i] = nd[i]; }
+    const float mean = nmean, rstd = nrstd;
+    if (row + stride < M) fetch(row + stride);
     float4 xh[NV], dz[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int j = lane + 64 * i;
       if (j < nv) {
-        const float4 xv = xr[j];
-        float4 d = dr[j];
+        const float4 xv = xc[i];
+        float4 d = dc[i];
         float4 h;
         h.x = (xv.x - mean) * rstd; h.y = (xv.y - mean) * rstd; h.z = (xv.z - mean) * rstd; h.w = (xv.w - mean) * rstd;
         if (act) {
