@@ -67,6 +67,8 @@ DEFER_REDUCTIONS = os.environ.get('GENRL_DEFER_REDUCTIONS', '1') != '0'
 
 def defer_begin():
     global _deferred
+    if _deferred:                  # (a pass that never reached its flush -- an exception on the way: its sums are completed now)
+        defer_flush()
     _deferred = [] if DEFER_REDUCTIONS else None
 
 
