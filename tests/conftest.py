@@ -22,3 +22,6 @@ os.environ.setdefault('GENRL_TN_MIN_ROWS', '64')
 # ... and the convolution products on plane operands (genrl_amd/ops_conv_planes.py, from 4096 pixel rows up by default)
 os.environ.setdefault('GENRL_PLANES_CONV_MIN_ROWS', '0')
 os.environ.setdefault('GENRL_PLANES_KR_MIN_K', '0')
+
+# scripts/ holds measurement one-offs that run GPU work at import: never collect them
+collect_ignore_glob = ['../scripts/*']
