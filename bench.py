@@ -53,7 +53,89 @@ def one_step(ag, batch):
     return mets
 
 
-def measure_traffic(timeout=300):
+def dreamer_step(ag, batch):
+    """configs[2]: DreamerAgent (dreamer_v3.yaml) -- train.py's update_wm + update_acting_behavior"""
+    state, outputs, mets = ag.update_wm(batch, 0)
+    _, mets = ag.update_acting_behavior(state, outputs, mets, batch)
+    return mets
+
+
+def datafree_step(ag, batch):
+    """configs[4]: one iteration of train.py with train_from_data=False (train.py:283-340; start_from_video=mix,
+    mix_random_actions=True, imag_warmup_steps=5): latent starts from the uniform prior mixed with connector rollouts of random
+    unit embeddings, a random-action and a policy warm-up rollout, then update_imag_behavior on the imagined starts.  No frames."""
+    cfg, wm = ag.cfg, ag.wm
+    BS, BL, W = cfg.batch_size, cfg.batch_length, 5
+    dev = ag.device
+    with torch.no_grad():
+        n_half = BS * (BL // 2)
+        init = wm.rssm.initial(n_half)
+        unif = wm.rssm.get_unif_dist(init)
+        init['logit'] = unif.mean
+        init['stoch'] = unif.sample()
+        T = wm.connector.n_frames * 2
+        B = n_half // T
+        video_embed = torch.nn.functional.normalize(torch.randn((B, T, wm.connector.viclip_emb_dim), device=dev), dim=-1)
+        vinit = wm.connector.video_imagine(video_embed, dreamer_init=None, sample=True, reset_every_n_frames=False, denoise=True)
+        vinit = {k: v.reshape(B * T, *v.shape[2:]) for k, v in vinit.items()}
+        probs = torch.rand((B * T, 1, 1), device=dev) > 0.5
+        init['stoch'] = (probs * init['stoch']) + ((~probs) * vinit['stoch'])
+        fake_action = torch.rand(n_half, W, ag.act_dim, device=dev) * 2 - 1
+        post1 = wm.rssm.imagine(fake_action, init, sample=True)
+        post1 = {k: v[:, -1].reshape([BS, BL // 2] + list(v.shape[2:])) for k, v in post1.items()}
+        init2 = {k: v.reshape([BS, BL // 2] + list(v.shape[1:])) for k, v in init.items()}
+        post2 = wm.imagine(ag._imag_behavior.actor, init2, None, W)
+        post2 = {k: v[-1, :].reshape([BS, BL // 2] + list(v.shape[2:])) for k, v in post2.items() if k in post1}
+        post = {k: torch.cat([post1[k], post2[k]], dim=1) for k in post1}
+    outputs = dict(post=post, is_terminal=torch.zeros(BS, BL, device=dev))
+    _, mets = ag.update_imag_behavior(state=None, outputs=outputs, metrics={}, seq_data=None)
+    return mets
+
+
+def dreamer_gflop(N, H=15, A=6):
+    """Dreamer-v3 widths (D = Hd = U = 512, F = 1536), posterior from [deter, embed], decoder on feat,
+    reward head trained with the world model, entropy re-evaluation executed (actor_ent = 3e-4); 2 x MAC."""
+    from genrl_amd import flops_model
+    m = flops_model.per_unit_macs(A=A, D=512, Hd=512, U=512)
+    S, D, U, E = 1024, 512, 512, 1536
+    F = S + D
+    post = (D + E) * 512 + 512 * S
+    dec = m['dec'] + D * 32 * 48                      # decoder input is feat, not stoch
+    head = F * U + 3 * U * U + U * 255                # reward head / critic
+    actor = F * U + 3 * U * U + 2 * A * U
+    d0 = F * U
+    wm_fwd = m['enc'] + post + m['img_step'] + dec + head
+    wm_bwd = 2 * wm_fwd - m['conv1']
+    imag_fwd = (H + 1) * actor + H * m['img_step'] + 2 * (H + 1) * head + (H - 1) * actor + H * head
+    imag_bwd = H * m['img_step'] + H * (2 * actor - d0) + 2 * (H + 1) * head + (H - 1) * (2 * actor - d0) + H * (2 * head - d0)
+    g = lambda macs: 2.0 * macs * N / 1e9
+    tot = g(wm_fwd + wm_bwd) + g(imag_fwd + imag_bwd)
+    return dict(wm=g(wm_fwd + wm_bwd), imag=g(imag_fwd + imag_bwd), total=tot, executed=tot)
+
+
+def datafree_gflop(N, H=15, A=10, W=5):
+    """the imagination / actor-critic update on N start rows + the forward-only warm-up block"""
+    from genrl_amd import flops_model
+    fl = flops_model.iteration_gflop(N, H=H, A=A)
+    m = flops_model.per_unit_macs(A=A)
+    warm = 2.0 * (N // 2 * W * m['img_step'] + N // 2 * ((W + 1) * m['actor'] + W * m['img_step']) + N * m['conn_step']) / 1e9
+    return dict(imag=fl['imag'], warmup=warm, total=fl['imag'] + warm, executed=fl['imag'] + warm - fl['entropy_reevaluation'])
+
+
+WORKLOADS = {
+    # name: (default batch, default length, action dim, image size, what BASELINE.json calls it)
+    'c2': (32, 32, 10, 64, 'configs[1]: full WM + 2x connector + imag-behaviour update, video_text_reward'),
+    'c3': (64, 50, 6, 64, 'configs[2]: walker, DreamerAgent (dreamer_v3.yaml: 512-wide RSSM / heads, posterior from [deter, embed], '
+                          'decoder on feat, trained reward head, env_reward, horizon 15): update_wm + update_acting_behavior'),
+    'c4': (32, 32, 9, 128, 'configs[3]: kitchen 128x128 RGB, five-layer conv encoder / decoder (the conv-bound roofline point), full WM + '
+                           '2x connector + imag-behaviour update'),
+    'c5': (16, 16, 10, 64, 'configs[4]: data-free RL (train_from_data=False, train.py:283-340): uniform / connector latent starts, '
+                           'random-action + policy warm-up rollouts (5 steps), imagination update with horizon 15 on batch_size x '
+                           'batch_length = 256 start rows per GPU; no frames'),
+}
+
+
+def measure_traffic(timeout=300, extra=()):
     """HBM bytes per launch of the MFMA GEMM kernels, measured NOW on this box: two separate rocprofv3 --pmc passes
     (FETCH_SIZE, then WRITE_SIZE; --kernel-trace only) over a short eager single-stream run of this script, as
     MI355X_MICROARCH.md's HBM section prescribes (FETCH_SIZE is in KiB and counts 64 B per 128-B request on gfx950: x2).
@@ -62,7 +144,7 @@ def measure_traffic(timeout=300):
     if shutil.which('rocprofv3') is None:
         return None, 'rocprofv3 not on PATH'
     child = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '1', '--graph', 'off', '--no-overlap',
-             '--no-cpu-baseline', '--no-kernel-profile', '--no-fp32-mode', '--no-traffic', '--input', 'fixed']
+             '--no-cpu-baseline', '--no-kernel-profile', '--no-fp32-mode', '--no-traffic', '--no-eager-leg', '--input', 'fixed'] + list(extra)
     env = dict(os.environ, TMPDIR='/tmp')
     tot = {}
     for counter, mult in (('FETCH_SIZE', 2.0 * 1024.0), ('WRITE_SIZE', 1024.0)):
@@ -154,8 +236,12 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=32)
-    ap.add_argument('--length', type=int, default=32)
+    ap.add_argument('--config', default='c2', choices=sorted(WORKLOADS),
+                    help="BASELINE.json workload: c2 = configs[1] (the metric's own; default), c3 = configs[2] (DreamerAgent, B64xT50), "
+                         "c4 = configs[3] (128x128 frames, five-layer convs), c5 = configs[4] (data-free imagination update, 256 rows)")
+    ap.add_argument('--batch', type=int, default=0, help='global batch (sequences); default: the config\'s own')
+    ap.add_argument('--length', type=int, default=0, help='sequence length; default: the config\'s own')
+    ap.add_argument('--no-eager-leg', action='store_true', help='skip the short eager (no hipGraph) timing beside the replayed one')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--no-fp32-mode', action='store_true', help='skip the comparison run with fp32 MFMAs throughout')
@@ -182,7 +268,7 @@ def main():
     build.build(verbose=False)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (the hot path has no CPU fallback)')
-    rank, world, local = dp.init()
+    rank, world, local = dp.init(ingraph=(args.graph != 'off' and args.dp_graph != 'cut'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     ndev = torch.cuda.device_count()
     local = local % ndev                          # (test rigs may oversubscribe one GPU with gloo)
@@ -191,17 +277,42 @@ def main():
     from genrl_amd.agent import dreamer_utils as common
     dp.install(common.Optimizer, common.RewardEMA)
 
-    B, T = args.batch, args.length
+    wl = args.config
+    dB, dT, A, img, wl_text = WORKLOADS[wl]
+    B, T = args.batch or dB, args.length or dT
     torch.manual_seed(0)                         # identical random-init weights on every rank
     # (the connector's side stream: always on one GPU; under data parallelism only with RCCL's stream-ordered collectives --
     # WorldModel.update_additional_detached_modules checks Optimizer.overlap_under_dp, set by dp.install)
-    cfg = config.default_cfg(B // world, T, device=dev, overlap_detached=not args.no_overlap, precision=args.precision)
     import contextlib
+    common_kw = dict(device=dev, overlap_detached=not args.no_overlap, precision=args.precision)
     with contextlib.redirect_stdout(sys.stderr):   # (the agent announces its parameter counts like the reference does;
-        ag = config.make_agent(cfg)                #  stdout carries the ONE JSON line only)
-    ag.wm.viclip_model = TextStub()
-    full = synth_batch(B, T)
-    batch = {k: v.to(dev) for k, v in dp.shard_batch({k: torch.from_numpy(v) for k, v in full.items()}, rank, world).items()}
+        if wl == 'c3':                             #  stdout carries the ONE JSON line only)
+            cfg = config.dreamer_cfg(B // world, T, **common_kw)
+            ag = config.make_dreamer_agent(cfg, act_dim=A)
+            step_fn, fl = dreamer_step, dreamer_gflop(B * T, A=A)
+        elif wl == 'c4':
+            ek, dk = [4, 4, 4, 4, 4], [5, 5, 5, 6, 6]
+            cfg = config.default_cfg(B // world, T, task='kitchen_microwave', encoder=dict(cnn_kernels=ek), decoder=dict(cnn_kernels=dk), **common_kw)
+            ag = config.make_agent(cfg, act_dim=A, img=img)
+            step_fn, fl = one_step, flops_model.iteration_gflop(B * T, A=A, img=img, enc_k=tuple(ek), dec_k=tuple(dk))
+        elif wl == 'c5':
+            cfg = config.default_cfg(B // world, T, imag_horizon=15, **common_kw)
+            ag = config.make_agent(cfg, act_dim=A)
+            step_fn, fl = datafree_step, datafree_gflop(B * T, A=A)
+        else:
+            cfg = config.default_cfg(B // world, T, **common_kw)
+            ag = config.make_agent(cfg)
+            step_fn, fl = one_step, flops_model.iteration_gflop(B * T)
+    if wl != 'c3':
+        ag.wm.viclip_model = TextStub()
+    if wl == 'c5':
+        full, batch = {}, {}
+        args.input = 'fixed'                     # (no replay batch on this path)
+    else:
+        full = synth_batch(B, T, A=A, img=img)
+        if wl == 'c3':
+            full.pop('clip_video')
+        batch = {k: v.to(dev) for k, v in dp.shard_batch({k: torch.from_numpy(v) for k, v in full.items()}, rank, world).items()}
     torch.manual_seed(1234 + rank)               # per-rank sampling noise
     replay = None
     if args.input == 'replay':
@@ -210,8 +321,8 @@ def main():
         specs = {k: (v.shape[2:], v.dtype) for k, v in full.items()}
         replay = DeviceReplay(specs, T, 16 * 8 * T, device=dev, batch_size=B // world)
         for i in range(16):
-            ep = synth_batch(1, 8 * T, seed=100 + i)
-            replay.store_episode({k: v[0] for k, v in ep.items()})
+            ep = synth_batch(1, 8 * T, A=A, img=img, seed=100 + i)
+            replay.store_episode({k: v[0] for k, v in ep.items() if k in full})
         np.random.seed(4321 + rank)
 
     # ---- hipGraph capture.  One GPU: the whole iteration is one graph.  Data parallel: the collectives are captured INSIDE the
@@ -248,7 +359,7 @@ def main():
         modes = ['cut'] if world == 1 else ((['ingraph'] if backend == 'nccl' and args.dp_graph != 'cut' else []) + ['cut'])
         for mode in modes:
             try:
-                g_try = GraphedStep(ag, batch, one_step, warmup=2, collectives=mode)
+                g_try = GraphedStep(ag, batch, step_fn, warmup=2, collectives=mode)
                 m_try = g_try()
                 torch.cuda.synchronize()
                 if not ranks_agree(m_try):
@@ -265,17 +376,17 @@ def main():
                 if world > 1:
                     resync_weights()
     if graphed is None and world > 1:
-        m_try = one_step(ag, batch); torch.cuda.synchronize()
+        m_try = step_fn(ag, batch); torch.cuda.synchronize()
         if not ranks_agree(m_try):
             print('[bench] WARNING: ranks disagree on reduced gradient norms in eager mode', file=sys.stderr)
     if replay is None:
-        run_step = (lambda: graphed()) if graphed is not None else (lambda: one_step(ag, batch))
+        run_step = (lambda: graphed()) if graphed is not None else (lambda: step_fn(ag, batch))
     elif graphed is not None:
         def run_step():
             replay.sample(out=graphed.static_batch)          # windows gathered straight into the graphs' inputs
             return graphed()
     else:
-        run_step = lambda: one_step(ag, replay.sample())
+        run_step = lambda: step_fn(ag, replay.sample())
     for _ in range(args.warmup):
         mets = run_step()
     torch.cuda.synchronize()
@@ -293,6 +404,21 @@ def main():
     loss = float(mets['model_loss'])
     assert np.isfinite(loss), loss
 
+    # ---- the same workload launched eagerly (no hipGraph: what an unmodified train.py loop gets), a short leg beside the replayed one
+    eager_ms = None
+    if world == 1 and graphed is not None and not args.no_eager_leg:
+        ac_ = GraphedStep._behavior(ag)
+        ac_._defer_slow_target = False
+        estep = (lambda: step_fn(ag, replay.sample())) if replay is not None else (lambda: step_fn(ag, batch))
+        estep(); torch.cuda.synchronize()
+        ne = max(3, min(args.steps, 10))
+        te = time.perf_counter()
+        for _ in range(ne):
+            estep()
+        torch.cuda.synchronize()
+        eager_ms = 1000.0 * (time.perf_counter() - te) / ne
+        ac_._defer_slow_target = True
+
     # ---- the same workload with fp32 MFMAs throughout (GENRL_GEMM_MODE=0 GENRL_PLANES=0 semantics), timed beside the default
     fp32_mode = None
     if world == 1 and args.precision == 32 and not args.no_fp32_mode and (ops.F32_MODE != 'f32' or planes.ENABLED):
@@ -304,7 +430,7 @@ def main():
             g2 = None
             if graphed is not None:
                 from genrl_amd.graph import GraphedStep
-                g2 = GraphedStep(ag, batch, one_step, warmup=1)
+                g2 = GraphedStep(ag, batch, step_fn, warmup=1)
             if replay is not None and g2 is not None:
                 def step2():
                     replay.sample(out=g2.static_batch)
@@ -312,7 +438,7 @@ def main():
             elif g2 is not None:
                 step2 = lambda: g2()
             else:
-                step2 = (lambda: one_step(ag, replay.sample())) if replay is not None else (lambda: one_step(ag, batch))
+                step2 = (lambda: step_fn(ag, replay.sample())) if replay is not None else (lambda: step_fn(ag, batch))
             n2 = max(3, min(args.steps, 10))
             step2(); torch.cuda.synchronize()
             t2 = time.perf_counter()
@@ -331,8 +457,8 @@ def main():
     out = None
     if rank == 0:
         sps = args.steps / dt
-        fl = flops_model.iteration_gflop(B * T)
-        out = {'metric': 'world-model+imag update steps/sec (B32xL32x64x64x3)', 'value': sps, 'unit': 'steps/s',
+        shape = f'B{B}xL{T}x{img}x{img}x3' if wl != 'c5' else f'{B * T} start rows, no frames'
+        out = {'metric': f'world-model+imag update steps/sec ({shape})', 'value': sps, 'unit': 'steps/s',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * dt / args.steps,
                'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
                'dtype': ('f32' if (ops.F32_MODE == 'f32' and not planes.ENABLED) else
@@ -349,10 +475,11 @@ def main():
                'data': 'synthetic (seeded uint8 64x64 RGB replay, random-init weights, stub text embedding); '
                        + ('fresh batch per step gathered on-GPU from a device-resident replay store' if replay is not None
                           else 'one fixed batch'),
-               'config': {'workload': 'configs[1]: full WM + 2x connector + imag-behaviour update, video_text_reward, '
-                                      f'batch {B} x seq {T}, 64x64x3, horizon 16, A=10',
+               'config': {'workload': f'{wl_text}, batch {B} x seq {T}, {img}x{img}x3, horizon {cfg.imag_horizon}, A={A}',
                           'global_batch': B, 'seq_len': T, 'parallelism': f'dp{world}',
-                          'launch': f'{launch_mode} ({sum(1 for k_, _ in graphed.items if k_ == "graph")} graphs per iteration)' if graphed is not None else 'eager'},
+                          'launch': f'{launch_mode} ({sum(1 for k_, _ in graphed.items if k_ == "graph")} graphs per iteration)' if graphed is not None else 'eager',
+                          # the same workload launched kernel by kernel from Python (no hipGraph), timed beside the replayed one
+                          'eager_ms_per_step': eager_ms, 'eager_steps_per_s': (1000.0 / eager_ms) if eager_ms else None},
                'algorithmic_gflop_per_step': fl['total'], 'executed_gflop_per_step': fl['executed'],
                # priced on the work this build EXECUTES (SURVEY's algorithmic count includes the policy's entropy re-evaluation,
                # 421 GF at c2, which contributes nothing with actor_ent = 0 and is not run here); the algorithmic figure beside it
@@ -373,7 +500,7 @@ def main():
             c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             c0.record(); torch.cuda._sleep(10_000_000); c1.record(); torch.cuda.synchronize()
             torch.cuda._sleep(int(10_000_000 * 150.0 / max(c0.elapsed_time(c1), 1e-3)))
-            one_step(ag, batch)
+            step_fn(ag, batch)
             torch.cuda.synchronize()
             pr = [(m, n, k, e0.elapsed_time(e1), tag) for (m, n, k, e0, e1, tag) in ops.gemm_profile + planes.gemm_profile]
             ops.gemm_profile = planes.gemm_profile = None
@@ -444,10 +571,11 @@ def main():
         dom = max(pipes, key=lambda k_: pipes[k_]['ms_per_step'])      # the pipe with the most kernel time leads the line
         # HBM bytes per launch of the GEMM kernels from the committed PMC passes of THIS round's build (rocprofv3 --pmc
         # runs are separate processes by construction: scripts/pmc.sh, FETCH_SIZE doubled per MI355X_MICROARCH.md)
-        traffic, tsrc = (None, 'skipped (--no-traffic)') if (args.no_traffic or world > 1) else measure_traffic()
+        traffic, tsrc = (None, 'skipped (--no-traffic)') if (args.no_traffic or world > 1) else measure_traffic(
+            extra=['--config', wl, '--batch', str(B), '--length', str(T)])
         if traffic is None:
             why = tsrc
-            for fn in ('r03_pmc.json', 'r02_pmc.json', 'r01_pmc.json'):
+            for fn in (('r04_pmc.json', 'r03_pmc.json', 'r02_pmc.json', 'r01_pmc.json') if wl == 'c2' else ()):
                 try:
                     pm = json.load(open(os.path.join(ROOT, 'profiles', fn)))
                     gk = [v for k_, v in pm.items() if k_.startswith('sgemm_') or k_.startswith('gemm_planes') or k_.startswith('gemm_x3')]
@@ -459,6 +587,10 @@ def main():
                     pass
         alg_bytes = sum(4.0 * (p_[0] * p_[2] + p_[1] * p_[2] + p_[0] * p_[1]) for p_ in prof) / max(len(prof), 1)
         out['roofline'] = {'bound': 'mfma', 'achieved': pipes[dom]['achieved'], 'peak': pipes[dom]['peak'],
+                           # both arithmetics in the parsed record: the headline (plane operands) and fp32 MFMAs in every product
+                           'fp32_mfma_mode_steps_per_s': fp32_mode['steps_per_s'] if fp32_mode else None,
+                           'fp32_mfma_mode_ms_per_step': fp32_mode['ms_per_step'] if fp32_mode else None,
+                           'default_mode_steps_per_s': sps,
                            'unit': 'TFLOP/s', 'frac': pipes[dom]['frac'], 'traffic': traffic, 'traffic_source': tsrc,
                            'algorithmic_operand_bytes_per_launch': alg_bytes, 'dominant_pipe': dom, 'pipes': pipes,
                            'all_gemm_fp32_equivalent': {'achieved': tot_fl / (tot_ms * 1e-3) / 1e12, 'peak': 157.3,

@@ -696,9 +696,12 @@ class Optimizer:
         ops.defer_begin()              # ... and the LayerNorm backward passes leave their parameter-gradient partials unreduced
         try:
             loss.backward(gradient=_one_like(loss))       # (a cached seed: torch would fill a fresh ones tensor per call)
-        finally:
+        except BaseException:
             ops.direct_grads = False
-            ops.defer_flush()          # one launch sums them all (the backward pass's streams have been joined by autograd)
+            ops.defer_abort()          # a failed backward pass: its partial sets (possibly never written) are NOT summed into the gradients
+            raise
+        ops.direct_grads = False
+        ops.defer_flush()              # one launch sums them all (the backward pass's streams have been joined by autograd)
         ops.wgrad_stream.join()
         if Optimizer.grad_hook is not None:
             Optimizer.grad_hook(self._name, live)
@@ -814,7 +817,12 @@ class StreamNorm:
         self.step += 1
         if self._momentum == 1 and self.mag is not None:
             return                                  # ema(old, new) = 1 * old + 0 * new: the statistics never move again
-        ema = lambda old, new: new.clone() if old is None else self._momentum * old + (1 - self._momentum) * new
+        # in place once the state exists: under hipGraph replay the state tensors keep their capture-time addresses, so the EMA
+        # advances across replays (a rebinding `old = m * old + (1 - m) * new` froze `old` at its warm-up value)
+        def ema(old, new):
+            if old is None:
+                return new.detach().clone()
+            return old.mul_(self._momentum).add_(new.detach(), alpha=1 - self._momentum)
         if mom is not None:        # scalar statistics from the one-pass kernel: the same EMA (ref :972-984), first call = copy
             self.mag, self.mean, self.square_mean = ema(self.mag, mom[2]), ema(self.mean, mom[0]), ema(self.square_mean, mom[3])
             return

@@ -17,8 +17,13 @@ import torch
 import torch.distributed as dist
 
 
-def init(backend=None):
-    """Initialise from the torchrun environment.  Returns (rank, world, local_rank)."""
+def init(backend=None, ingraph=None):
+    """Initialise from the torchrun environment.  Returns (rank, world, local_rank).
+
+    ingraph: will collectives be captured inside hipGraphs (graph.GraphedStep(collectives='ingraph'))?  Default: the
+    GENRL_DP_INGRAPH environment variable, else True for RCCL.  Only then is TORCH_NCCL_RETHROW_CUDA_ERRORS=0 set (see below);
+    a run that keeps its collectives eager / at graph cuts (GENRL_DP_INGRAPH=0, bench.py --dp-graph cut) leaves the process
+    group's default behaviour -- abort on an asynchronous device error -- in place."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -29,13 +34,70 @@ def init(backend=None):
         if backend is None:
             backend = os.environ.get('GENRL_DP_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
-            torch.cuda.set_device(local)
-            # a HIP error met by the process group's watchdog thread (it polls completion events; HIP refuses the query of an event
-            # whose stream has gone into capture -- graph.GraphedStep drains the watchdog's list before every capture so that this
-            # does not happen) must not abort the run: log it, do not rethrow
-            os.environ.setdefault('TORCH_NCCL_RETHROW_CUDA_ERRORS', '0')
+            torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+            prepare_nccl_env(ingraph)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def prepare_nccl_env(ingraph=None):
+    """Environment of an RCCL process group that may see hipGraph captures (call BEFORE init_process_group: the process group
+    reads both variables when it is constructed).
+    * TORCH_NCCL_TRACE_BUFFER_SIZE: the flight recorder, whose per-collective 'retired' flag is what drain_watchdog() polls;
+    * TORCH_NCCL_RETHROW_CUDA_ERRORS=0, ONLY for in-graph collectives: the watchdog thread polls the completion events of eager
+      collectives; HIP refuses the query of an event whose stream has meanwhile gone into capture and the watchdog would turn
+      that into an abort.  drain_watchdog() empties the watchdog's list before every capture, so the situation should not arise;
+      the variable is the second line of defence.  Its price, stated plainly: in this mode a genuine asynchronous device error
+      seen by the watchdog is LOGGED, not thrown -- the run continues until the next synchronising call reports it."""
+    if ingraph is None:
+        ingraph = os.environ.get('GENRL_DP_INGRAPH', '1') != '0'
+    os.environ.setdefault('TORCH_NCCL_TRACE_BUFFER_SIZE', '2000')
+    if ingraph:
+        os.environ.setdefault('TORCH_NCCL_RETHROW_CUDA_ERRORS', '0')
+
+
+_captured_ids = set()     # flight-recorder entries of collectives issued DURING a capture: the watchdog never tracks (or retires) those
+
+
+def _trace_entries():
+    import pickle
+    tr = pickle.loads(torch._C._distributed_c10d._dump_nccl_trace())
+    ents = tr.get('entries', []) if isinstance(tr, dict) else tr
+    return [(e.get('record_id', (e.get('pg_id'), e.get('collective_seq_id'), e.get('p2p_seq_id'), e.get('op_id'))), bool(e.get('retired', True)))
+            for e in ents]
+
+
+def note_captured():
+    """Called when a capture ends (graph.GraphedStep._end): every collective that is not retired NOW was issued inside the capture
+    (drain_watchdog() emptied the list before the capture began) and will never be retired -- drain_watchdog() ignores it from here on."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl'):
+        return
+    try:
+        _captured_ids.update(i for i, retired in _trace_entries() if not retired)
+    except Exception:
+        pass
+
+
+def drain_watchdog(timeout=2.0):
+    """Block until the RCCL process group's watchdog holds no eager collective any more: device synchronise, then poll the
+    flight recorder until every recorded eager collective is marked retired (the watchdog sets the flag when it drops the work from
+    its list).  Deterministic where the recorder is available (TORCH_NCCL_TRACE_BUFFER_SIZE > 0, prepare_nccl_env); otherwise, and
+    on a timeout, synchronise + two watchdog polling periods as before.  -> True when the list was seen empty."""
+    import time
+    if not (dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl'):
+        return True
+    torch.cuda.synchronize()
+    try:
+        if int(os.environ.get('TORCH_NCCL_TRACE_BUFFER_SIZE', '0')) > 0:
+            t0 = time.time()
+            while time.time() - t0 < timeout:
+                if all(retired or i in _captured_ids for i, retired in _trace_entries()):
+                    return True
+                time.sleep(0.01)
+    except Exception:
+        pass
+    time.sleep(0.25)
+    return False
 
 
 def shard_batch(batch, rank, world):

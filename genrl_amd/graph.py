@@ -54,7 +54,7 @@ class GraphedStep:
         self.step_fn = step_fn
         self.items = []          # ('graph', CUDAGraph) | ('eager', fn)
         self.metrics = None
-        ac = agent._imag_behavior
+        ac = self._behavior(agent)
         ac._defer_slow_target = True
         self.stream = torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())
@@ -109,12 +109,9 @@ class GraphedStep:
         (hipEventQuery, every 100 ms); HIP refuses that query -- 'operation not permitted on an event last recorded in a capturing
         stream', which the watchdog turns into an abort of the process -- once the stream the event was recorded on is capturing.
         Collectives issued during a capture are not put on that list, so it is enough to let the list run empty before a capture
-        begins: everything finished on the device, then two polling periods for the watchdog to reap it."""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl':
-            import time
-            torch.cuda.synchronize()
-            time.sleep(0.25)
+        begins: dp.drain_watchdog() synchronises the device and polls the flight recorder until every collective is retired."""
+        from . import dp
+        dp.drain_watchdog()
 
     def _begin(self):
         self._drain_backend()
@@ -125,6 +122,8 @@ class GraphedStep:
 
     def _end(self):
         self._g.capture_end()
+        from . import dp
+        dp.note_captured()
         self.items.append(('graph', self._g))
         self._g = None
 
@@ -146,11 +145,18 @@ class GraphedStep:
                 it()
         for g, d in zip(self._groups_captured, self._step_delta):
             g.step += d
-        self.agent._imag_behavior.update_slow_target()
+        self._behavior(self.agent).update_slow_target()
         return self.metrics
+
+    @staticmethod
+    def _behavior(agent):
+        """the actor-critic the iteration trains: GenRLAgent's imagination behaviour, DreamerAgent's acting behaviour"""
+        b = getattr(agent, '_imag_behavior', None)
+        return b if b is not None else agent._acting_behavior
 
     def _groups(self):
         """every flat optimiser group the iteration steps (the connector's lives in wm.model_opt beside the world model's)"""
         ag = self.agent
-        opts = [ag.wm.model_opt, ag._imag_behavior.actor_opt, ag._imag_behavior.critic_opt]
+        ac = self._behavior(ag)
+        opts = [ag.wm.model_opt, ac.actor_opt, ac.critic_opt]
         return [g for o in opts for g in o._groups]

@@ -67,9 +67,16 @@ DEFER_REDUCTIONS = os.environ.get('GENRL_DEFER_REDUCTIONS', '1') != '0'
 
 def defer_begin():
     global _deferred
-    if _deferred:                  # (a pass that never reached its flush -- an exception on the way: its sums are completed now)
-        defer_flush()
+    if _deferred:                  # (a pass that never reached its flush nor its abort: nothing of it may be summed later)
+        _deferred = None
     _deferred = [] if DEFER_REDUCTIONS else None
+
+
+def defer_abort():
+    """drop the registered partial sets without summing them (the backward pass that registered them raised: a launch that failed
+    after its set was registered never wrote its workspace)"""
+    global _deferred
+    _deferred = None
 
 
 def defer_reduce(M, N, ws, g0, g1, g2=None):
@@ -106,7 +113,10 @@ def defer_flush():
             r = (set(), [])
             rounds.append(r)
         r[0].add(key); r[1].append(it)
+    cur = torch.cuda.current_stream()
     for _, its in rounds:
+        for it in its:                 # a workspace filled on a side stream (the connector's) and summed here: keep it alive for this stream
+            it[0].record_stream(cur)
         arr = (_ReduceDesc * len(its))()
         for d, (ws, parts, N, np_, g0, g1, g2) in zip(arr, its):
             d.part, d.out0, d.out1, d.out2 = ws.data_ptr(), g0.data_ptr(), g1.data_ptr(), (g2.data_ptr() if g2 is not None else None)
@@ -1493,14 +1503,17 @@ def gru_step(x, h, W, gamma, beta):
     return _GRUStep.apply(x, h, W, gamma, beta)
 
 
-def scan_coop_variant(B, D, T):
+def scan_coop_variant(B, D, T, I=0):
     """0: the per-step launches (default); 1 / 2: the persistent scan kernel with one / two grid barriers per step
-    (GENRL_SCAN_COOP=1|2|auto; auto = one barrier where it exists (B <= 8), else two)"""
-    mode = os.environ.get('GENRL_SCAN_COOP', '0')
-    if mode in ('', '0') or D % 4 or not (8 <= D // 4 <= 256) or B not in (4, 8, 16, 32):
+    (GENRL_SCAN_COOP=1|2|auto; auto = one barrier where it exists (B <= 8), else two).  I: width of the input half of the GRU
+    weight (the W_h block starts at column I of each row: 16-byte aligned only when I % 4 == 0)."""
+    mode = os.environ.get('GENRL_SCAN_COOP', '0').strip().lower()
+    if mode in ('', '0', 'off') or D % 4 or I % 4 or not (8 <= D // 4 <= 256) or B not in (4, 8, 16, 32):
         return 0
     if mode == 'auto':
         return 1 if B <= 8 else 2
+    if mode not in ('1', '2'):
+        raise ValueError(f"GENRL_SCAN_COOP={mode!r}: expected 0, 1, 2 or auto")
     v = int(mode)
     return v if (v == 2 or B <= 8) else 0
 
@@ -1530,7 +1543,7 @@ class _GRUSeq(Function):
         else:
             hm = None
         BD, B3D = B * D, B * 3 * D
-        variant = scan_coop_variant(B, D, T)
+        variant = scan_coop_variant(B, D, T, I)
         if variant:
             # the whole recurrence in ONE persistent launch (csrc/scan_coop.hip): W_h resident in LDS, grid barriers per step
             ws = torch.empty(lib().genrl_gru_scan_coop_ws_floats(B, D) + 64, device=dev)
@@ -1538,6 +1551,13 @@ class _GRUSeq(Function):
             check(lib().genrl_gru_scan_coop(_p(pre), W.data_ptr() + 4 * I, K, _p(gamma), _p(beta), _p(h0), _p(mask), _p(out),
                                             _p(hm), _p(mean), _p(rstd), wsp, T, B, D, 1e-5, variant, _stream()), 'gru_scan_coop')
             ctx._coop_ws = ws
+            # the kernel is a plain launch of D/4 workgroups that must all be resident (one per CU): with other streams' kernels on
+            # the GPU a barrier can time out, the kernel then exits early and sets its fail word (workspace word 416).  Outside graph
+            # capture the word is read back (one host sync; this path is opt-in) and a truncated scan is an error, never silent.
+            if not torch.cuda.is_current_stream_capturing():
+                off = (wsp - ws.data_ptr()) // 4
+                if int(ws.view(torch.int32)[off + 416].item()) != 0:
+                    raise GenrlHipError('gru_scan_coop: a grid barrier timed out (workgroups not co-resident); unset GENRL_SCAN_COOP')
         for t in (range(T) if not variant else ()):
             if hm is not None:
                 hprev, hoff = hm, t * BD

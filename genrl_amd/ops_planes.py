@@ -288,7 +288,10 @@ class _DenseLNActPlanes(Function):
         ctx.has2 = c is not None
         ctx.bias = b
         # the inputs' planes serve the weight gradient again (genrl_gemm_h2_tn): kept with the node
-        ctx.in_planes = ((P1, r1), (P2, r2)) if (P1 is not None and (c is None or P2 is not None)) else None
+        # (only when that product will really take them: otherwise the fp16 copies would live from forward to backward for nothing)
+        keep = (P1 is not None and (c is None or P2 is not None) and ctx.needs_input_grad[2] and planes.tn_ok(M, N, K1, K)
+                and (c is None or K2 % 4 == 0) and r1 % 4 == 0 and r2 % 4 == 0)
+        ctx.in_planes = ((P1, r1), (P2, r2)) if keep else None
         ctx.shapes = (x1.shape, x2.shape if x2 is not None else None)
         return y.reshape(*x1.shape[:-1], N)
 
@@ -366,7 +369,7 @@ class _LinearPlanes(Function):
         ctx.save_for_backward(x2, W)
         ctx.bias = b
         ctx.xshape = x.shape
-        ctx.in_planes = (P, r0)
+        ctx.in_planes = (P, r0) if (ctx.needs_input_grad[1] and planes.tn_ok(M, N, K, K) and r0 % 4 == 0) else None
         return (y if Np == N else y[:, :N]).view(*x.shape[:-1], N)
 
     @staticmethod
@@ -377,7 +380,7 @@ class _LinearPlanes(Function):
         b = ctx.bias
         dy2, ldy = ops._rows_ld(dy.reshape(M, N))        # (a gradient arriving in padded rows is read in place)
         dx = dW = db = None
-        tn = ctx.needs_input_grad[1] and planes.tn_ok(M, N, K, K)
+        tn = ctx.needs_input_grad[1] and ctx.in_planes is not None and planes.tn_ok(M, N, K, K)
         dyp = planes.split(dy2) if (ctx.needs_input_grad[0] or tn) else None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dy.device)

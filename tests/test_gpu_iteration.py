@@ -79,6 +79,15 @@ def run_product(name, lr_zero, cfg_over, ocfg_over, overlap=False):
     return g, ocfg, p, batch_cpu, noise, ag, outputs, mets_wm, mets, grads
 
 
+def measured(name, value):
+    """GENRL_PARITY_REPORT=<file>: append the MEASURED value behind an assertion (the tolerances below are set to ~2x what this
+    reports on MI355X, so that a regression of the plane arithmetic shows; profiles/r04_parity_measured.txt is one such report)"""
+    path = os.environ.get('GENRL_PARITY_REPORT')
+    if path:
+        with open(path, 'a') as f:
+            f.write(f'{name} {value:.3e}\n')
+
+
 def check_vs_golden(g, mets_wm, mets, rtol):
     for key, val in g.items():
         for pre, src in (('metrics_wm.', mets_wm), ('metrics_conn2.', mets), ('metrics_imag.', mets)):
@@ -128,7 +137,7 @@ def test_tiny_optimizer_step_vs_reference():
     g, ocfg, p, batch, noise, ag, outputs, mets_wm, mets, grads = run_product('tiny_opt.npz', False, config.tiny_overrides(), tiny_o)
     check_vs_golden(g, mets_wm, mets, 1e-3)
     sd = ag.state_dict()
-    bad = 0
+    bad, worst = 0, 0.0
     for key, val in g.items():
         if key.startswith('psum.'):
             name = key[len('psum.'):]
@@ -137,6 +146,15 @@ def test_tiny_optimizer_step_vs_reference():
             d = (sd[name].cpu() - p[name]).double()
             if not np.isclose(d.abs().sum().item(), val[1], rtol=0.05, atol=1e-7):
                 bad += 1
+            # SURVEY 8(c)'s elementwise bound, for THIS test too: one Adam step moves an element by <= lr (m / sqrt(v) = +-1 on the
+            # first step) plus weight decay, so a parameter may differ from the reference's updated one by at most 2 lr per step
+            # taken -- the connector's group steps twice per iteration (Q1)
+            lr = ag.cfg.model_opt.lr if name.startswith('wm.') else ag.cfg.actor_opt.lr
+            nstep = 2 if name.startswith('wm.connector') else 1
+            worst = max(worst, d.abs().max().item() / (lr * nstep))
+            assert d.abs().max().item() <= 2.0 * lr * nstep * (1 + 1e-3), (name, d.abs().max().item(), lr, nstep)
+    measured('tiny_opt.max_elem_delta_over_lr', worst)
+    measured('tiny_opt.groups_outside_5pct_L1', bad)
     assert bad <= 3, bad
     # slow critic hard-copied after the first update (agent/dreamer.py:455-462)
     for k in sd:
@@ -144,17 +162,27 @@ def test_tiny_optimizer_step_vs_reference():
             assert torch.equal(sd[k], sd[k.replace('_target_critic', 'critic')])
 
 
+# tolerances of the full-width c1 case = ~2x the values measured on MI355X with plane operands forced on at every size
+# (profiles/r04_parity_measured.txt): sampled-latent mismatches and the worst relative error of a per-tensor gradient L2 norm
+C1_MAX_IDX_MISMATCH = 5e-4
+C1_GRAD_L2_RTOL = 1e-3
+
+
 @pytest.mark.parametrize('overlap', [False, True])
 def test_c1_full_dims_vs_reference(overlap):
     g, ocfg, p, batch, noise, ag, outputs, mets_wm, mets, grads = run_product('c1_full.npz', True, {}, {}, overlap=overlap)
     mism = (outputs['post']['stoch'].argmax(-1).cpu().numpy() != g['post_idx']).mean()
-    assert mism < 2e-3, mism
+    measured(f'c1_full.post_idx_mismatch[overlap={overlap}]', mism)
+    assert mism <= C1_MAX_IDX_MISMATCH, mism
     check_vs_golden(g, mets_wm, mets, 1e-3)
+    worst = 0.0
     for key, val in g.items():
         if key.startswith('gsum.'):
             _, ph, name = key.split('.', 2)
             l2 = grads[ph][name].double().norm().item()
-            np.testing.assert_allclose(l2, val[2], rtol=5e-3, atol=1e-6, err_msg=key)
+            worst = max(worst, abs(l2 - val[2]) / max(abs(val[2]), 1e-12) if abs(val[2]) > 1e-6 else 0.0)
+            np.testing.assert_allclose(l2, val[2], rtol=C1_GRAD_L2_RTOL, atol=1e-6, err_msg=key)
+    measured(f'c1_full.worst_grad_L2_rel[overlap={overlap}]', worst)
 
 
 def test_c4_128px_five_layer_convs_vs_reference():

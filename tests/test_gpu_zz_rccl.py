@@ -55,15 +55,19 @@ def _rccl_worker(port, q):
                     out.append({k: float(torch.as_tensor(v).detach()) for k, v in m.items()})
                 return out, sum(1 for k, _ in gs.items if k == 'graph')
         ref, _ = run('eager')                                  # no process group, no hooks
+        dp.prepare_nccl_env(ingraph=True)                      # flight recorder on (drain_watchdog polls it), watchdog errors logged
         dist.init_process_group('nccl', rank=0, world_size=1)
         dp.install(common.Optimizer, common.RewardEMA, force=True)
         assert common.Optimizer.grad_reduce is not None and common.Optimizer.overlap_under_dp
         eager, _ = run('eager')
+        drained = [dp.drain_watchdog()]                        # eager collectives behind us: the recorder must show them all retired
         ingraph, n_in = run('ingraph')
+        drained.append(dp.drain_watchdog())                    # ... and captured ones must not keep the drain waiting
         cut, n_cut = run('cut')
+        drained.append(dp.drain_watchdog())
         dp.uninstall(common.Optimizer, common.RewardEMA)
         dist.destroy_process_group()
-        q.put(('ok', ref, eager, ingraph, cut, n_in, n_cut))
+        q.put(('ok', ref, eager, ingraph, cut, n_in, n_cut, drained))
     except BaseException:
         import traceback
         q.put(('error', traceback.format_exc()))
@@ -82,7 +86,8 @@ def test_rccl_one_rank_eager_ingraph_and_cut():
     finally:
         if p_.is_alive():
             p_.terminate()
-    _, ref, eager, ingraph, cut, n_in, n_cut = item
+    _, ref, eager, ingraph, cut, n_in, n_cut, drained = item
+    assert all(drained), drained           # the deterministic drain (flight recorder) saw the watchdog's list empty every time
     assert n_in == 1, n_in                 # every collective inside the one captured graph
     assert n_cut > 1, n_cut                # the fallback really cuts
     for step in range(3):
