@@ -401,8 +401,9 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = dp.barrier_max(time.perf_counter() - t0, dev)
-    loss = float(mets['model_loss'])
-    assert np.isfinite(loss), loss
+    loss_key = 'model_loss' if 'model_loss' in mets else 'imag_critic_loss'      # (configs[4] has no world-model phase)
+    loss = float(mets[loss_key])
+    assert np.isfinite(loss), (loss_key, loss)
 
     # ---- the same workload launched eagerly (no hipGraph: what an unmodified train.py loop gets), a short leg beside the replayed one
     eager_ms = None
@@ -486,7 +487,7 @@ def main():
                'step_roofline': {'bound': 'mfma', 'achieved': fl['executed'] * sps / 1e3 / world, 'peak': PEAK_F32_MFMA_TFLOPS,
                                  'unit': 'TFLOP/s', 'frac': fl['executed'] * sps / 1e3 / world / PEAK_F32_MFMA_TFLOPS,
                                  'on': 'executed GF per step', 'frac_on_algorithmic_gflop': fl['total'] * sps / 1e3 / world / PEAK_F32_MFMA_TFLOPS},
-               'final_model_loss': loss, 'fp32_mfma_mode': fp32_mode}
+               'final_model_loss': loss, 'final_loss_key': loss_key, 'fp32_mfma_mode': fp32_mode}
     # ---- kernel roofline: HIP events around every launch of the fp32-MFMA GEMM kernel in one extra step
     # (data parallel: no event-instrumented extra steps -- they would contain collectives and every rank would have to take
     # part in lock step; the kernel roofline is the N=1 line's business)

@@ -268,3 +268,77 @@ extern "C" int genrl_gather_windows(const void* src, long row_bytes, long ring_r
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Helpers of the gather ("sub-pixel") form of the stride-2 transposed convolutions (genrl_gemm_h2_subpixel, gemm_planes.hip).
+namespace {
+// dst[p][n][y][x][:] = src[p][n][y - pad][x - pad][:] inside, 0 on the border; one 16-byte lane per 8 channels, both planes;
+// the uniform inverse scale is broadcast to every padded row
+__global__ __launch_bounds__(256) void pad_planes_kernel(const uint4* __restrict__ src, long splane16, const float* __restrict__ sinv,
+                                                         uint4* __restrict__ dst, long dplane16, float* __restrict__ dinv,
+                                                         int Nimg, int H, int W, int ld16, int pad) {
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  const long total = (long)Nimg * Hp * Wp * ld16;
+  const float iv = sinv[0];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long pix = i / ld16;
+    const int c = (int)(i - pix * ld16);
+    const int x = (int)(pix % Wp);
+    const long t = pix / Wp;
+    const int y = (int)(t % Hp);
+    const long n = t / Hp;
+    const int sy = y - pad, sx = x - pad;
+    uint4 h = make_uint4(0u, 0u, 0u, 0u), l = h;
+    if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
+      const long sp = ((n * H + sy) * W + sx) * ld16 + c;
+      h = src[sp]; l = src[splane16 + sp];
+    }
+    dst[i] = h; dst[dplane16 + i] = l;
+    if (c == 0) dinv[pix] = iv;
+  }
+}
+
+// Wsub[(a, b, co)][(u, v, ci)] = w(ci, co, a + 2 (T - 1 - u), b + 2 (T - 1 - v)) (0 where the tap index reaches k); one thread per
+// output element (<= 2.7 M elements per layer, once per optimiser step)
+__global__ __launch_bounds__(256) void subpixel_weight_kernel(const float* __restrict__ W, long s_ci, long s_co, long s_tap, int Ci, int Co, int k, int T,
+                                                              float* __restrict__ Wsub, const float* __restrict__ bias,
+                                                              float* __restrict__ bias4) {
+  const long K = (long)T * T * Ci, total = 4L * Co * K;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < 4L * Co && bias4) bias4[i] = bias[i % Co];
+  if (i >= total) return;
+  const long n = i / K;
+  const int kk = (int)(i - n * K);
+  const int cls = (int)(n / Co), co = (int)(n - (long)cls * Co);
+  const int a = cls >> 1, b = cls & 1;
+  const int tap = kk / Ci, ci = kk - tap * Ci;
+  const int u = tap / T, v = tap - u * T;
+  const int kh = a + 2 * (T - 1 - u), kw = b + 2 * (T - 1 - v);
+  Wsub[i] = (kh < k && kw < k) ? W[ci * s_ci + co * s_co + (kh * k + kw) * s_tap] : 0.f;
+}
+}  // namespace
+
+extern "C" int genrl_pad_planes(const uint16_t* src, long splane, const float* sinv, uint16_t* dst, long dplane, float* dinv, int Nimg,
+                                int H, int W, long ld, int pad, void* stream) {
+  GENRL_ENTER();
+  if (Nimg <= 0 || H <= 0 || W <= 0 || pad < 0 || (ld & 7) || (splane & 7) || (dplane & 7) ||
+      ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15))
+    return GENRL_EINVAL;
+  const long total = (long)Nimg * (H + 2 * pad) * (W + 2 * pad) * (ld / 8);
+  const int blocks = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
+  hipLaunchKernelGGL(pad_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint4*>(src), splane / 8,
+                     sinv, reinterpret_cast<uint4*>(dst), dplane / 8, dinv, Nimg, H, W, (int)(ld / 8), pad);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}
+
+extern "C" int genrl_subpixel_weight(const float* W, long s_ci, long s_co, long s_tap, int Ci, int Co, int k, int T, float* Wsub,
+                                     const float* bias, float* bias4, void* stream) {
+  GENRL_ENTER();
+  if (Ci <= 0 || Co <= 0 || k < 1 || T < 1 || 2 * T < k || (bias4 && !bias)) return GENRL_EINVAL;
+  const long total = 4L * Co * T * T * Ci;
+  hipLaunchKernelGGL(subpixel_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, W, s_ci, s_co, s_tap, Ci, Co, k, T,
+                     Wsub, bias, bias4);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}

@@ -74,7 +74,14 @@ struct SampleEpi {
 // address does the gather (16-byte chunks = 8 channels of one pixel; C % 8 == 0); chunks beyond K = k k C re-read the last valid
 // one (finite data against the zero padding of the weight planes).
 struct ConvGather {
-  int H, W, C, k, Ho, Wo, K;     // image height / width / channels, kernel size, output height / width, k k C
+  int H, W, C, k, Ho, Wo, K;     // image height / width / channels, kernel WIDTH (taps per patch row), patch grid height / width, K
+  int s;                         // patch stride in pixels (2: the stride-2 convolutions; 1: the sub-pixel gather form below)
+  // Sub-pixel ("pixel shuffle") epilogue, sCo > 0 -- the GATHER form of a stride-2 transposed convolution / of a stride-2
+  // convolution's input gradient with an even kernel k = 2T: all four output parity classes (a, b) of out[2 py + a][2 px + b] read
+  // the SAME T x T patch of the zero-padded input, so one product with rows m = (image, py, px) and columns n = (a, b, co) does
+  // the whole layer, and the epilogue writes row m / column n to out[image][2 py + a][2 px + b][co] (NHWC, sHo x sWo x sCo;
+  // positions beyond sHo / sWo are dropped): no cols matrix, no col2im pass.
+  int sHo, sWo, sCo;
 };
 
 // a / b for exact powers of two (exponent arithmetic; clamped to the normal range)
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
         const int m = min(m0 + row, M - 1);
         const int n_img = m / (cg.Ho * cg.Wo), rem = m - n_img * (cg.Ho * cg.Wo);
         const int oy = rem / cg.Wo, ox = rem - oy * cg.Wo;
-        voff[i] = (unsigned)(((long)p * plane + ((long)(n_img * cg.H + 2 * oy) * cg.W + 2 * ox) * ld) * 2);
+        voff[i] = (unsigned)(((long)p * plane + ((long)(n_img * cg.H + cg.s * oy) * cg.W + cg.s * ox) * ld) * 2);
       }
 #pragma unroll
       for (int par = 0; par < 2; ++par) {
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_hl_kernel(PlaneSeg s0, flo
       const int m = min(m0 + row, M - 1);
       const int n_img = m / (cg.Ho * cg.Wo), rem = m - n_img * (cg.Ho * cg.Wo);
       const int oy = rem / cg.Wo, ox = rem - oy * cg.Wo;
-      voff[i] = (unsigned)((((long)(n_img * cg.H + 2 * oy) * cg.W + 2 * ox) * ld) * 2);
+      voff[i] = (unsigned)((((long)(n_img * cg.H + cg.s * oy) * cg.W + cg.s * ox) * ld) * 2);
     }
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
@@ -801,11 +808,18 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_hl_kernel(PlaneSeg s0, flo
     return make_float4(t[0], t[1], t[2], t[3]);
   };
   const bool vec_c = ((ldc & 3) == 0) && (((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0);
+  const bool shuffle = CONV && cg.sCo > 0;      // (host side guarantees: sCo % 4 == 0, 16-byte aligned output, no accumulate)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = m0 + (wm * 2 + i) * 32 + l32;
     if (row >= M) continue;
     const float ra = s0.a_inv ? epi_f((wm * 2 + i) * 32 + l32) : 1.f;
+    int s_py = 0, s_px = 0; long s_img = 0;      // sub-pixel epilogue: this row's patch position
+    if (shuffle) {
+      const int per = cg.Ho * cg.Wo, n_img = row / per, rem = row - n_img * per;
+      s_py = rem / cg.Wo; s_px = rem - s_py * cg.Wo;
+      s_img = (long)n_img * cg.sHo;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -819,6 +833,13 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_hl_kernel(PlaneSeg s0, flo
 #pragma unroll
         for (int v = 0; v < 4; ++v)
           o[v] = (acc[0][i][j][4 * gq + v] * (1.f / 2048.f) + acc[1][i][j][4 * gq + v]) * ra * cbv[v] + bsv[v];
+        if (shuffle) {        // columns col .. col + 3 = channels co .. co + 3 of parity class (a, b)
+          const int cls = col / cg.sCo, co = col - cls * cg.sCo;
+          const int oy = 2 * s_py + (cls >> 1), ox = 2 * s_px + (cls & 1);
+          if (oy < cg.sHo && ox < cg.sWo)
+            *reinterpret_cast<float4*>(C + ((s_img + oy) * cg.sWo + ox) * cg.sCo + co) = make_float4(o[0], o[1], o[2], o[3]);
+          continue;
+        }
         float* c = C + (long)row * ldc + col;
         if (vec_c && col + 3 < N) {
           if (accumulate) {
@@ -1278,11 +1299,41 @@ int genrl_gemm_h2_conv(const uint16_t* img, long ld_img, long plane_img, const f
   log_launch("h2/conv128", M, N, (int)b_ld);
   if (hl_on())
     gemm_planes_hl_kernel<true><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, C, ldc, bias, M, N, accumulate, tm, tn, xcd_split(tm, tn),
-                                                                          ConvGather{H, W, Cc, k, Ho, Wo, K});
+                                                                          ConvGather{H, W, Cc, k, Ho, Wo, K, 2, 0, 0, 0});
   else
     gemm_planes_kernel<2, 2, 64, 2, 1, 2, false, true><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, none, C, ldc, bias, M, N, accumulate, tm, tn,
                                                                                              xcd_split(tm, tn), SampleEpi{},
-                                                                                             ConvGather{H, W, Cc, k, Ho, Wo, K});
+                                                                                             ConvGather{H, W, Cc, k, Ho, Wo, K, 2, 0, 0, 0});
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}
+
+/* Gather ("sub-pixel") form of a stride-2 transposed convolution with an even kernel k = 2T -- nn.ConvTranspose2d(k, 2) forward
+ * (agent/dreamer_utils.py:686-706) and, with the roles of the channels swapped, the input gradient of nn.Conv2d(k, 2) (:590-612):
+ *   out[n][2 py + a][2 px + b][co] = bias[(a, b, co)] + sum_{u, v, c} img[n][py + u][px + v][c] * B[(a, b, co)][(u, v, c)]
+ * img: UNIFORM-scale planes of the input zero-padded by T - 1 pixels on every side, [Nimg][Hp][Wp][ld_img]; patches T x T with
+ * stride 1 (Hq = Hp - T + 1 patch rows); B: planes of the rearranged weight, 4 Co rows x T T Cc columns (b_ld = that rounded up to
+ * 64), B[(a, b, co)][(u, v, c)] = W[c][co][a + 2 (T - 1 - u)][b + 2 (T - 1 - v)]; bias: 4 Co floats or NULL.  out: fp32 NHWC
+ * [Nimg][Ho][Wo][Co]; output positions with 2 py + a >= Ho or 2 px + b >= Wo are dropped, positions no patch reaches are NOT
+ * written (the caller zero-fills when Ho > 2 Hq).  Cc % 8 == 0, Cc >= 48, Co % 4 == 0, out 16-byte aligned. */
+int genrl_gemm_h2_subpixel(const uint16_t* img, long ld_img, long plane_img, const float* img_inv, int Nimg, int Hp, int Wp, int Cc, int T,
+                           const uint16_t* b, long b_ld, long b_plane, const float* b_inv, float* out, int Ho, int Wo, int Co,
+                           const float* bias, void* stream) {
+  GENRL_ENTER();
+  const int Hq = Hp - T + 1, Wq = Wp - T + 1, K = T * T * Cc, N = 4 * Co;
+  const long Ml = (long)Nimg * Hq * Wq;
+  if (Nimg <= 0 || T < 1 || Hq <= 0 || Wq <= 0 || Co <= 0 || (Co & 3) || (Cc & 7) || Cc < 48 || ld_img < Cc || (ld_img & 7) || (b_ld & 63) ||
+      b_ld < K || b_ld >= K + 64 || !img_inv || !b_inv || Ml > 0x7fffffffL || Ho <= 0 || Wo <= 0 || (reinterpret_cast<uintptr_t>(out) & 15) ||
+      (reinterpret_cast<uintptr_t>(bias) & 15))
+    return GENRL_EINVAL;
+  if ((((long)Nimg * Hp * Wp * ld_img + plane_img) * 2) >= 0xffffffffL) return GENRL_EINVAL;     // (32-bit byte offsets in the gather)
+  if (!hl_on()) return GENRL_EINVAL;                                                              // (the epilogue lives in the half-stage kernel)
+  const int M = (int)Ml;
+  PlaneSeg s0{img, ld_img, plane_img, b, b_ld, b_plane, (int)b_ld, img_inv, b_inv};
+  const int tm = cdiv(M, 128), tn = cdiv(N, 128);
+  log_launch("h2/subpixel128", M, N, (int)b_ld);
+  gemm_planes_hl_kernel<true><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, out, 4, bias, M, N, 0, tm, tn, xcd_split(tm, tn),
+                                                                        ConvGather{Hp, Wp, Cc, T, Hq, Wq, K, 1, Ho, Wo, Co});
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }

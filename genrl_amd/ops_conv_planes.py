@@ -62,6 +62,7 @@ def _uniform_split(x2d):
     P = planes.Planes(R, C, x2d.device, zero=False)
     ws = torch.empty(1024, device=x2d.device)
     check(lib().genrl_split_h2u(_p(x2d), C, R, C, P.ptr(), P.ld, P.plane, P.inv_ptr(), _p(ws), _stream()), 'split_h2u')
+    P.uniform = True
     return P
 
 
@@ -75,6 +76,7 @@ def _ln_fwd(pre2d, gamma, beta, eps, want_planes):
         P = planes.Planes(M, N, pre2d.device, zero=False)
         check(lib().genrl_ln_act_fwd_h2u(_p(pre2d), N, _p(gamma), _p(beta), _p(y), N, _p(mean), _p(rstd), M, N, eps, 1,
                                          P.ptr(), P.ld, P.plane, P.inv_ptr(), _stream()), 'ln_act_fwd_h2u')
+        P.uniform = True
     else:
         check(lib().genrl_ln_act_fwd(_p(pre2d), N, _p(gamma), _p(beta), _p(y), N, _p(mean), _p(rstd), M, N, eps, 1, _stream()),
               'ln_act_fwd')
@@ -104,6 +106,7 @@ def _ln_bwd(dy2d, pre2d, gamma, beta, mean, rstd, bias, want_planes):
         check(lib().genrl_ln_act_bwd_h2u(_p(dy2d), N, _p(pre2d), N, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dpre), N, _p(g0), _p(g1),
                                          _p(g2), _p(ws), M, N, 1, acc_p, P.ptr(), P.ld, P.plane, P.inv_ptr(), _p(amax), _stream()),
               'ln_act_bwd_h2u')
+        P.uniform = True
     else:
         check(lib().genrl_ln_act_bwd(_p(dy2d), N, _p(pre2d), N, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dpre), N, _p(g0), _p(g1),
                                      _p(g2), _p(ws), M, N, 1, acc_p, _stream()), 'ln_act_bwd')
@@ -139,6 +142,49 @@ def _gemm_tn_conv(Ap, img_p, Nimg, H, W, C, k, out, ldc, NI, M):
     if planes.gemm_profile is not None:
         e1 = torch.cuda.Event(enable_timing=True); e1.record()
         planes.gemm_profile.append((NI, NJ, M, e0, e1, 'rr/conv2/h2tn/pipe4'))
+
+
+# ---- gather ("sub-pixel") form of the scatter side: ConvTranspose2d forward / Conv2d input gradient without cols + col2im ---------
+SUBPIXEL = os.environ.get('GENRL_SUBPIXEL', '1') != '0'
+SUBPIXEL_ODD = os.environ.get('GENRL_SUBPIXEL_ODD', '0') != '0'     # odd kernels (k = 5 treated as 6 with a zero tap: 1.4x the taps)
+
+
+def _hl_on():
+    return os.environ.get('GENRL_PLANES_HL', '1')[:1] != '0'
+
+
+def subpixel_ok(xp, Nimg, Hi, Wi, Cs, Cp, k):
+    """may genrl_gemm_h2_subpixel take this layer?  xp: planes of the [Nimg Hi Wi][Cs] input (must be uniform-scale); Cs summed
+    channels, Cp produced channels, k the stride-2 kernel"""
+    T = (k + 1) // 2
+    return (SUBPIXEL and _hl_on() and xp is not None and xp.uniform and (k % 2 == 0 or SUBPIXEL_ODD) and Cs % 8 == 0 and Cs >= 48 and Cp % 4 == 0
+            and xp.cols == Cs and Nimg * (Hi + T - 1) * (Wi + T - 1) >= min_rows() // 4)
+
+
+def _subpixel(xp, Nimg, Hi, Wi, Cs, Cp, k, Wsrc, s_ci, s_co, s_tap, bias, out):
+    """out[n][2 py + a][2 px + b][cp] = bias[cp] + sum over the T x T patch of the zero-padded input and the Cs summed channels
+    (genrl_gemm_h2_subpixel); out: fp32 NHWC (Nimg, Ho, Wo, Cp), fully written when Ho <= 2 (Hi + T - 1) (the caller zero-fills otherwise)"""
+    T = (k + 1) // 2
+    pad = T - 1
+    dev = out.device
+    Hp, Wp = Hi + 2 * pad, Wi + 2 * pad
+    if planes.gemm_profile is not None:
+        e0 = torch.cuda.Event(enable_timing=True); e0.record()
+    xq = planes.Planes(Nimg * Hp * Wp, Cs, dev, zero=False)
+    assert xq.ld == xp.ld
+    check(lib().genrl_pad_planes(xp.ptr(), xp.plane, xp.inv_ptr(), xq.ptr(), xq.plane, xq.inv_ptr(), Nimg, Hi, Wi, xp.ld, pad, _stream()),
+          'pad_planes')
+    K = T * T * Cs
+    wsub = torch.empty(4 * Cp, K, device=dev)
+    b4 = torch.empty(4 * Cp, device=dev) if bias is not None else None
+    check(lib().genrl_subpixel_weight(_p(Wsrc), s_ci, s_co, s_tap, Cs, Cp, k, T, _p(wsub), _p(bias), _p(b4), _stream()), 'subpixel_weight')
+    wp = planes.split(wsub)
+    _, Ho, Wo, _ = out.shape
+    check(lib().genrl_gemm_h2_subpixel(xq.ptr(), xq.ld, xq.plane, xq.inv_ptr(), Nimg, Hp, Wp, Cs, T, wp.ptr(), wp.ld, wp.plane, wp.inv_ptr(),
+                                       _p(out), Ho, Wo, Cp, _p(b4), _stream()), 'gemm_h2_subpixel')
+    if planes.gemm_profile is not None:
+        e1 = torch.cuda.Event(enable_timing=True); e1.record()
+        planes.gemm_profile.append((Nimg * (Hp - T + 1) * (Wp - T + 1), 4 * Cp, K, e0, e1, 'kk/subpixel/h2/pipe4'))
 
 
 KR_MIN_K = int(os.environ.get('GENRL_PLANES_KR_MIN_K', '512'))      # GEMM -> col2im products: with few input channels (K = C) a 128 x 128 tile is two K stages of prologue and a
@@ -192,7 +238,9 @@ class _Conv2dS2P(Function):
         need_dx = (not u8) and ctx.needs_input_grad[0]
         tn = xp is not None and ctx.needs_input_grad[1] and M % 64 == 0 and K % 8 == 0
         kr = need_dx and M >= min_rows() and Co >= KR_MIN_K
-        dy2, dg, dbe, db, dyp = _ln_bwd(dy.reshape(M, Co).contiguous(), pre, gamma, beta, mean, rstd, ctx.bias, want_planes=tn or kr)
+        # (the LayerNorm backward's planes are uniform-scale whenever it makes them itself: Co <= 256)
+        sp_maybe = need_dx and SUBPIXEL and _hl_on() and (k % 2 == 0 or SUBPIXEL_ODD) and Co % 8 == 0 and Co >= 48 and C % 4 == 0
+        dy2, dg, dbe, db, dyp = _ln_bwd(dy.reshape(M, Co).contiguous(), pre, gamma, beta, mean, rstd, ctx.bias, want_planes=tn or kr or sp_maybe)
         dx = dW = None
         if ctx.needs_input_grad[1]:
             dW = torch.empty(Co, K, device=dy.device)
@@ -204,7 +252,13 @@ class _Conv2dS2P(Function):
                 cols = ops._im2col(x, Nimg, Hi, Wi, C, k, 2 if u8 else 0)
                 sgemm(dy2, 1, Co, cols, 1, K, dW, K, None, Co, K, M)
                 del cols
-        if need_dx:
+        if need_dx and sp_maybe and subpixel_ok(dyp, Nimg, Ho, Wo, Co, C, k):
+            # gather form: dx[n][2 py + a][2 px + b][ci] = sum over the T x T patch of the zero-padded dy and co -- no cols, no col2im
+            T = (k + 1) // 2
+            full = Hi <= 2 * (Ho + T - 1) and Wi <= 2 * (Wo + T - 1)        # (an odd input size leaves its last row / column without a patch)
+            dx = (torch.empty if full else torch.zeros)(Nimg, Hi, Wi, C, device=dy.device)
+            _subpixel(dyp, Nimg, Ho, Wo, Co, C, k, Wp, K, 1, C, None, dx)      # Wp = (co, kh, kw, ci): strides of (co, ci, tap) = (K, 1, C)
+        elif need_dx:
             dcols = torch.empty(M, K, device=dy.device)
             if kr and dyp is not None:
                 planes.gemm(dyp, planes.split(Wp.detach(), transpose=True), dcols, K, None, M, K)      # dcols = dy W
@@ -224,15 +278,21 @@ class _ConvT2dS2P(Function):
         Nw = Wp.shape[1]
         Co = Nw // (k * k)
         M = Nimg * Hi * Wi
-        cols = torch.empty(M, Nw, device=x.device)
         if xp is None and M >= min_rows() // 4 and Ci % 4 == 0:
             xp = planes.split(x.reshape(M, Ci))                      # (the first layer's input comes from a Linear)
         on_planes = xp is not None and M * (k * k) >= min_rows()
-        if on_planes and Ci >= KR_MIN_K:
-            planes.gemm(xp, planes.split(Wp.detach(), transpose=True), cols, Nw, None, M, Nw)      # cols = x W
+        if on_planes and Hi > 1 and subpixel_ok(xp, Nimg, Hi, Wi, Ci, Co, k):
+            # gather form: every output pixel sums its T x T patch of the zero-padded input -- no cols matrix, no col2im
+            y = torch.empty(Nimg, 2 * (Hi - 1) + k, 2 * (Wi - 1) + k, Co, device=x.device)
+            _subpixel(xp, Nimg, Hi, Wi, Ci, Co, k, Wp, Nw, 1, Co, b, y)         # Wp = (ci, kh, kw, co): strides of (ci, co, tap) = (Nw, 1, Co)
         else:
-            sgemm(x, Ci, 1, Wp, 1, Nw, cols, Nw, None, M, Nw, Ci)
-        y = ops._col2im(cols, b, Nimg, Hi, Wi, Co, k)
+            cols = torch.empty(M, Nw, device=x.device)
+            if on_planes and Ci >= KR_MIN_K:
+                planes.gemm(xp, planes.split(Wp.detach(), transpose=True), cols, Nw, None, M, Nw)      # cols = x W
+            else:
+                sgemm(x, Ci, 1, Wp, 1, Nw, cols, Nw, None, M, Nw, Ci)
+            y = ops._col2im(cols, b, Nimg, Hi, Wi, Co, k)
+            del cols
         Ho, Wo = y.shape[1], y.shape[2]
         out, mean, rstd, outp = _ln_fwd(y.reshape(-1, Co), gamma, beta, eps, want_planes=Nimg * Ho * Wo >= min_rows())
         holder.append(outp)

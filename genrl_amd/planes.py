@@ -29,10 +29,11 @@ def r64(k):
 
 class Planes:
     """planes of a (rows x cols) matrix; .t int16 [2, rows, ld] (fp16 bits), .inv fp32 [rows]"""
-    __slots__ = ('t', 'inv', 'rows', 'cols', 'ld', 'plane')
+    __slots__ = ('t', 'inv', 'rows', 'cols', 'ld', 'plane', 'uniform')
 
     def __init__(self, rows, cols, dev, zero=True):
         self.rows, self.cols, self.ld = rows, cols, r64(cols)
+        self.uniform = False         # ONE scale for the whole tensor (the convolution operands: set by their producers)
         # padding columns must hold zeros (0 x garbage may be NaN): zero-filled once when there are any -- unless the
         # producer writes the padding itself (zero=False: the channel-LayerNorm and uniform-split kernels do)
         mk = torch.zeros if (self.ld != cols and zero) else torch.empty

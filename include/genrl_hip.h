@@ -130,6 +130,30 @@ int genrl_gru_scan_coop(float* pre, const float* Wh, long ldw, const float* gamm
 int genrl_gemm_h2_conv(const uint16_t* img, long ld_img, long plane_img, const float* img_inv, int Nimg, int H, int W, int Cc, int k,
                        const uint16_t* b, long b_ld, long b_plane, const float* b_inv, float* C, long ldc, const float* bias, int N,
                        int accumulate, void* stream);
+/* Gather ("sub-pixel") form of a stride-2 transposed convolution with an even kernel k = 2T -- nn.ConvTranspose2d(k, 2) forward
+ * (agent/dreamer_utils.py:686-706) and, with the channel roles swapped, the input gradient of nn.Conv2d(k, 2) (:590-612): all four
+ * output parity classes (a, b) read the SAME T x T patch of the zero-padded input, so ONE product with rows (image, py, px) and
+ * columns (a, b, co) does the layer and the epilogue writes straight to out[n][2 py + a][2 px + b][co] (no cols matrix, no col2im):
+ *   out[n][2 py + a][2 px + b][co] = bias[(a, b, co)] + sum_{u, v, c} img[n][py + u][px + v][c] * B[(a, b, co)][(u, v, c)]
+ * img: UNIFORM-scale planes of the input zero-padded by T - 1 pixels on every side, [Nimg][Hp][Wp][ld_img] (genrl_pad_planes);
+ * B: planes [4 Co][b_ld] of the rearranged weight (genrl_subpixel_weight), b_ld = T T Cc rounded up to 64; bias: 4 Co floats or NULL.
+ * out: fp32 NHWC [Nimg][Ho][Wo][Co]; positions beyond Ho / Wo are dropped, positions no patch reaches are not written.
+ * Cc % 8 == 0, Cc >= 48, Co % 4 == 0, out and bias 16-byte aligned. */
+int genrl_gemm_h2_subpixel(const uint16_t* img, long ld_img, long plane_img, const float* img_inv, int Nimg, int Hp, int Wp, int Cc, int T,
+                           const uint16_t* b, long b_ld, long b_plane, const float* b_inv, float* out, int Ho, int Wo, int Co,
+                           const float* bias, void* stream);
+/* Zero-padded copy of NHWC planes: dst[p][n][y + pad][x + pad][:ld] = src[p][n][y][x][:ld], the border pixels zero (both planes);
+ * dinv[0 .. Nimg (H + 2 pad)(W + 2 pad)) = sinv[0] (uniform scale).  ld % 8 == 0. */
+int genrl_pad_planes(const uint16_t* src, long splane, const float* sinv, uint16_t* dst, long dplane, float* dinv, int Nimg, int H, int W,
+                     long ld, int pad, void* stream);
+/* The rearranged weight of genrl_gemm_h2_subpixel as an fp32 matrix [4 Co][T T Ci] (+ the bias repeated per class, 4 Co floats, if
+ * bias4 != NULL):  Wsub[(a, b, co)][(u, v, ci)] = w(ci, co, a + 2 (T - 1 - u), b + 2 (T - 1 - v)), zero where a tap index reaches k
+ * (odd k: the kernel is treated as k + 1 with a zero last tap).  w(ci, co, kh, kw) = W[ci s_ci + co s_co + (kh k + kw) s_tap]:
+ * nn.ConvTranspose2d's (Ci, Co, k, k) layout has (s_ci, s_co, s_tap) = (Co k k, k k, 1), its channel-last permutation (ci, kh, kw, co)
+ * (k k Co, 1, Co); for the input gradient of nn.Conv2d -- summed channel = Cout, produced channel = Cin -- pass Ci := Cout, Co := Cin
+ * and the strides of (cout, cin) in the weight's storage. */
+int genrl_subpixel_weight(const float* W, long s_ci, long s_co, long s_tap, int Ci, int Co, int k, int T, float* Wsub, const float* bias,
+                          float* bias4, void* stream);
 /* Weight-gradient product on the SAME planes (csrc/gemm_planes_tn.hip):  C[i, j] (+)= sum_m A(m, i) B(m, j) for h2 planes
  * A [2][M][a_ld] (columns i < NI) and B [2][M][b_ld] (columns j < NJ) with per-row inverse scales a_inv[M], b_inv[M] -- dW = dY^T X
  * (agent/dreamer_utils.py:739-747 backward) read against the planes' storage order through the transposing LDS read

@@ -95,3 +95,50 @@ def test_uniform_planes_of_the_channel_layernorm():
     U = cp._uniform_split(x)
     assert (U.inv == U.inv[0]).all() and float(x.abs().max()) / float(U.inv[0]) < 2 ** 15 and float(x.abs().max()) / float(U.inv[0]) >= 2 ** 14
     assert ((U.float() - x).abs() <= 2.0 ** -22 * x.abs() + 2.0 ** -37 * float(x.abs().max())).all()
+
+
+@pytest.mark.parametrize('N,Hi,Wi,Ci,Co,k', [(4, 13, 13, 96, 48, 6), (2, 5, 7, 192, 96, 6), (3, 5, 5, 192, 96, 5), (64, 13, 13, 96, 48, 6),
+                                             (2, 6, 6, 48, 4, 4), (1, 3, 2, 56, 12, 2)])
+def test_subpixel_gather_form_of_the_transposed_convolution(N, Hi, Wi, Ci, Co, k):
+    """genrl_gemm_h2_subpixel (+ genrl_pad_planes, genrl_subpixel_weight): ConvTranspose2d(k, stride 2) forward as ONE product over
+    the T x T patches of the zero-padded input with the pixel-shuffle epilogue, against torch in float64 -- even kernels, an odd one
+    (k = 5 as 6 with a zero tap: the last output row / column is dropped), non-square images, channel counts off the tile sizes"""
+    from genrl_amd import ops_conv_planes as cp
+    x = torch.randn(N, Hi, Wi, Ci, generator=g(1))
+    W = torch.randn(Ci, Co, k, k, generator=g(2)) / (Ci * k) ** .5
+    b = 0.1 * torch.randn(Co, generator=g(3))
+    ref = F.conv_transpose2d(x.double().permute(0, 3, 1, 2), W.double(), b.double(), stride=2).permute(0, 2, 3, 1)
+    xd = x.cuda()
+    xp = cp._uniform_split(xd.reshape(-1, Ci))
+    Wp = W.permute(0, 2, 3, 1).contiguous().cuda()                     # (ci, kh, kw, co)
+    Ho, Wo = 2 * (Hi - 1) + k, 2 * (Wi - 1) + k
+    out = torch.full((N, Ho, Wo, Co), float('nan'), device='cuda')
+    cp._subpixel(xp, N, Hi, Wi, Ci, Co, k, Wp, k * k * Co, 1, Co, b.cuda(), out)
+    err = (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err
+    # the original (Ci, Co, k, k) layout through its own strides, no bias
+    out2 = torch.empty_like(out)
+    cp._subpixel(xp, N, Hi, Wi, Ci, Co, k, W.cuda(), Co * k * k, k * k, 1, None, out2)
+    assert torch.equal(out2, out - b.cuda())  or (out2 - (out - b.cuda())).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize('N,Hi,Ci,Co,k', [(4, 31, 48, 96, 4), (8, 14, 96, 192, 4), (2, 6, 192, 384, 4), (2, 30, 48, 96, 4)])
+def test_subpixel_gather_form_of_the_convolution_input_gradient(N, Hi, Ci, Co, k):
+    """the same product with the channel roles swapped = the input gradient of Conv2d(k, stride 2): against autograd in float64;
+    Hi = 31: the last input row / column is reached by no patch and must come back as zeros"""
+    from genrl_amd import ops_conv_planes as cp
+    x = torch.randn(N, Ci, Hi, Hi, generator=g(1)).double().requires_grad_(True)
+    W = torch.randn(Co, Ci, k, k, generator=g(2)) / (Ci * k * k) ** .5
+    y = F.conv2d(x, W.double(), None, stride=2)
+    dy = torch.randn(y.shape, generator=g(3))
+    y.backward(dy.double())
+    ref = x.grad.permute(0, 2, 3, 1)
+    Ho = y.shape[2]
+    dyp = cp._uniform_split(dy.permute(0, 2, 3, 1).contiguous().cuda().reshape(-1, Co))
+    Wp = W.permute(0, 2, 3, 1).contiguous().cuda()                     # (co, kh, kw, ci)
+    T = k // 2
+    full = Hi <= 2 * (Ho + T - 1)
+    dx = (torch.empty if full else torch.zeros)(N, Hi, Hi, Ci, device='cuda')
+    cp._subpixel(dyp, N, Ho, Ho, Co, Ci, k, Wp, k * k * Ci, 1, Ci, None, dx)
+    err = (dx.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err

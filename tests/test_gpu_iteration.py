@@ -137,6 +137,7 @@ def test_tiny_optimizer_step_vs_reference():
     g, ocfg, p, batch, noise, ag, outputs, mets_wm, mets, grads = run_product('tiny_opt.npz', False, config.tiny_overrides(), tiny_o)
     check_vs_golden(g, mets_wm, mets, 1e-3)
     sd = ag.state_dict()
+    trained = {n for n, _ in ag.named_parameters()}
     bad, worst = 0, 0.0
     for key, val in g.items():
         if key.startswith('psum.'):
@@ -149,6 +150,8 @@ def test_tiny_optimizer_step_vs_reference():
             # SURVEY 8(c)'s elementwise bound, for THIS test too: one Adam step moves an element by <= lr (m / sqrt(v) = +-1 on the
             # first step) plus weight decay, so a parameter may differ from the reference's updated one by at most 2 lr per step
             # taken -- the connector's group steps twice per iteration (Q1)
+            if name not in trained:                      # (buffers -- the return-quantile EMA -- are not optimiser state)
+                continue
             lr = ag.cfg.model_opt.lr if name.startswith('wm.') else ag.cfg.actor_opt.lr
             nstep = 2 if name.startswith('wm.connector') else 1
             worst = max(worst, d.abs().max().item() / (lr * nstep))
@@ -164,8 +167,9 @@ def test_tiny_optimizer_step_vs_reference():
 
 # tolerances of the full-width c1 case = ~2x the values measured on MI355X with plane operands forced on at every size
 # (profiles/r04_parity_measured.txt): sampled-latent mismatches and the worst relative error of a per-tensor gradient L2 norm
-C1_MAX_IDX_MISMATCH = 5e-4
-C1_GRAD_L2_RTOL = 1e-3
+# measured (round 4): 0 mismatching samples of 65 536; worst gradient-norm error 4.9e-7
+C1_MAX_IDX_MISMATCH = 5e-5          # (three samples)
+C1_GRAD_L2_RTOL = 5e-6
 
 
 @pytest.mark.parametrize('overlap', [False, True])
