@@ -1288,7 +1288,8 @@ int genrl_gemm_h2_conv(const uint16_t* img, long ld_img, long plane_img, const f
   GENRL_ENTER();
   const int Ho = (H - k) / 2 + 1, Wo = (W - k) / 2 + 1, K = k * k * Cc;
   const long Ml = (long)Nimg * Ho * Wo;
-  if (Nimg <= 0 || Ho <= 0 || Wo <= 0 || N <= 0 || (Cc & 7) || Cc < 48 || ld_img < Cc || (ld_img & 7) || (b_ld & 63) || b_ld < K || b_ld >= K + 64 ||
+  /* (K >= 64: every chunk of the first stage lies inside the patch -- the gather's run-off rule only covers LATER stages) */
+  if (Nimg <= 0 || Ho <= 0 || Wo <= 0 || N <= 0 || (Cc & 7) || Cc < 48 || ld_img < Cc || (ld_img & 7) || (b_ld & 63) || b_ld < K || b_ld >= K + 64 || K < 64 ||
       !img_inv || !b_inv || Ml > 0x7fffffffL)
     return GENRL_EINVAL;
   if ((((long)Nimg * H * W * ld_img + plane_img) * 2) >= 0xffffffffL) return GENRL_EINVAL;     // (32-bit byte offsets in the gather)
@@ -1323,7 +1324,7 @@ int genrl_gemm_h2_subpixel(const uint16_t* img, long ld_img, long plane_img, con
   const int Hq = Hp - T + 1, Wq = Wp - T + 1, K = T * T * Cc, N = 4 * Co;
   const long Ml = (long)Nimg * Hq * Wq;
   if (Nimg <= 0 || T < 1 || Hq <= 0 || Wq <= 0 || Co <= 0 || (Co & 3) || (Cc & 7) || Cc < 48 || ld_img < Cc || (ld_img & 7) || (b_ld & 63) ||
-      b_ld < K || b_ld >= K + 64 || !img_inv || !b_inv || Ml > 0x7fffffffL || Ho <= 0 || Wo <= 0 || (reinterpret_cast<uintptr_t>(out) & 15) ||
+      b_ld < K || b_ld >= K + 64 || K < 64 || !img_inv || !b_inv || Ml > 0x7fffffffL || Ho <= 0 || Wo <= 0 || (reinterpret_cast<uintptr_t>(out) & 15) ||
       (reinterpret_cast<uintptr_t>(bias) & 15))
     return GENRL_EINVAL;
   if ((((long)Nimg * Hp * Wp * ld_img + plane_img) * 2) >= 0xffffffffL) return GENRL_EINVAL;     // (32-bit byte offsets in the gather)

@@ -114,7 +114,17 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_tn_kernel(TnArgs g) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
 
   const int ntiles = g.tiles_i * g.tiles_j;
-  const int split = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
+  // XCD-aware order (round 4): workgroup b runs on XCD b % 8, and each XCD has its own L2.  With split = b / ntiles the 32 workgroups of
+  // an XCD (1024 x 1024 x 16384: 64 tiles x 4 splits) were the tiles (i = 0..7, j = x) of ALL splits -- 32 different A panels + 4 B
+  // panels fetched into that L2, 568 MB read per launch against 134 MB of operands (profiles/r03_pmc.txt).  Now every XCD takes a
+  // CONTIGUOUS range of the split-major work list: 32 consecutive tiles of one split = 4 A panels + 8 B panels.  Only the placement
+  // changes; every partial tile still lands in its own slot, so the result is bit-identical.
+  int L;
+  {
+    const int total = gridDim.x, x = blockIdx.x % 8, r = blockIdx.x / 8, q = total / 8, rem = total % 8;
+    L = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + r;
+  }
+  const int split = L / ntiles, tile = L % ntiles;
   const int i0 = (tile / g.tiles_j) * 128, j0 = (tile % g.tiles_j) * 128;
   const int st0 = split * g.stages_per_split;
   const int nk = min(g.stages_per_split, g.M / BK - st0);

@@ -158,7 +158,7 @@ def subpixel_ok(xp, Nimg, Hi, Wi, Cs, Cp, k):
     channels, Cp produced channels, k the stride-2 kernel"""
     T = (k + 1) // 2
     return (SUBPIXEL and _hl_on() and xp is not None and xp.uniform and (k % 2 == 0 or SUBPIXEL_ODD) and Cs % 8 == 0 and Cs >= 48 and Cp % 4 == 0
-            and xp.cols == Cs and Nimg * (Hi + T - 1) * (Wi + T - 1) >= min_rows() // 4)
+            and xp.cols == Cs and T * T * Cs >= 64 and Nimg * (Hi + T - 1) * (Wi + T - 1) >= min_rows() // 4)
 
 
 def _subpixel(xp, Nimg, Hi, Wi, Cs, Cp, k, Wsrc, s_ci, s_co, s_tap, bias, out):

@@ -98,7 +98,7 @@ def test_uniform_planes_of_the_channel_layernorm():
 
 
 @pytest.mark.parametrize('N,Hi,Wi,Ci,Co,k', [(4, 13, 13, 96, 48, 6), (2, 5, 7, 192, 96, 6), (3, 5, 5, 192, 96, 5), (64, 13, 13, 96, 48, 6),
-                                             (2, 6, 6, 48, 4, 4), (1, 3, 2, 56, 12, 2)])
+                                             (2, 6, 6, 48, 4, 4), (1, 3, 2, 64, 12, 2)])
 def test_subpixel_gather_form_of_the_transposed_convolution(N, Hi, Wi, Ci, Co, k):
     """genrl_gemm_h2_subpixel (+ genrl_pad_planes, genrl_subpixel_weight): ConvTranspose2d(k, stride 2) forward as ONE product over
     the T x T patches of the zero-padded input with the pixel-shuffle epilogue, against torch in float64 -- even kernels, an odd one

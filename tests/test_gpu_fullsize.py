@@ -30,13 +30,14 @@ def _check_metrics(mets, om, min_checked):
     assert n >= min_checked, (n, sorted(set(mets) & set(om)))
 
 
-def test_c4_kitchen_128px_full_width_vs_oracle():
+@pytest.mark.parametrize('B,T', [(8, 16), (32, 32)])
+def test_c4_kitchen_128px_full_width_vs_oracle(B, T):
     """configs[3]: 128x128 frames, five-layer encoder / decoder at cnn_depth 48 (48..768 channels, E = 3072), A = 9,
-    default 1024-wide RSSM / heads; B8 x T16."""
+    default 1024-wide RSSM / heads; B8 x T16 and the config's FULL size B32 x T32 (the CPU oracle needs ~15 s for that one)."""
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     over = dict(encoder=dict(cnn_kernels=[4, 4, 4, 4, 4]), decoder=dict(cnn_kernels=[5, 5, 5, 6, 6]))
     oc = dict(img=128, enc_kernels=(4, 4, 4, 4, 4), dec_kernels=(5, 5, 5, 6, 6))
-    meta = {'meta': (8, 16, 9, 32, 32, 16, 4), 'img': 128}
+    meta = {'meta': (B, T, 9, 32, 32, 16, 4), 'img': 128}
     g, ocfg, p, batch, noise, ag, outputs, mets_wm, mets, grads = run_product(meta, True, over, oc)
     assert outputs['embed'].shape[-1] == 3072
     res = run_iteration(p, ocfg, batch, noise, FakeClip().get_txt_feat(''), apply_updates=False)
@@ -47,14 +48,15 @@ def test_c4_kitchen_128px_full_width_vs_oracle():
         np.testing.assert_allclose(_phase_norm(grads[ph]), _phase_norm(res['grads'][ph]), rtol=1e-3, err_msg=ph)
 
 
-def test_c3_dreamer_v3_512_units_vs_oracle():
+@pytest.mark.parametrize('T', [48, 50])
+def test_c3_dreamer_v3_512_units_vs_oracle(T):
     """configs[2] at its widths: DreamerAgent with dreamer_v3.yaml (deter = hidden = units = 512, posterior from
     [deter, embed], decoder on feat, trained reward head, env_reward, actor entropy 3e-4, horizon 15), walker A = 6,
-    T = 48 (not a GenRL length); B8."""
+    T = 48 and the config's own T = 50 (no multiple of 8: not a GenRL length); B8 = the per-GPU batch of its DP-8 layout."""
     from genrl_amd import config, noise as gnoise
     from genrl_amd.agent import dreamer_utils as common
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    B, T, A, S, K, H, seed = 8, 48, 6, 32, 32, 15, 6
+    B, A, S, K, H, seed = 8, 6, 32, 32, 15, 6
     zero = dict(lr=0.0, wd=0.0)
     cfg = config.dreamer_cfg(B, T, device='cuda', model_opt=zero, actor_opt=zero, critic_opt=zero)
     ag = config.make_dreamer_agent(cfg, act_dim=A)
