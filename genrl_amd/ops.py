@@ -1250,7 +1250,9 @@ class _PermuteWeight(Function):
     def forward(ctx, W):
         A, B, k, _ = W.shape
         ctx.W = W
-        return transpose_last2_raw(W.detach().reshape(A, B, k * k))
+        # (cached per optimiser step: the encoder / decoder weights are permuted once, not once per call -- planes.derived)
+        from . import planes
+        return planes.derived(W, 'perm', lambda: transpose_last2_raw(W.detach().reshape(A, B, k * k))).detach()
 
     @staticmethod
     def backward(ctx, g):

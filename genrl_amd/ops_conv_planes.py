@@ -161,7 +161,7 @@ def subpixel_ok(xp, Nimg, Hi, Wi, Cs, Cp, k):
             and xp.cols == Cs and T * T * Cs >= 64 and Nimg * (Hi + T - 1) * (Wi + T - 1) >= min_rows() // 4)
 
 
-def _subpixel(xp, Nimg, Hi, Wi, Cs, Cp, k, Wsrc, s_ci, s_co, s_tap, bias, out):
+def _subpixel(xp, Nimg, Hi, Wi, Cs, Cp, k, Wsrc, s_ci, s_co, s_tap, bias, out, wkey=None):
     """out[n][2 py + a][2 px + b][cp] = bias[cp] + sum over the T x T patch of the zero-padded input and the Cs summed channels
     (genrl_gemm_h2_subpixel); out: fp32 NHWC (Nimg, Ho, Wo, Cp), fully written when Ho <= 2 (Hi + T - 1) (the caller zero-fills otherwise)"""
     T = (k + 1) // 2
@@ -175,16 +175,27 @@ def _subpixel(xp, Nimg, Hi, Wi, Cs, Cp, k, Wsrc, s_ci, s_co, s_tap, bias, out):
     check(lib().genrl_pad_planes(xp.ptr(), xp.plane, xp.inv_ptr(), xq.ptr(), xq.plane, xq.inv_ptr(), Nimg, Hi, Wi, xp.ld, pad, _stream()),
           'pad_planes')
     K = T * T * Cs
-    wsub = torch.empty(4 * Cp, K, device=dev)
-    b4 = torch.empty(4 * Cp, device=dev) if bias is not None else None
-    check(lib().genrl_subpixel_weight(_p(Wsrc), s_ci, s_co, s_tap, Cs, Cp, k, T, _p(wsub), _p(bias), _p(b4), _stream()), 'subpixel_weight')
-    wp = planes.split(wsub)
+
+    def build():
+        wsub = torch.empty(4 * Cp, K, device=dev)
+        b4_ = torch.empty(4 * Cp, device=dev) if bias is not None else None
+        check(lib().genrl_subpixel_weight(_p(Wsrc), s_ci, s_co, s_tap, Cs, Cp, k, T, _p(wsub), _p(bias), _p(b4_), _stream()), 'subpixel_weight')
+        return planes.split(wsub), b4_
+    # (once per optimiser step when the caller names the parameter the weight comes from; weight and bias are stepped together)
+    wp, b4 = planes.derived(wkey, ('subpixel', bias is not None), build) if wkey is not None else build()
     _, Ho, Wo, _ = out.shape
     check(lib().genrl_gemm_h2_subpixel(xq.ptr(), xq.ld, xq.plane, xq.inv_ptr(), Nimg, Hp, Wp, Cs, T, wp.ptr(), wp.ld, wp.plane, wp.inv_ptr(),
                                        _p(out), Ho, Wo, Cp, _p(b4), _stream()), 'gemm_h2_subpixel')
     if planes.gemm_profile is not None:
         e1 = torch.cuda.Event(enable_timing=True); e1.record()
         planes.gemm_profile.append((Nimg * (Hp - T + 1) * (Wp - T + 1), 4 * Cp, K, e0, e1, 'kk/subpixel/h2/pipe4'))
+
+
+def _wplanes(wsrc, Wp, transpose):
+    """planes of the permuted weight matrix Wp (or of its transpose): once per optimiser step when the parameter it comes from is known"""
+    if wsrc is None:
+        return planes.split(Wp.detach(), transpose=transpose)
+    return planes.derived(wsrc, ('perm_planes', transpose), lambda: planes.split(Wp.detach(), transpose=transpose))
 
 
 KR_MIN_K = int(os.environ.get('GENRL_PLANES_KR_MIN_K', '512'))      # GEMM -> col2im products: with few input channels (K = C) a 128 x 128 tile is two K stages of prologue and a
@@ -199,7 +210,8 @@ class _Conv2dS2P(Function):
     """ops._Conv2dS2 with plane products.  x: f32 NHWC (N,H,W,C) [xp: its uniform planes or None] or u8 NCHW frames;
     Wp (Co, k*k*Ci) = weight permuted to (co, kh, kw, ci); channel-LayerNorm + SiLU fused; returns NHWC with ._planes set."""
     @staticmethod
-    def forward(ctx, x, Wp, b, k, gamma, beta, eps, xp, holder):
+    def forward(ctx, x, Wp, b, k, gamma, beta, eps, xp, holder, wsrc=(None,)):
+        ctx.wsrc = wsrc[0]
         u8 = x.dtype == torch.uint8
         x = x.contiguous()
         if u8:
@@ -212,7 +224,7 @@ class _Conv2dS2P(Function):
         y = torch.empty(M, Co, device=x.device)
         on_planes = (not u8) and xp is not None and _gather_ok(M, C)
         if on_planes:
-            _gemm_conv(xp, Nimg, Hi, Wi, C, k, planes.split(Wp.detach()), y, Co, b, Co)
+            _gemm_conv(xp, Nimg, Hi, Wi, C, k, _wplanes(ctx.wsrc, Wp, False), y, Co, b, Co)
         elif ops._implicit_conv(x, C):
             sgemm_conv(x, K, 1, Wp, K, 1, y, Co, b, M, Co, K, 1, (Hi, Wi, C, k))
         else:
@@ -257,22 +269,23 @@ class _Conv2dS2P(Function):
             T = (k + 1) // 2
             full = Hi <= 2 * (Ho + T - 1) and Wi <= 2 * (Wo + T - 1)        # (an odd input size leaves its last row / column without a patch)
             dx = (torch.empty if full else torch.zeros)(Nimg, Hi, Wi, C, device=dy.device)
-            _subpixel(dyp, Nimg, Ho, Wo, Co, C, k, Wp, K, 1, C, None, dx)      # Wp = (co, kh, kw, ci): strides of (co, ci, tap) = (K, 1, C)
+            _subpixel(dyp, Nimg, Ho, Wo, Co, C, k, Wp, K, 1, C, None, dx, wkey=ctx.wsrc)      # Wp = (co, kh, kw, ci): strides of (co, ci, tap) = (K, 1, C)
         elif need_dx:
             dcols = torch.empty(M, K, device=dy.device)
             if kr and dyp is not None:
-                planes.gemm(dyp, planes.split(Wp.detach(), transpose=True), dcols, K, None, M, K)      # dcols = dy W
+                planes.gemm(dyp, _wplanes(ctx.wsrc, Wp, True), dcols, K, None, M, K)      # dcols = dy W
             else:
                 sgemm(dy2, Co, 1, Wp, 1, K, dcols, K, None, M, K, Co)
             dx = ops._col2im(dcols, None, Nimg, Ho, Wo, C, k, Hi, Wi)
-        return dx, dW, db, None, dg, dbe, None, None, None
+        return dx, dW, db, None, dg, dbe, None, None, None, None
 
 
 class _ConvT2dS2P(Function):
     """ops._ConvT2dS2 (with the fused channel-LayerNorm + SiLU) with plane products.  x NHWC (N,Hi,Wi,Ci), xp: planes of its rows
     (uniform or per-row scales) or None; Wp (Ci, k*k*Co) = weight permuted to (ci, kh, kw, co)."""
     @staticmethod
-    def forward(ctx, x, Wp, b, k, gamma, beta, eps, xp, holder):
+    def forward(ctx, x, Wp, b, k, gamma, beta, eps, xp, holder, wsrc=(None,)):
+        ctx.wsrc = wsrc[0]
         x = _f32(x).contiguous()
         Nimg, Hi, Wi, Ci = x.shape
         Nw = Wp.shape[1]
@@ -284,11 +297,11 @@ class _ConvT2dS2P(Function):
         if on_planes and Hi > 1 and subpixel_ok(xp, Nimg, Hi, Wi, Ci, Co, k):
             # gather form: every output pixel sums its T x T patch of the zero-padded input -- no cols matrix, no col2im
             y = torch.empty(Nimg, 2 * (Hi - 1) + k, 2 * (Wi - 1) + k, Co, device=x.device)
-            _subpixel(xp, Nimg, Hi, Wi, Ci, Co, k, Wp, Nw, 1, Co, b, y)         # Wp = (ci, kh, kw, co): strides of (ci, co, tap) = (Nw, 1, Co)
+            _subpixel(xp, Nimg, Hi, Wi, Ci, Co, k, Wp, Nw, 1, Co, b, y, wkey=ctx.wsrc)         # Wp = (ci, kh, kw, co): strides of (ci, co, tap) = (Nw, 1, Co)
         else:
             cols = torch.empty(M, Nw, device=x.device)
             if on_planes and Ci >= KR_MIN_K:
-                planes.gemm(xp, planes.split(Wp.detach(), transpose=True), cols, Nw, None, M, Nw)      # cols = x W
+                planes.gemm(xp, _wplanes(ctx.wsrc, Wp, True), cols, Nw, None, M, Nw)      # cols = x W
             else:
                 sgemm(x, Ci, 1, Wp, 1, Nw, cols, Nw, None, M, Nw, Ci)
             y = ops._col2im(cols, b, Nimg, Hi, Wi, Co, k)
@@ -321,7 +334,7 @@ class _ConvT2dS2P(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, Ci, device=dy.device)
             if dgr and dyp is not None:
-                _gemm_conv(dyp, Nimg, Ho, Wo, Co, k, planes.split(Wp.detach()), dx, Ci, None, Ci)      # dx = patches(dy) W^T
+                _gemm_conv(dyp, Nimg, Ho, Wo, Co, k, _wplanes(ctx.wsrc, Wp, False), dx, Ci, None, Ci)      # dx = patches(dy) W^T
             elif implicit:
                 sgemm_conv(dyv, Nw, 1, Wp, Nw, 1, dx, Ci, None, M, Ci, Nw, 1, (Ho, Wo, Co, k))
             else:
@@ -338,7 +351,7 @@ class _ConvT2dS2P(Function):
                 if dcols is None:
                     dcols = ops._im2col(dyv, Nimg, Ho, Wo, Co, k, 0)
                 sgemm(x, 1, Ci, dcols, 1, Nw, dW, Nw, None, Ci, Nw, M)
-        return dx, dW, db, None, dg, dbe, None, None, None
+        return dx, dW, db, None, dg, dbe, None, None, None, None
 
 
 def conv2d_s2(x, W, b, ln):
@@ -347,7 +360,7 @@ def conv2d_s2(x, W, b, ln):
     Co, Ci, k, _ = W.shape
     Wp = ops._PermuteWeight.apply(W).reshape(Co, k * k * Ci)
     holder = []
-    y = _Conv2dS2P.apply(x, Wp, b, k, ln[0], ln[1], float(ln[2]), getattr(x, '_planes', None), holder)
+    y = _Conv2dS2P.apply(x, Wp, b, k, ln[0], ln[1], float(ln[2]), getattr(x, '_planes', None), holder, (W,))
     y._planes = holder[0] if holder else None
     return y
 
@@ -356,6 +369,6 @@ def convT2d_s2(x, W, b, ln):
     Ci, Co, k, _ = W.shape
     Wp = ops._PermuteWeight.apply(W).reshape(Ci, k * k * Co)
     holder = []
-    y = _ConvT2dS2P.apply(x, Wp, b, k, ln[0], ln[1], float(ln[2]), getattr(x, '_planes', None), holder)
+    y = _ConvT2dS2P.apply(x, Wp, b, k, ln[0], ln[1], float(ln[2]), getattr(x, '_planes', None), holder, (W,))
     y._planes = holder[0] if holder else None
     return y

@@ -80,6 +80,25 @@ class _Desc(ctypes.Structure):          # genrl_split_desc (include/genrl_hip.h)
                 ('transpose', ctypes.c_int)]
 
 
+_dcache = {}             # (id(W), tag) -> [epoch, object derived from W, W.data_ptr(), weakref(W), stream that built it]
+
+
+def derived(W, tag, build):
+    """build() -- something computed from the parameter W alone (a permuted copy, planes of a rearrangement) -- cached until W is
+    invalidated (optimiser step, slow-target copy, load_state_dict: `invalidate`), rebuilt at the first use after that on the stream
+    that uses it; a use on another stream than the one that built it rebuilds too (no cross-stream ordering is assumed).  Inside a
+    captured iteration everything is stale at the capture's start, so every replay rebuilds at the same place."""
+    if not isinstance(W, torch.nn.Parameter):
+        return build()
+    key, st = (id(W), tag), _stream()
+    ent = _dcache.get(key)
+    if ent is None or ent[0] != _epoch or ent[2] != W.data_ptr() or ent[3]() is not W or ent[4] != st:
+        if ent is None:
+            weakref.finalize(W, _dcache.pop, key, None)
+        ent = _dcache[key] = [_epoch, build(), W.data_ptr(), weakref.ref(W), st]
+    return ent[1]
+
+
 def invalidate(params=None):
     """some parameters changed (optimiser step, slow-target copy, load_state_dict): their cached planes are stale.
     params: the tensors that changed (None: everything)"""
@@ -89,6 +108,9 @@ def invalidate(params=None):
         return
     ids = {id(q) for q in params}
     for key, ent in _wcache.items():
+        if key[0] in ids:
+            ent[0] = -1
+    for key, ent in _dcache.items():
         if key[0] in ids:
             ent[0] = -1
 
