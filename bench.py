@@ -471,8 +471,8 @@ def main():
                          'the fp16 planes (operand representation 2^-23 relative; profiles/*planes_bench*), at or below theirs for '
                          'the exact 3-term bf16 split; GENRL_GEMM_MODE=0 GENRL_PLANES=0 = fp32 MFMAs throughout, timed beside as '
                          'fp32_mfma_mode)') if args.precision == 32
-               else 'precision-16 variant: bf16-rounded MFMA operands in the fp32-operand kernels, f32 accumulate and storage; the '
-                    'products that run on fp16 planes (rollout, Dense+LN+SiLU chains from 512 rows up) keep fp32-grade arithmetic',
+               else 'precision-16 mode: EVERY matrix product rounds both operands to bf16 (nearest even), f32 accumulation and storage '
+                    '(oracle-pinned: tests/test_gpu_iteration.py::test_precision16_vs_the_oracles_bf16_operand_mode; NOT the fp32 headline)',
                'data': 'synthetic (seeded uint8 64x64 RGB replay, random-init weights, stub text embedding); '
                        + ('fresh batch per step gathered on-GPU from a device-resident replay store' if replay is not None
                           else 'one fixed batch'),

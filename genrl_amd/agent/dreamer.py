@@ -74,6 +74,16 @@ class DreamerAgent(Module):
         """The GEMM arithmetic mode is process-wide in the library: every entry point of an agent (re)selects its own, so
         that two agents of different `precision` in one process do not change each other's arithmetic."""
         ops.set_gemm_precision('bf16' if self._use_amp else ops.F32_MODE)
+        # precision 16 is ONE arithmetic -- every matrix product rounds both operands to bf16 and accumulates in fp32 (what
+        # oracle/genrl_oracle.py restates as `bf16_operands`, tests/test_gpu_precision16.py) -- so the pre-split fp16-plane
+        # products (fp32-grade) are switched off while an agent of that precision runs, and back on for the next fp32 agent
+        from .. import planes
+        if self._use_amp:
+            if planes._amp_saved is None:
+                planes._amp_saved = planes.ENABLED
+            planes.ENABLED = False
+        elif planes._amp_saved is not None:
+            planes.ENABLED, planes._amp_saved = planes._amp_saved, None
 
     # ------------------------------------------------------------------ training entry points
     def update_wm(self, data, step):  # agent/dreamer.py:66-71

@@ -1588,7 +1588,11 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
   // of 32 give 256 workgroups and one launch where the 64x64 tiles need a K split + reduce launch (7.8 vs 11.0 us measured;
   // longer K or wider N favour the tiles again: scripts/small_m.py)
   const bool skinny_mid = M <= 128 && N <= 1024 && K <= 1024 && !getenv("GENRL_SKINNY_MAX_M");
-  if ((M <= skinny_max_m || skinny_mid) && a_ks == 1 && G == 0) {
+  // precision 16 (mode 1: EVERY product rounds both operands to bf16, fp32 accumulation -- the arithmetic oracle/genrl_oracle.py
+  // restates as `bf16_operands`): only sgemm_rr_kernel<BF = 1> implements it, so the weight-streaming and tall-stream kernels
+  // (fp32 MFMAs fed straight from memory) are bypassed and a product that misses sgemm_rr's alignment preconditions is refused
+  const bool p16 = g_gemm_bf16 == 1;
+  if (!p16 && (M <= skinny_max_m || skinny_mid) && a_ks == 1 && G == 0) {
     const bool b_kc = (b_ks == 1);
     const long b_ld = b_kc ? b_rs : b_ks;
     const int vec = ((a_rs & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
@@ -1609,7 +1613,7 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
   }
 #endif
   // tall stream with a register-resident B (see sgemm_tall_kernel)
-  if (G == 0 && a_ks == 1 && M >= 16384 && K <= 112 && K >= 4 && (K & 3) == 0 && (a_rs & 3) == 0 && (ldc & 3) == 0 &&
+  if (!p16 && G == 0 && a_ks == 1 && M >= 16384 && K <= 112 && K >= 4 && (K & 3) == 0 && (a_rs & 3) == 0 && (ldc & 3) == 0 &&
       ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(C)) & 15) == 0 && use_tall()) {
     const bool b_kc = (b_ks == 1);
     const long b_ld = b_kc ? b_rs : b_ks;
@@ -1647,6 +1651,8 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
       (rc = launch_rr<4>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, p.splits, (p.k_per_split + 63) / 64 * 64,
                          wsp, s, G, gp)) >= 0)
     ;
+  else if (p.big && p16)
+    return GENRL_EINVAL;      // (see above: no bf16-operand mode in the fallback kernel)
   else if (p.big)
     rc = launch_cfg<128, 128, GENRL_BIG_BK, GENRL_BIG_KG, GENRL_BIG_PD>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate,
                                                             p.splits, p.k_per_split, wsp, s, G, gp);
@@ -1655,6 +1661,8 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
     ;
   else if (trace_fallback(M, N, K, a_rs, a_ks, b_rs, b_ks, A, B), false)
     ;
+  else if (p16)
+    return GENRL_EINVAL;      // (the scalar-load fallback kernel has no bf16-operand mode: precision 16 needs 16-byte aligned operand lines)
   else if ((p.splits == 1 && (long)cdiv(M, 64) * cdiv(N, 64) >= GENRL_MID_TILES) || force_mid())
     // several 64x64 tiles per CU: 256-thread workgroups (one wave per SIMD each, 4+ resident per CU,
     // independent barriers) beat the single 1024-thread workgroup per CU by 10-13 % (measured)
@@ -1671,6 +1679,7 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
 }
 
 extern "C" int genrl_sgemm_last_pipe(void) { return g_last_pipe; }
+extern "C" int genrl_gemm_precision(void) { return g_gemm_bf16; }
 extern "C" int genrl_set_gemm_precision(int bf16 /* mode 0..3, see the header */) {
   const int prev = g_gemm_bf16;
   g_gemm_bf16 = (bf16 >= 1 && bf16 <= 3) ? bf16 : 0;

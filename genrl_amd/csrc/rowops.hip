@@ -458,6 +458,13 @@ __global__ void actor_head_fwd_rows_kernel(const float* __restrict__ raw, const 
   for (int a = 0; a < A; ++a) h2_store1(xo, r * xo.ld + a, action[r * ld_action + a], sc);
 }
 
+// fp32 -> nearest-even bf16 -> fp32 (finite inputs), componentwise
+__device__ __forceinline__ float bf16r(float x) {
+  const unsigned u = __builtin_bit_cast(unsigned, x);
+  return __builtin_bit_cast(float, (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u);
+}
+__device__ __forceinline__ float4 bf16r4(float4 v) { return make_float4(bf16r(v.x), bf16r(v.y), bf16r(v.z), bf16r(v.w)); }
+
 // The policy's output layer and its Normal head in one launch (out = Linear(U -> 2A), DistLayer 'normal' + rsample:
 // agent/dreamer_utils.py:798,814-819): one 256-thread workgroup per row, wave w owns the k-quarter w of the row (one float4 per
 // lane and 256 columns), so ALL 2A weight rows of its quarter are one batch of loads in flight; 2A wave reductions, the four
@@ -467,7 +474,8 @@ template <int MAXO>
 __global__ __launch_bounds__(256) void actor_head_linear_fwd_kernel(const float* __restrict__ y, long ldy, const float* __restrict__ W,
                                                                     const float* __restrict__ b, const float* __restrict__ eps,
                                                                     float* __restrict__ raw, float* __restrict__ action, long R, int U,
-                                                                    int A, float min_std, float max_std, long ld_action, PlaneOut xo) {
+                                                                    int A, float min_std, float max_std, long ld_action, PlaneOut xo,
+                                                                    int p16) {
   __shared__ float part[4][MAXO];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nv = U >> 2;
   const long row = blockIdx.x;
@@ -483,6 +491,11 @@ __global__ __launch_bounds__(256) void actor_head_linear_fwd_kernel(const float*
     float4 wv[MAXO];
 #pragma unroll
     for (int u = 0; u < MAXO; ++u) wv[u] = reinterpret_cast<const float4*>(W + (long)min(u, O - 1) * U)[jc];
+    if (p16) {          // precision 16: this product's operands are rounded to bf16 like every GEMM's (fp32 accumulation)
+      v = bf16r4(v);
+#pragma unroll
+      for (int u = 0; u < MAXO; ++u) wv[u] = bf16r4(wv[u]);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < MAXO; ++u) sacc[u] += v.x * wv[u].x + v.y * wv[u].y + v.z * wv[u].z + v.w * wv[u].w;
@@ -525,7 +538,7 @@ __global__ __launch_bounds__(256) void actor_head_linear_bwd_kernel(const float*
                                                                     const float* __restrict__ daction_up, long ld_action,
                                                                     const float* __restrict__ raw, const float* __restrict__ eps,
                                                                     float* __restrict__ draw, long R, int U, int A, float min_std,
-                                                                    float max_std) {
+                                                                    float max_std, int p16) {
   __shared__ float part[4][MAXO];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nv = U >> 2;
   const long row = blockIdx.x;
@@ -540,6 +553,11 @@ __global__ __launch_bounds__(256) void actor_head_linear_bwd_kernel(const float*
     float4 wv[MAXO];
 #pragma unroll
     for (int u = 0; u < MAXO; ++u) wv[u] = reinterpret_cast<const float4*>(WaT + (long)min(u, A - 1) * U)[jc];
+    if (p16) {
+      v = bf16r4(v);
+#pragma unroll
+      for (int u = 0; u < MAXO; ++u) wv[u] = bf16r4(wv[u]);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < MAXO; ++u) sacc[u] += v.x * wv[u].x + v.y * wv[u].y + v.z * wv[u].z + v.w * wv[u].w;
@@ -1654,7 +1672,7 @@ int genrl_actor_head_linear_fwd(const float* y, long ldy, const float* W, const 
   const long lda = ld_action > 0 ? ld_action : (long)A;
   const dim3 grid((unsigned)R), block(256);
   hipStream_t s = (hipStream_t)stream;
-#define GO(MO) hipLaunchKernelGGL((actor_head_linear_fwd_kernel<MO>), grid, block, 0, s, y, ldy, W, b, eps, raw, action, R, U, A, min_std, max_std, lda, xo)
+#define GO(MO) hipLaunchKernelGGL((actor_head_linear_fwd_kernel<MO>), grid, block, 0, s, y, ldy, W, b, eps, raw, action, R, U, A, min_std, max_std, lda, xo, (int)(genrl_gemm_precision() == 1))
   if (2 * A <= 12) GO(12); else if (2 * A <= 20) GO(20); else if (2 * A <= 32) GO(32); else GO(64);
 #undef GO
   GENRL_CHECK_LAUNCH();
@@ -1672,7 +1690,7 @@ int genrl_actor_head_linear_bwd(const float* dx, long lddx, const float* WaT, co
   if (((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(WaT)) & 15) != 0) return GENRL_EINVAL;
   const dim3 grid((unsigned)R), block(256);
   hipStream_t s = (hipStream_t)stream;
-#define GO(MO) hipLaunchKernelGGL((actor_head_linear_bwd_kernel<MO>), grid, block, 0, s, dx, lddx, WaT, daction_up, ld_action, raw, eps, draw, R, U, A, min_std, max_std)
+#define GO(MO) hipLaunchKernelGGL((actor_head_linear_bwd_kernel<MO>), grid, block, 0, s, dx, lddx, WaT, daction_up, ld_action, raw, eps, draw, R, U, A, min_std, max_std, (int)(genrl_gemm_precision() == 1))
   if (A <= 6) GO(6); else if (A <= 10) GO(10); else if (A <= 16) GO(16); else GO(32);
 #undef GO
   GENRL_CHECK_LAUNCH();

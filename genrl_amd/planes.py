@@ -14,6 +14,7 @@ import torch
 from ._lib import lib, check, GenrlHipError
 
 ENABLED = os.environ.get('GENRL_PLANES', '1') != '0'
+_amp_saved = None            # ENABLED as it was before a precision-16 agent switched the plane products off (agent/dreamer.py)
 gemm_profile = None          # bench.py: list of (M, N, K, start_event, end_event, tag)
 
 

@@ -42,6 +42,9 @@ int genrl_set_gemm_precision(int mode);
 /* matrix pipe the most recent genrl_sgemm / genrl_sgemm_conv launch ran on (measurement: bench.py prices each pipe against
  * its own peak): 0 fp32 MFMA, 1 bf16-rounded operands, 3 fp32 operands split into three bf16 terms (six bf16 MFMAs) */
 int genrl_sgemm_last_pipe(void);
+/* the mode genrl_set_gemm_precision last selected (the fused row kernels that contain a small matrix product -- the policy's
+ * output layer inside the Normal-head kernels -- round their operands to bf16 in mode 1 as well) */
+int genrl_gemm_precision(void);
 int genrl_sgemm(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks, float* C, long ldc,
                 const float* bias, int M, int N, int K, int accumulate, float* ws, long ws_floats, void* stream);
 

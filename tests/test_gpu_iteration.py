@@ -280,25 +280,53 @@ def test_c2_full_size_vs_oracle_and_determinism():
     assert mets_wm2 == mets_wm and mets2 == mets, 'HIP path is not run-to-run deterministic'
 
 
-def test_precision16_bf16_mode_tracks_fp32():
-    """cfg.precision = 16 (the reference's autocast mode; here: bf16 MFMA operands, fp32 accumulation and storage,
-    SURVEY 8f.4): one full-size-layer iteration at B4xT16 on the same weights / batch / injected noise must stay
-    within a few 1e-2 relative of the fp32 path's losses -- and must not be bit-identical to it (the mode is on).
-    Parity of this mode against the reference is NOT pinned: the reference's fp16 autocast only exists on CUDA."""
-    from genrl_amd import ops
+def _restore_fp32_arithmetic():
+    """precision 16 switches process-wide state (GEMM mode, plane products): put the suite's defaults back"""
+    from genrl_amd import ops, planes
+    ops.set_gemm_precision(ops.F32_MODE)
+    if planes._amp_saved is not None:
+        planes.ENABLED, planes._amp_saved = planes._amp_saved, None
+
+
+def test_precision16_vs_the_oracles_bf16_operand_mode():
+    """cfg.precision = 16.  The PRODUCT's definition: every matrix product -- Linear / GRU / conv / transposed conv,
+    forward, input gradient and weight gradient, the policy's output layer inside the head kernels included -- rounds both operands
+    to bf16 (nearest even) and accumulates in fp32; LayerNorm, softmax, losses, optimiser and all tensors stay fp32; no GradScaler
+    (bf16 has fp32's exponent range).  Pinned HERE against the oracle's restatement of exactly that arithmetic
+    (`O.bf16_operands()`) on a full-width B4 x T16 iteration: every metric within north_star's 1e-3, phase gradient norms within
+    1e-3, sampled latents equal up to near-ties.  NOT pinned against the reference: its precision-16 path (fp16 autocast +
+    GradScaler, agent/dreamer_utils.py:889-932) only runs on CUDA and could not be recorded -- "oracle-pinned, reference-unpinned"."""
+    from genrl_amd import ops, planes
     meta = {'meta': (4, 16, 10, 32, 32, 16, 5), 'img': 64}
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     try:
-        _, _, _, _, _, _, _, w32, m32, _ = run_product(meta, True, {}, {})
-        _, _, _, _, _, _, _, w16, m16, _ = run_product(meta, True, dict(precision=16), {})
+        g, ocfg, p, batch, noise, ag, outputs, w16, m16, grads = run_product(meta, True, dict(precision=16), {})
+        assert ops.set_gemm_precision('bf16') == 'bf16' and not planes.ENABLED        # the mode was on, the fp32-grade plane products off
     finally:
-        ops.set_gemm_precision('f32')
-    assert w16['model_loss'] != w32['model_loss']
+        _restore_fp32_arithmetic()
+    with O.bf16_operands():
+        res = run_iteration(p, ocfg, batch, noise, FakeClip().get_txt_feat(''), apply_updates=False)
+    om = {k: float(v) for k, v in res['metrics'].items()}
+    n, worst = 0, 0.0
+    for k, v in {**w16, **m16}.items():
+        if k in om and np.isfinite(om[k]):
+            np.testing.assert_allclose(v, om[k], rtol=1e-3, atol=1e-5, err_msg=k)
+            worst = max(worst, abs(v - om[k]) / max(abs(om[k]), 1e-5))
+            n += 1
+    assert n >= 20, n
+    measured('precision16.worst_metric_rel_vs_oracle', worst)
+    mism = (outputs['post']['stoch'].argmax(-1).cpu().numpy() != res['outs']['post']['stoch'].argmax(-1).numpy()).mean()
+    measured('precision16.post_idx_mismatch', mism)
+    assert mism < 2e-3, mism
+    for ph in ('wm', 'conn2', 'actor', 'critic'):
+        a = np.sqrt(sum(float((t.double() ** 2).sum()) for t in grads[ph].values()))
+        b = np.sqrt(sum(float((t.double() ** 2).sum()) for t in res['grads'][ph].values()))
+        np.testing.assert_allclose(a, b, rtol=1e-3, err_msg=ph)
+    # ... and it is a DIFFERENT arithmetic from the fp32 path (the mode is really on), within bf16's error of it
+    _, _, _, _, _, _, _, w32, m32, _ = run_product(meta, True, {}, {})
+    assert planes.ENABLED and w16['model_loss'] != w32['model_loss']
     for k in ('model_loss', 'observation_loss', 'reward_loss', 'kl_loss', 'model_kl'):
         np.testing.assert_allclose(w16[k], w32[k], rtol=3e-2, err_msg=k)
-    later = [k for k in m32 if k.endswith(('critic_loss', 'connector_kl', 'aligner_loss')) and np.isfinite(m32[k])]
-    assert later, sorted(m32)
-    for k in later:          # phases downstream of the (sampled) world-model state: looser
-        np.testing.assert_allclose(m16[k], m32[k], rtol=1e-1, atol=1e-3, err_msg=k)
 
 
 @pytest.mark.parametrize('mode,planes_on', [('f32', False), ('bf16x3', True), ('bf16x3-big', False)])

@@ -179,3 +179,41 @@ def test_c3_dreamer_agent_vs_reference():
         if key.startswith('gsum.'):
             _, ph, name = key.split('.', 2)
             np.testing.assert_allclose(summarize(res['grads'][ph][name], 4)[1:3], val[1:3], rtol=5e-4, atol=1e-5, err_msg=key)
+
+
+def test_bf16_operand_mode_of_the_oracle():
+    """`with O.bf16_operands()` (the product's `precision: 16` arithmetic: every matrix product rounds both operands to bf16,
+    fp32 accumulation; oracle-pinned only): the products are exactly the fp32 products of the rounded operands -- forward, input
+    gradient and weight gradient -- and a whole tiny iteration runs, stays finite and tracks the fp32 one within bf16's error."""
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 3, 24, generator=gen, requires_grad=True)
+    w = torch.randn(16, 24, generator=gen, requires_grad=True)
+    b = torch.randn(16, generator=gen, requires_grad=True)
+    dy = torch.randn(5, 3, 16, generator=gen)
+    r = lambda t: t.to(torch.bfloat16).float()
+    with O.bf16_operands():
+        y = O.F.linear(x, w, b)
+        y.backward(dy)
+    assert torch.equal(y.detach(), torch.nn.functional.linear(r(x), r(w), b).detach())
+    assert torch.allclose(x.grad, r(dy) @ r(w), rtol=0, atol=1e-6)
+    assert torch.allclose(w.grad, r(dy).reshape(-1, 16).t() @ r(x).reshape(-1, 24).detach(), rtol=0, atol=1e-5)
+    assert torch.allclose(b.grad, dy.reshape(-1, 16).sum(0), rtol=0, atol=1e-6)
+    for kind, shape_w in (('conv2d', (6, 4, 4, 4)), ('conv_transpose2d', (4, 6, 4, 4))):
+        xi = torch.randn(2, 4, 10, 10, generator=gen, requires_grad=True)
+        wi = torch.randn(*shape_w, generator=gen, requires_grad=True)
+        with O.bf16_operands():
+            yi = getattr(O.F, kind)(xi, wi, None, stride=2)
+        ref = getattr(torch.nn.functional, kind)(r(xi), r(wi), None, stride=2)
+        assert torch.equal(yi.detach(), ref.detach())
+        gy = torch.randn(yi.shape, generator=gen)
+        yi.backward(gy)
+        xr, wr = r(xi).detach().requires_grad_(True), r(wi).detach().requires_grad_(True)
+        gx, gw = torch.autograd.grad(getattr(torch.nn.functional, kind)(xr, wr, None, stride=2), (xr, wr), r(gy))
+        assert torch.equal(xi.grad, gx) and torch.equal(wi.grad, gw)
+    g, cfg, p, batch, noise, text = setup_case('tiny_iter.npz', deter=32, hidden=32, units=32, cnn_depth=4)
+    res32 = run_iteration(p, cfg, batch, noise, text, apply_updates=False)
+    with O.bf16_operands():
+        res16 = run_iteration(p, cfg, batch, noise, text, apply_updates=False)
+    assert not O._BF16_OPERANDS
+    a, b_ = float(res16['metrics']['model_loss']), float(res32['metrics']['model_loss'])
+    assert np.isfinite(a) and a != b_ and abs(a - b_) <= 3e-2 * abs(b_), (a, b_)
