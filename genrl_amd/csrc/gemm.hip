@@ -99,7 +99,13 @@ namespace {
 struct Gather {
   int seg_len, seg_stride, ow, ohw, sn, sy, sx;
   float inv_seg, inv_ow, inv_ohw;
+  int p16;        // sgemm_kernel only (it has no BF template): precision 16 -- round both operands' fragments to bf16 on the way to the MFMA
 };
+// fp32 -> nearest-even bf16 -> fp32 (finite inputs)
+__device__ __forceinline__ float bf16_round_f32(float x) {
+  const unsigned u = __builtin_bit_cast(unsigned, x);
+  return __builtin_bit_cast(float, (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u);
+}
 __device__ __forceinline__ int fdiv(int x, int d, float inv) {
   int q = (int)((float)x * inv);
   const int r = x - q * d;
@@ -326,6 +332,15 @@ __global__ __launch_bounds__(64 * (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1) * KG, 
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) b4[jn][e] = bs[(8 * j + 4 * lk + e) * LDB + wn0 + jn * 32 + lrow];
+        }
+      }
+      if (g.p16) {        // (wave-uniform; this kernel is the unaligned-operand fallback: a handful of thin products per step)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a4[i][e] = bf16_round_f32(a4[i][e]);
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn) b4[jn][e] = bf16_round_f32(b4[jn][e]);
         }
       }
     };
@@ -1382,6 +1397,7 @@ inline int tail_split_rows(int M, int N, int K, const SplitPlan& p) {
   return (main_tm > 0 && main_tm < tm) ? (int)(main_tm * 128) : 0;
 }
 
+static int current_gemm_mode();
 template <int BM, int BN, int BK, int KG, int PD>
 int launch_cfg(const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks, float* C,
                long ldc, const float* bias, int M, int N, int K, int accumulate, int splits, int kps, float* ws,
@@ -1391,8 +1407,9 @@ int launch_cfg(const float* A, long a_rs, long a_ks, const float* B, long b_rs, 
   int a_vec = ((a_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   int b_vec = ((b_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
   Gather g{};
+  if (G) g = *gp;
+  g.p16 = current_gemm_mode() == 1;
   if (G) {
-    g = *gp;
     const int ok = ((g.seg_len | g.seg_stride | g.sn | g.sy | g.sx) & 3) == 0;
     if (G == 1) a_vec = ok && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
     else b_vec = ok && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
@@ -1455,6 +1472,7 @@ static int initial_gemm_mode() {
   return (f && f[0] >= '0' && f[0] <= '3') ? f[0] - '0' : 2;
 }
 static int g_gemm_bf16 = initial_gemm_mode();
+static int current_gemm_mode() { return g_gemm_bf16; }
 static int g_last_pipe = 0;    // matrix pipe of the most recent product: 0 fp32 MFMA, 1 bf16 operands, 3 fp32 split into 3 bf16 terms
 
 template <int WB>
@@ -1590,7 +1608,8 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
   const bool skinny_mid = M <= 128 && N <= 1024 && K <= 1024 && !getenv("GENRL_SKINNY_MAX_M");
   // precision 16 (mode 1: EVERY product rounds both operands to bf16, fp32 accumulation -- the arithmetic oracle/genrl_oracle.py
   // restates as `bf16_operands`): only sgemm_rr_kernel<BF = 1> implements it, so the weight-streaming and tall-stream kernels
-  // (fp32 MFMAs fed straight from memory) are bypassed and a product that misses sgemm_rr's alignment preconditions is refused
+  // (fp32 MFMAs fed straight from memory) are bypassed; a product that misses sgemm_rr's alignment preconditions runs on the fallback
+  // sgemm_kernel, which rounds its LDS fragments (Gather::p16)
   const bool p16 = g_gemm_bf16 == 1;
   if (!p16 && (M <= skinny_max_m || skinny_mid) && a_ks == 1 && G == 0) {
     const bool b_kc = (b_ks == 1);
@@ -1651,8 +1670,6 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
       (rc = launch_rr<4>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, p.splits, (p.k_per_split + 63) / 64 * 64,
                          wsp, s, G, gp)) >= 0)
     ;
-  else if (p.big && p16)
-    return GENRL_EINVAL;      // (see above: no bf16-operand mode in the fallback kernel)
   else if (p.big)
     rc = launch_cfg<128, 128, GENRL_BIG_BK, GENRL_BIG_KG, GENRL_BIG_PD>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate,
                                                             p.splits, p.k_per_split, wsp, s, G, gp);
@@ -1661,8 +1678,7 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
     ;
   else if (trace_fallback(M, N, K, a_rs, a_ks, b_rs, b_ks, A, B), false)
     ;
-  else if (p16)
-    return GENRL_EINVAL;      // (the scalar-load fallback kernel has no bf16-operand mode: precision 16 needs 16-byte aligned operand lines)
+
   else if ((p.splits == 1 && (long)cdiv(M, 64) * cdiv(N, 64) >= GENRL_MID_TILES) || force_mid())
     // several 64x64 tiles per CU: 256-thread workgroups (one wave per SIMD each, 4+ resident per CU,
     // independent barriers) beat the single 1024-thread workgroup per CU by 10-13 % (measured)

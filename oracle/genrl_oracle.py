@@ -34,6 +34,8 @@ import torch.nn.functional as _TF
 # own precision-16 path (fp16 autocast + GradScaler, agent/dreamer_utils.py:889-932) runs on CUDA alone and could not be
 # recorded, so no fixture of it exists -- "parity unpinned against the reference" for that row.
 _BF16_OPERANDS = False
+_BF16_ACC64 = False        # (tests only: accumulate the rounded-operand products in float64 -- a second summation order of the SAME arithmetic,
+#                            used to measure how far two correct implementations of this mode drift apart: its rounding noise floor)
 
 
 def _r(t):
@@ -52,11 +54,11 @@ class _RoundedProduct(torch.autograd.Function):
 
     @staticmethod
     def _fn(kind):
-        if kind == 'linear':
-            return lambda x, w, b: _TF.linear(x, w, b)
-        if kind == 'conv':
-            return lambda x, w, b: _TF.conv2d(x, w, b, stride=2)
-        return lambda x, w, b: _TF.conv_transpose2d(x, w, b, stride=2)
+        base = {'linear': lambda x, w, b: _TF.linear(x, w, b), 'conv': lambda x, w, b: _TF.conv2d(x, w, b, stride=2),
+                'convT': lambda x, w, b: _TF.conv_transpose2d(x, w, b, stride=2)}[kind]
+        if not _BF16_ACC64:
+            return base
+        return lambda x, w, b: base(x.double(), w.double(), None if b is None else b.double()).float()
 
     @staticmethod
     def backward(ctx, dy):
@@ -95,13 +97,13 @@ F = _Products()
 
 
 @contextlib.contextmanager
-def bf16_operands():
-    global _BF16_OPERANDS
-    prev, _BF16_OPERANDS = _BF16_OPERANDS, True
+def bf16_operands(acc64=False):
+    global _BF16_OPERANDS, _BF16_ACC64
+    prev, _BF16_OPERANDS, _BF16_ACC64 = (_BF16_OPERANDS, _BF16_ACC64), True, acc64
     try:
         yield
     finally:
-        _BF16_OPERANDS = prev
+        _BF16_OPERANDS, _BF16_ACC64 = prev
 
 
 # ----------------------------------------------------------------------------- config

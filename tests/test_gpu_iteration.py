@@ -293,9 +293,17 @@ def test_precision16_vs_the_oracles_bf16_operand_mode():
     forward, input gradient and weight gradient, the policy's output layer inside the head kernels included -- rounds both operands
     to bf16 (nearest even) and accumulates in fp32; LayerNorm, softmax, losses, optimiser and all tensors stay fp32; no GradScaler
     (bf16 has fp32's exponent range).  Pinned HERE against the oracle's restatement of exactly that arithmetic
-    (`O.bf16_operands()`) on a full-width B4 x T16 iteration: every metric within north_star's 1e-3, phase gradient norms within
-    1e-3, sampled latents equal up to near-ties.  NOT pinned against the reference: its precision-16 path (fp16 autocast +
-    GradScaler, agent/dreamer_utils.py:889-932) only runs on CUDA and could not be recorded -- "oracle-pinned, reference-unpinned"."""
+    (`O.bf16_operands()`) on a full-width B4 x T16 iteration.
+
+    What "pinned" can mean for this arithmetic: operands rounded to 8 bits turn a 1e-7 difference of summation order into a flipped
+    rounding now and then, the flips into ~1e-3 differences a few layers on, and those into the odd flipped latent SAMPLE of the
+    16-step rollout -- the oracle differs from ITSELF by that much when its rounded-operand products are accumulated in float64
+    instead of float32 (measured: world-model phase 2e-6, imagination losses 1e-3, actor gradient norm 1e-2, 0.2 % of the imagined
+    latents; a second host's BLAS moves the fp32-accumulated oracle by as much again).  So: world-model and connector metrics and
+    gradient norms within north_star's 1e-3; every imagination-phase number within that self-noise -- 5e-3 (losses, statistics) /
+    2e-2 (gradient norms) -- or three times the oracle's own fp32- vs fp64-accumulation spread of that number, whichever is larger.
+    NOT pinned against the reference: its precision-16 path (fp16 autocast + GradScaler, agent/dreamer_utils.py:889-932) only runs
+    on CUDA and could not be recorded -- "oracle-pinned, reference-unpinned"."""
     from genrl_amd import ops, planes
     meta = {'meta': (4, 16, 10, 32, 32, 16, 5), 'img': 64}
     torch.set_num_threads(min(16, os.cpu_count() or 1))
@@ -304,24 +312,40 @@ def test_precision16_vs_the_oracles_bf16_operand_mode():
         assert ops.set_gemm_precision('bf16') == 'bf16' and not planes.ENABLED        # the mode was on, the fp32-grade plane products off
     finally:
         _restore_fp32_arithmetic()
+    text = FakeClip().get_txt_feat('')
     with O.bf16_operands():
-        res = run_iteration(p, ocfg, batch, noise, FakeClip().get_txt_feat(''), apply_updates=False)
+        res = run_iteration(p, ocfg, batch, noise, text, apply_updates=False)
+    with O.bf16_operands(acc64=True):
+        res64 = run_iteration(p, ocfg, batch, noise, text, apply_updates=False)
     om = {k: float(v) for k, v in res['metrics'].items()}
-    n, worst = 0, 0.0
+    om64 = {k: float(v) for k, v in res64['metrics'].items()}
+    n, worst_wm, worst_imag = 0, 0.0, 0.0
     for k, v in {**w16, **m16}.items():
-        if k in om and np.isfinite(om[k]):
-            np.testing.assert_allclose(v, om[k], rtol=1e-3, atol=1e-5, err_msg=k)
-            worst = max(worst, abs(v - om[k]) / max(abs(om[k]), 1e-5))
-            n += 1
+        if k not in om or not np.isfinite(om[k]):
+            continue
+        err = abs(v - om[k])
+        if k.startswith('imag_'):
+            floor = 2e-2 if k.endswith('grad_norm') else 5e-3           # (the mode's measured self-noise, see the docstring)
+            tol = max(floor * abs(om[k]) + 1e-5, 3.0 * abs(om[k] - om64[k]))
+            worst_imag = max(worst_imag, err / max(abs(om[k]), 1e-5))
+        else:
+            tol = 1e-3 * abs(om[k]) + 1e-5
+            worst_wm = max(worst_wm, err / max(abs(om[k]), 1e-5))
+        assert err <= tol, (k, v, om[k], om64[k])
+        n += 1
     assert n >= 20, n
-    measured('precision16.worst_metric_rel_vs_oracle', worst)
+    measured('precision16.worst_wm_connector_metric_rel_vs_oracle', worst_wm)
+    measured('precision16.worst_imagination_metric_rel_vs_oracle', worst_imag)
+    # posterior latents (world-model phase): equal up to near-ties
     mism = (outputs['post']['stoch'].argmax(-1).cpu().numpy() != res['outs']['post']['stoch'].argmax(-1).numpy()).mean()
     measured('precision16.post_idx_mismatch', mism)
     assert mism < 2e-3, mism
+    norm = lambda gs: np.sqrt(sum(float((t.double() ** 2).sum()) for t in gs.values()))
     for ph in ('wm', 'conn2', 'actor', 'critic'):
-        a = np.sqrt(sum(float((t.double() ** 2).sum()) for t in grads[ph].values()))
-        b = np.sqrt(sum(float((t.double() ** 2).sum()) for t in res['grads'][ph].values()))
-        np.testing.assert_allclose(a, b, rtol=1e-3, err_msg=ph)
+        a, b, b64 = norm(grads[ph]), norm(res['grads'][ph]), norm(res64['grads'][ph])
+        tol = 1e-3 * b if ph in ('wm', 'conn2') else max(2e-2 * b, 3.0 * abs(b - b64))
+        measured(f'precision16.grad_norm_rel_vs_oracle[{ph}]', abs(a - b) / b)
+        assert abs(a - b) <= tol, (ph, a, b, b64)
     # ... and it is a DIFFERENT arithmetic from the fp32 path (the mode is really on), within bf16's error of it
     _, _, _, _, _, _, _, w32, m32, _ = run_product(meta, True, {}, {})
     assert planes.ENABLED and w16['model_loss'] != w32['model_loss']
