@@ -342,3 +342,127 @@ extern "C" int genrl_subpixel_weight(const float* W, long s_ci, long s_co, long 
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The 3-channel end of the decoder: nn.ConvTranspose2d(Ci -> Co <= 4, k = 2T, stride 2) forward in GATHER form on the fp32 matrix
+// cores (agent/dreamer_utils.py:686-706, last layer: 48 -> 3 channels, 30 x 30 -> 64 x 64).  The plane kernels have no tile for
+// N = 4 Co = 12 columns, and GEMM -> col2im writes and re-reads a 400 MB cols matrix for 11 GFLOP.  Here one wave owns 16
+// consecutive patch positions (py, px0 .. px0 + 15) of one image: rows of a v_mfma_f32_16x16x4_f32 block; columns n = (a, b, c):
+// the four output parity classes x Co channels (12 of 16 used); K = T T Ci: the T x T input patch.  A lane's float4 at
+// x[image][py + u - (T-1)][px + v - (T-1)][16 j + 4 (lane / 16) ..] IS its A fragment for 4 MFMA steps (any k order works as long as
+// both operands use it), the weight fragments of all T T Ci / 4 steps live in registers for the whole kernel (108 VGPRs), so the
+// loop is: 3 predicated 16-byte loads + 12 MFMAs per tap, no LDS, no barrier.  Output NCHW (the reference's frame layout) or NHWC:
+// the block's 2 x Co x 32 (NCHW) outputs leave through a per-wave LDS transpose as 16-byte stores.  Exact fp32 arithmetic.
+namespace {
+template <int T, int J>      // k = 2T taps per dimension pair; Ci = 16 J
+__global__ __launch_bounds__(256) void convt_small_co_fwd_kernel(const float* __restrict__ x, const float* __restrict__ Wp,
+                                                                 const float* __restrict__ bias, float* __restrict__ out, int Nimg,
+                                                                 int Hi, int Wi, int Co, int out_nchw) {
+  constexpr int Ci = 16 * J, NS = T * T * J * 4, k = 2 * T;
+  __shared__ float tr[4][2][4][32];                       // [wave][a][c][2 i + b]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const int Hq = Hi + T - 1, Wq = Wi + T - 1, Ho = 2 * Hq - (k & 1), Wo = 2 * Wq - (k & 1);     // (k even: Ho = 2 Hq)
+  const int bpr = (Wq + 15) / 16;                         // blocks per patch row
+  const long nblk = (long)Nimg * Hq * bpr;
+  // ---- weight fragments: step s = ((u T + v) J + j) 4 + e multiplies k = (u, v, ci = 16 j + 4 kq + e); this lane's column n = r
+  const int n = r, cls = n / Co, c_n = n - cls * Co, a_n = cls >> 1, b_n = cls & 1;
+  float bf[NS];
+#pragma unroll
+  for (int u = 0; u < T; ++u)
+#pragma unroll
+    for (int v = 0; v < T; ++v)
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int kh = a_n + 2 * (T - 1 - u), kw = b_n + 2 * (T - 1 - v), ci = 16 * j + 4 * kq + e;
+          bf[((u * T + v) * J + j) * 4 + e] = (n < 4 * Co) ? Wp[(long)ci * (k * k * Co) + (kh * k + kw) * Co + c_n] : 0.f;
+        }
+  const float bias_n = (bias && n < 4 * Co) ? bias[c_n] : 0.f;
+  for (long blk = (long)blockIdx.x * 4 + wave; blk < nblk; blk += (long)gridDim.x * 4) {
+    const int bx = (int)(blk % bpr);
+    const long t = blk / bpr;
+    const int py = (int)(t % Hq);
+    const int img = (int)(t / Hq);
+    const int px = bx * 16 + r;                           // this lane's patch column (A row r)
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};     // (one chain: per-channel-group accumulators measured no faster, 229 vs 190 us)
+    // taps in flight: the loads of tap t + 1 are issued before the 4 J MFMAs of tap t (two register sets)
+    auto load_tap = [&](int tap, float4 (&av)[J]) __attribute__((always_inline)) {
+      const int u = tap / T, v = tap - u * T;
+      const int iy = py + u - (T - 1), ix = px + v - (T - 1);
+      const bool ok = iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
+      const float* p = x + ((long)(img * Hi + (ok ? iy : 0)) * Wi + (ok ? ix : 0)) * Ci + 4 * kq;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        av[j] = *reinterpret_cast<const float4*>(p + 16 * j);
+        if (!ok) av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    float4 av[2][J];
+    load_tap(0, av[0]);
+#pragma unroll
+    for (int tap = 0; tap < T * T; ++tap) {
+      if (tap + 1 < T * T) load_tap(tap + 1, av[(tap + 1) & 1]);
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int s = (tap * J + j) * 4;
+        const float4 a4 = av[tap & 1][j];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bf[s + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bf[s + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bf[s + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bf[s + 3], acc, 0, 0, 0);
+      }
+    }
+    // D[i = 4 kq + vv][n = r]: patch position px0 + i, column (a, b, c) -> output pixel (2 py + a, 2 (px0 + i) + b), channel c
+    if (n < 4 * Co) {
+#pragma unroll
+      for (int vv = 0; vv < 4; ++vv) tr[wave][a_n][c_n][2 * (4 * kq + vv) + b_n] = acc[vv] + bias_n;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own LDS writes (wave-private slab: no workgroup barrier needed)
+    __builtin_amdgcn_wave_barrier();
+    const int ox0 = 32 * bx;
+    if (out_nchw) {
+      // 2 x Co segments of 32 floats: lane -> (a, c, 16-byte piece q4)
+      for (int idx = lane; idx < 2 * Co * 8; idx += 64) {
+        const int q4 = idx & 7, ac = idx >> 3, a = ac / Co, c = ac - a * Co;
+        const int oy = 2 * py + a, ox = ox0 + 4 * q4;
+        if (oy < Ho && ox < Wo) {
+          float* o = out + (((long)img * Co + c) * Ho + oy) * Wo + ox;
+          const float* s = &tr[wave][a][c][4 * q4];
+          if (ox + 3 < Wo && ((Wo & 3) == 0)) *reinterpret_cast<float4*>(o) = make_float4(s[0], s[1], s[2], s[3]);
+          else
+            for (int e = 0; e < 4; ++e)
+              if (ox + e < Wo) o[e] = s[e];
+        }
+      }
+    } else {
+      for (int idx = lane; idx < 2 * 32 * Co; idx += 64) {     // NHWC: out[img][oy][ox][c]
+        const int a = idx / (32 * Co), rem = idx - a * (32 * Co), oxl = rem / Co, c = rem - oxl * Co;
+        const int oy = 2 * py + a, ox = ox0 + oxl;
+        if (oy < Ho && ox < Wo) out[(((long)img * Ho + oy) * Wo + ox) * Co + c] = tr[wave][a][c][oxl];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+}  // namespace
+
+/* nn.ConvTranspose2d(Ci -> Co, k, stride 2) forward for Co <= 4 output channels (the decoder's last layer), gather form on the fp32
+ * matrix cores: x fp32 NHWC [Nimg][Hi][Wi][Ci], Wp = the weight permuted to (ci, kh, kw, co), bias[Co] or NULL, out fp32
+ * [Nimg][Co][Ho][Wo] (out_nchw) or [Nimg][Ho][Wo][Co], Ho = 2 (Hi - 1) + k.  Supported: k = 6, Ci = 48 (the 64 x 64 and 128 x 128
+ * decoders); GENRL_EINVAL otherwise (the caller falls back to GEMM -> col2im). */
+extern "C" int genrl_convt_small_co_fwd(const float* x, const float* Wp, const float* bias, float* out, int Nimg, int Hi, int Wi, int Ci,
+                                        int Co, int k, int out_nchw, void* stream) {
+  GENRL_ENTER();
+  if (Nimg <= 0 || Hi <= 0 || Wi <= 0 || Co < 1 || Co > 4 || k != 6 || Ci != 48 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15))
+    return GENRL_EINVAL;
+  const long nblk = (long)Nimg * (Hi + 2) * ((Wi + 2 + 15) / 16);
+  /* resident waves only (3 per SIMD at 153 VGPRs): a wave builds its 108 weight fragments once and then walks many blocks */
+  static const int wg_cap = getenv("GENRL_CONVT_WGS") ? atoi(getenv("GENRL_CONVT_WGS")) : 768;
+  const int blocks = (int)(cdiv(nblk, 4) < wg_cap ? cdiv(nblk, 4) : wg_cap);
+  hipLaunchKernelGGL((convt_small_co_fwd_kernel<3, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, Wp, bias, out, Nimg, Hi, Wi, Co,
+                     out_nchw);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}

@@ -1275,6 +1275,9 @@ def conv2d_s2(x, W, b, ln=None):
     return _Conv2dS2.apply(x, Wp, b, k, ln[0], ln[1], float(ln[2]))
 
 
+CONVT_DIRECT = os.environ.get('GENRL_CONVT_DIRECT', '1') != '0'
+
+
 class _ConvT2dS2(Function):
     """nn.ConvTranspose2d(k, stride 2) as GEMM + gather-form col2im.  x NHWC (N,Hi,Wi,Ci);
     Wp (Ci, k*k*Co) = weight permuted to (ci, kh, kw, co); returns NHWC."""
@@ -1285,10 +1288,22 @@ class _ConvT2dS2(Function):
         Nw = Wp.shape[1]
         Co = Nw // (k * k)
         M = Nimg * Hi * Wi
-        cols = torch.empty(M, Nw, device=x.device)
-        sgemm(x, Ci, 1, Wp, 1, Nw, cols, Nw, None, M, Nw, Ci)         # cols = x W
         assert not (out_nchw and gamma is not None)
-        y = _col2im(cols, b, Nimg, Hi, Wi, Co, k, nchw=out_nchw)       # (the last decoder layer hands out NCHW frames)
+        if Co <= 4 and k == 6 and Ci == 48 and CONVT_DIRECT and Wp.is_contiguous():
+            # the 3-channel end of the decoder: gather form on the fp32 matrix cores, no cols matrix (genrl_convt_small_co_fwd)
+            Ho, Wo = 2 * (Hi - 1) + k, 2 * (Wi - 1) + k
+            y = torch.empty((Nimg, Co, Ho, Wo) if out_nchw else (Nimg, Ho, Wo, Co), device=x.device)
+            if gemm_profile is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e0.record()
+            check(lib().genrl_convt_small_co_fwd(_p(x), _p(Wp), _p(b), _p(y), Nimg, Hi, Wi, Ci, Co, k, int(out_nchw), _stream()),
+                  'convt_small_co_fwd')
+            if gemm_profile is not None:
+                e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                gemm_profile.append((Nimg * (Hi + 2) * (Wi + 2), 4 * Co, 9 * Ci, e0, e1, 'kk/convt_direct'))
+        else:
+            cols = torch.empty(M, Nw, device=x.device)
+            sgemm(x, Ci, 1, Wp, 1, Nw, cols, Nw, None, M, Nw, Ci)         # cols = x W
+            y = _col2im(cols, b, Nimg, Hi, Wi, Co, k, nchw=out_nchw)       # (the last decoder layer hands out NCHW frames)
         ctx.out_nchw = out_nchw
         ctx.dims = (Nimg, Hi, Wi, Ci, Co, k)
         ctx.fused_ln = gamma is not None

@@ -157,6 +157,13 @@ int genrl_pad_planes(const uint16_t* src, long splane, const float* sinv, uint16
  * and the strides of (cout, cin) in the weight's storage. */
 int genrl_subpixel_weight(const float* W, long s_ci, long s_co, long s_tap, int Ci, int Co, int k, int T, float* Wsub, const float* bias,
                           float* bias4, void* stream);
+/* nn.ConvTranspose2d(Ci -> Co, k, stride 2) forward for Co <= 4 output channels -- the decoder's last layer
+ * (agent/dreamer_utils.py:686-706) -- in gather form on the fp32 matrix cores (csrc/conv.hip): every wave owns 16 consecutive patch
+ * positions, all four output parity classes x Co channels are the 16 MFMA columns, the weights live in registers; exact fp32, no cols
+ * matrix, no col2im.  x fp32 NHWC [Nimg][Hi][Wi][Ci], Wp = the weight permuted to (ci, kh, kw, co), bias[Co] or NULL; out fp32
+ * [Nimg][Co][Ho][Wo] (out_nchw != 0) or [Nimg][Ho][Wo][Co], Ho = 2 (Hi - 1) + k.  Supported: k = 6, Ci = 48; GENRL_EINVAL otherwise. */
+int genrl_convt_small_co_fwd(const float* x, const float* Wp, const float* bias, float* out, int Nimg, int Hi, int Wi, int Ci, int Co,
+                             int k, int out_nchw, void* stream);
 /* Weight-gradient product on the SAME planes (csrc/gemm_planes_tn.hip):  C[i, j] (+)= sum_m A(m, i) B(m, j) for h2 planes
  * A [2][M][a_ld] (columns i < NI) and B [2][M][b_ld] (columns j < NJ) with per-row inverse scales a_inv[M], b_inv[M] -- dW = dY^T X
  * (agent/dreamer_utils.py:739-747 backward) read against the planes' storage order through the transposing LDS read

@@ -142,3 +142,30 @@ def test_subpixel_gather_form_of_the_convolution_input_gradient(N, Hi, Ci, Co, k
     cp._subpixel(dyp, N, Ho, Ho, Co, Ci, k, Wp, k * k * Ci, 1, Ci, None, dx)
     err = (dx.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     assert err < 2e-6, err
+
+
+@pytest.mark.parametrize('N,Hi,Wi,Co,nchw', [(4, 30, 30, 3, True), (3, 13, 9, 3, True), (2, 62, 62, 3, True), (5, 30, 30, 3, False), (2, 7, 30, 4, True),
+                                             (1, 1, 1, 1, False)])
+def test_direct_three_channel_transposed_convolution(N, Hi, Wi, Co, nchw):
+    """genrl_convt_small_co_fwd: the decoder's last layer (48 -> 3 channels, k 6, stride 2) in gather form on the fp32 matrix cores,
+    NCHW frames out -- against torch's conv_transpose2d in float64 (forward) and with every gradient through the unchanged backward;
+    widths that are no multiple of the 16-position blocks, the 128 px decoder's 62 x 62 input, NHWC output, 4 and 1 channels"""
+    from genrl_amd import ops
+    Ci, k = 48, 6
+    x = torch.randn(N, Hi, Wi, Ci, generator=g(1))
+    W = torch.randn(Ci, Co, k, k, generator=g(2)) / (Ci * k) ** .5
+    b = 0.1 * torch.randn(Co, generator=g(3))
+
+    def ref(x, W, b):
+        y = F.conv_transpose2d(x.permute(0, 3, 1, 2), W, b, stride=2)
+        return y if nchw else y.permute(0, 2, 3, 1)
+
+    def hip(x, W, b):
+        return ops.convT2d_s2(x, W, b, out_nchw=nchw)
+    assert ops.CONVT_DIRECT
+    y = hip(x.cuda(), W.cuda(), b.cuda())
+    r = ref(x.double(), W.double(), b.double())
+    assert y.shape == r.shape
+    err = (y.cpu().double() - r).abs().max().item() / r.abs().max().item()
+    assert err < 2e-6, err
+    _check(hip, ref, [x, W, b], rtol=1e-4, atol=1e-4)
