@@ -164,6 +164,20 @@ int genrl_subpixel_weight(const float* W, long s_ci, long s_co, long s_tap, int 
  * [Nimg][Co][Ho][Wo] (out_nchw != 0) or [Nimg][Ho][Wo][Co], Ho = 2 (Hi - 1) + k.  Supported: k = 6, Ci = 48; GENRL_EINVAL otherwise. */
 int genrl_convt_small_co_fwd(const float* x, const float* Wp, const float* bias, float* out, int Nimg, int Hi, int Wi, int Ci, int Co,
                              int k, int out_nchw, void* stream);
+/* Few-row layers with the LayerNorm in the CONSUMER's loader (csrc/fused_small.hip; the imagination rollout at <= 256 rows, data
+ * parallel): C[M][N] = act(A0) W0^T (+ A1 W1^T) + bias, M <= 512, where act = LayerNorm + SiLU of segment 0's rows taken from the
+ * PRODUCER's partial statistics (stats0 != NULL: [nparts0][M][2] = (mean, M2) of k0 / nparts0 consecutive columns of every row;
+ * gamma0 / beta0 [k0]) or the identity (stats0 == NULL); this product's own partial statistics go to stats_out (!= NULL:
+ * [N / 16][M][2], N % 16 == 0) for the next consumer.  W0 [N][k0], W1 [N][k1] k-contiguous; k0, k1 % 4 == 0; 16-byte aligned rows.
+ * agent/dreamer_utils.py:739-747 (Dense + LayerNorm + SiLU), :459-473 (img_step). */
+int genrl_small_fused(const float* a0, long a0_ld, const float* w0, long w0_ld, int k0, const float* stats0, int nparts0,
+                      const float* gamma0, const float* beta0, float eps0, const float* a1, long a1_ld, const float* w1, long w1_ld,
+                      int k1, const float* bias, float* C, long ldc, int M, int N, float* stats_out, void* stream);
+/* genrl_actor_head_linear_fwd with the LayerNorm + SiLU in front of the policy's output layer applied inside (y = the RAW rows of
+ * the last trunk layer, stats [nparts][R][2] from genrl_small_fused, nparts <= 64) */
+int genrl_actor_head_ln_linear_fwd(const float* y, long ldy, const float* stats, int nparts, const float* gamma, const float* beta,
+                                   float ln_eps, const float* W, const float* b, const float* eps, float* raw, float* action, long R,
+                                   int U, int A, float min_std, float max_std, long ld_action, void* stream);
 /* Weight-gradient product on the SAME planes (csrc/gemm_planes_tn.hip):  C[i, j] (+)= sum_m A(m, i) B(m, j) for h2 planes
  * A [2][M][a_ld] (columns i < NI) and B [2][M][b_ld] (columns j < NJ) with per-row inverse scales a_inv[M], b_inv[M] -- dW = dY^T X
  * (agent/dreamer_utils.py:739-747 backward) read against the planes' storage order through the transposing LDS read
