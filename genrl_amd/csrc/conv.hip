@@ -466,3 +466,181 @@ extern "C" int genrl_convt_small_co_fwd(const float* x, const float* Wp, const f
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the same layer (nn.ConvTranspose2d(Ci -> Co <= 4, k = 6, stride 2), NCHW output gradient): the input gradient is the
+// stride-2 convolution dx[m][ci] = sum_{kh, kw, c} dy[n][c][2 iy + kh][2 ix + kw] Wp[ci][(kh k + kw) Co + c], the weight gradient
+// dWp[ci][k'] = sum_m x[m][ci] dy-patch[m][k'].  Both used to read a materialised patch matrix (im2col: 400 MB written, read twice);
+// here the MFMA operands are gathered from dy itself (4-byte loads, L1-resident: every element serves 9 patches), fp32 MFMAs.
+namespace {
+// dgrad: a wave owns 16 consecutive input pixels of one image row (MFMA rows), the Ci = 16 CB channels are CB column blocks,
+// K = 36 Co in steps of 4 with k' = 4 s + lane / 16 (= the weight matrix's own column order); weights in registers.
+template <int CB, int NS>
+__global__ __launch_bounds__(256) void convt_small_co_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ Wp,
+                                                                   float* __restrict__ dx, int Nimg, int Hi, int Wi, int Co) {
+  constexpr int Ci = 16 * CB, k = 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
+  const int Ho = 2 * (Hi - 1) + k, Wo = 2 * (Wi - 1) + k, K = k * k * Co;
+  const int bpr = (Wi + 15) / 16;
+  const long nblk = (long)Nimg * Hi * bpr;
+  float bf[NS][CB];
+  int aoff[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int kk = 4 * s + kq;
+    const bool kv = kk < K;
+    const int kc = kv ? kk : 0;
+    const int tap = kc / Co, c = kc - tap * Co, kh = tap / k, kw = tap - kh * k;
+    aoff[s] = kv ? (c * Ho + kh) * Wo + kw : -1;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) bf[s][cb] = kv ? Wp[(long)(16 * cb + r) * K + kc] : 0.f;
+  }
+  for (int blk = blockIdx.x * 4 + wave; blk < (int)nblk; blk += gridDim.x * 4) {        // (nblk < 2^31: checked by the host)
+    const int bx = blk % bpr, t = blk / bpr;
+    const int iy = t % Hi, img = t / Hi;
+    const int ix = bx * 16 + r;
+    const bool pv = ix < Wi;
+    const float* base = dy + (long)img * Co * Ho * Wo + (long)(2 * iy) * Wo + 2 * (pv ? ix : 0);
+    f32x4 acc[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      float a = base[aoff[s] >= 0 ? aoff[s] : 0];
+      if (!pv || aoff[s] < 0) a = 0.f;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[s][cb], acc[cb], 0, 0, 0);
+    }
+    // D[i = 4 kq + v][j = r]: pixel bx 16 + i, channel 16 cb + r
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int ox = bx * 16 + 4 * kq + v;
+      if (ox < Wi) {
+        float* o = dx + (((long)img * Hi + iy) * Wi + ox) * Ci + r;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) o[16 * cb] = acc[cb][v];
+      }
+    }
+  }
+}
+
+// wgrad: MFMA rows = input channels (RB blocks), columns = k' (NCB blocks of 16 >= 36 Co), the contraction runs over pixels, 4 consecutive
+// ix of one image row per step; every wave keeps all RB x NCB accumulator blocks, the workgroup's 4 waves meet in LDS (fixed order) and the
+// workgroup writes ONE partial matrix [Ci][16 NCB]; convt_small_co_wreduce_kernel sums the partials in workgroup order (deterministic).
+template <int RB, int NCB>
+__global__ __launch_bounds__(256) void convt_small_co_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                   float* __restrict__ part, int Nimg, int Hi, int Wi, int Co) {
+  constexpr int Ci = 16 * RB, k = 6;
+  __shared__ float red[4][NCB * 4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
+  const int Ho = 2 * (Hi - 1) + k, Wo = 2 * (Wi - 1) + k, K = k * k * Co;
+  const int gpr = (Wi + 3) / 4;                            // groups of 4 pixels per image row
+  const long ngrp = (long)Nimg * Hi * gpr;
+  int boff[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int kk = 16 * cb + r;
+    const bool kv = kk < K;
+    const int kc = kv ? kk : 0;
+    const int tap = kc / Co, c = kc - tap * Co, kh = tap / k, kw = tap - kh * k;
+    boff[cb] = kv ? (c * Ho + kh) * Wo + kw : -1;
+  }
+  f32x4 acc[RB][NCB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nw = gridDim.x * 4, wid = blockIdx.x * 4 + wave;
+  // contiguous share of the groups per wave (row-major: neighbouring groups share dy rows in L1); the operands of group g + 1 are
+  // requested before the MFMAs of group g (two register sets)
+  const int per = (int)((ngrp + nw - 1) / nw), g0 = wid * per, g1 = (int)min(ngrp, (long)g0 + per);
+  auto load = [&](int g, float (&a)[RB], float (&b)[NCB]) __attribute__((always_inline)) {
+    const int gx = g % gpr, t = g / gpr;
+    const int iy = t % Hi, img = t / Hi;
+    const int ix = 4 * gx + kq;
+    const bool pv = ix < Wi;
+    const float* xp = x + (((long)img * Hi + iy) * Wi + (pv ? ix : 0)) * Ci + r;
+    const float* dp = dy + (long)img * Co * Ho * Wo + (long)(2 * iy) * Wo + 2 * (pv ? ix : 0);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) { a[rb] = xp[16 * rb]; if (!pv) a[rb] = 0.f; }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) { b[cb] = dp[boff[cb] >= 0 ? boff[cb] : 0]; if (!pv || boff[cb] < 0) b[cb] = 0.f; }
+  };
+  float a0[RB], b0[NCB], a1[RB], b1[NCB];
+  if (g0 < g1) load(g0, a0, b0);
+  for (int g = g0; g < g1; g += 2) {
+    if (g + 1 < g1) load(g + 1, a1, b1);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[rb], b0[cb], acc[rb][cb], 0, 0, 0);
+    if (g + 1 < g1) {
+      if (g + 2 < g1) load(g + 2, a0, b0);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rb], b1[cb], acc[rb][cb], 0, 0, 0);
+    }
+  }
+  float* out = part + (long)blockIdx.x * Ci * (16 * NCB);
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) red[wave][cb * 4 + v][lane] = acc[rb][cb][v];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NCB * 4 * 64; idx += 256) {
+      const int l = idx & 63, cv = idx >> 6, cb = cv >> 2, v = cv & 3;
+      const float sum = red[0][cv][l] + red[1][cv][l] + red[2][cv][l] + red[3][cv][l];
+      // D[i = 4 (l / 16) + v][j = l % 16]
+      out[(long)(16 * rb + 4 * (l >> 4) + v) * (16 * NCB) + 16 * cb + (l & 15)] = sum;
+    }
+  }
+}
+
+__global__ void convt_small_co_wreduce_kernel(const float* __restrict__ part, int nparts, int Ci, int ldp, int K, float* __restrict__ dW) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Ci * K) return;
+  const int ci = i / K, kk = i - ci * K;
+  const float* p = part + (long)ci * ldp + kk;
+  float s = 0.f;
+  const long st = (long)Ci * ldp;
+  int w = 0;
+  for (; w + 8 <= nparts; w += 8) {            // eight loads in flight, summed in workgroup order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(w + u) * st];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; w < nparts; ++w) s += p[w * st];
+  dW[i] = s;
+}
+}  // namespace
+
+/* Backward of genrl_convt_small_co_fwd for an NCHW output gradient dy [Nimg][Co][Ho][Wo]: dx (fp32 NHWC [Nimg][Hi][Wi][Ci], may be NULL)
+ * and dWp ([Ci][k k Co], the permuted weight's layout; may be NULL).  ws: genrl_convt_small_co_bwd_ws_floats() floats.  k = 6, Ci = 48. */
+extern "C" long genrl_convt_small_co_bwd_ws_floats(int Ci, int Co) { return 512L * Ci * 16 * ((36 * Co + 15) / 16); }
+extern "C" int genrl_convt_small_co_bwd(const float* x, const float* Wp, const float* dy, float* dx, float* dWp, float* ws, int Nimg, int Hi,
+                                        int Wi, int Ci, int Co, int k, void* stream) {
+  GENRL_ENTER();
+  if (Nimg <= 0 || Hi <= 0 || Wi <= 0 || Co != 3 || k != 6 || Ci != 48 || (dWp && !ws) || (long)Nimg * Hi * Wi > 0x3fffffffL) return GENRL_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (dx) {
+    const long nblk = (long)Nimg * Hi * ((Wi + 15) / 16);
+    const int blocks = (int)(cdiv(nblk, 4) < 768 ? cdiv(nblk, 4) : 768);
+    hipLaunchKernelGGL((convt_small_co_dgrad_kernel<3, 27>), dim3(blocks), dim3(256), 0, s, dy, Wp, dx, Nimg, Hi, Wi, Co);
+    GENRL_CHECK_LAUNCH();
+  }
+  if (dWp) {
+    const int nparts = 512;
+    hipLaunchKernelGGL((convt_small_co_wgrad_kernel<3, 7>), dim3(nparts), dim3(256), 0, s, x, dy, ws, Nimg, Hi, Wi, Co);
+    GENRL_CHECK_LAUNCH();
+    const int K = k * k * Co;
+    hipLaunchKernelGGL(convt_small_co_wreduce_kernel, dim3(cdiv((long)Ci * K, 256)), dim3(256), 0, s, ws, nparts, Ci, 16 * 7, K, dWp);
+    GENRL_CHECK_LAUNCH();
+  }
+  return GENRL_OK;
+}

@@ -1369,6 +1369,10 @@ def conv2d_s2(x, W, b, ln=None):
 
 
 CONVT_DIRECT = os.environ.get('GENRL_CONVT_DIRECT', '1') != '0'
+# the same layer's backward with the patch operands gathered from dy itself (genrl_convt_small_co_bwd): parity-tested, measured SLOWER than
+# im2col + the two thin GEMMs it replaces (dgrad 358 + wgrad 202 + reduce 23 us against 180 + 147 + 133 + 32 us: 4-byte gather loads feed
+# 81 MFMAs per 16 pixels at a fifth of the matrix rate) -- opt-in
+CONVT_DIRECT_BWD = os.environ.get('GENRL_CONVT_DIRECT_BWD', '0') != '0'
 
 
 class _ConvT2dS2(Function):
@@ -1421,8 +1425,26 @@ class _ConvT2dS2(Function):
             dy, dg, dbe, db_ln = _ln_bwd_rows(dy.reshape(-1, Co), pre.reshape(-1, Co), gamma, beta, mean, rstd, ctx.bias)
             dy = dy.reshape(Nimg, Ho, Wo, Co)
         implicit = _implicit_conv(dy, Co) and Ci % 4 == 0 and not ctx.out_nchw
-        dcols = None if implicit else _im2col(dy, Nimg, Ho, Wo, Co, k, 1 if ctx.out_nchw else 0)   # (M, Nw) patch matrix of dy
         dx = dW = db = None
+        if CONVT_DIRECT_BWD and ctx.out_nchw and not ctx.fused_ln and Co == 3 and k == 6 and Ci == 48 and Wp.is_contiguous():
+            # the decoder's 3-channel end: both gradients gather their patch operands from dy itself (genrl_convt_small_co_bwd), no im2col
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty(Nimg, Hi, Wi, Ci, device=dy.device)
+            ws = None
+            if ctx.needs_input_grad[1]:
+                dW = torch.empty(Ci, Nw, device=dy.device)
+                ws = torch.empty(lib().genrl_convt_small_co_bwd_ws_floats(Ci, Co), device=dy.device)
+            if gemm_profile is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e0.record()
+            check(lib().genrl_convt_small_co_bwd(_p(x), _p(Wp), _p(dy), _p(dx), _p(dW), _p(ws), Nimg, Hi, Wi, Ci, Co, k, _stream()),
+                  'convt_small_co_bwd')
+            if gemm_profile is not None:
+                e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                gemm_profile.append((M, Ci, Nw, e0, e1, 'kk/convt_direct_bwd'))
+            if ctx.needs_input_grad[2]:
+                db = dy.sum((0, 2, 3))
+            return dx, dW, db, None, None, None, None, None
+        dcols = None if implicit else _im2col(dy, Nimg, Ho, Wo, Co, k, 1 if ctx.out_nchw else 0)   # (M, Nw) patch matrix of dy
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, Ci, device=dy.device)
             if implicit:

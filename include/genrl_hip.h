@@ -178,6 +178,13 @@ int genrl_small_fused(const float* a0, long a0_ld, const float* w0, long w0_ld, 
 int genrl_actor_head_ln_linear_fwd(const float* y, long ldy, const float* stats, int nparts, const float* gamma, const float* beta,
                                    float ln_eps, const float* W, const float* b, const float* eps, float* raw, float* action, long R,
                                    int U, int A, float min_std, float max_std, long ld_action, void* stream);
+/* Backward of genrl_convt_small_co_fwd for an NCHW output gradient dy [Nimg][Co][Ho][Wo] (the decoder's frames): the input gradient dx
+ * (fp32 NHWC [Nimg][Hi][Wi][Ci]; NULL: skipped) and the weight gradient dWp ([Ci][k k Co], the permuted weight's own layout; NULL: skipped)
+ * with the patch operands gathered from dy itself on the fp32 matrix cores -- no im2col matrix.  ws: genrl_convt_small_co_bwd_ws_floats
+ * floats (per-workgroup partial weight gradients, summed in workgroup order: deterministic).  Supported: k = 6, Ci = 48, Co = 3. */
+long genrl_convt_small_co_bwd_ws_floats(int Ci, int Co);
+int genrl_convt_small_co_bwd(const float* x, const float* Wp, const float* dy, float* dx, float* dWp, float* ws, int Nimg, int Hi, int Wi,
+                             int Ci, int Co, int k, void* stream);
 /* Weight-gradient product on the SAME planes (csrc/gemm_planes_tn.hip):  C[i, j] (+)= sum_m A(m, i) B(m, j) for h2 planes
  * A [2][M][a_ld] (columns i < NI) and B [2][M][b_ld] (columns j < NJ) with per-row inverse scales a_inv[M], b_inv[M] -- dW = dY^T X
  * (agent/dreamer_utils.py:739-747 backward) read against the planes' storage order through the transposing LDS read

@@ -146,7 +146,8 @@ def test_subpixel_gather_form_of_the_convolution_input_gradient(N, Hi, Ci, Co, k
 
 @pytest.mark.parametrize('N,Hi,Wi,Co,nchw', [(4, 30, 30, 3, True), (3, 13, 9, 3, True), (2, 62, 62, 3, True), (5, 30, 30, 3, False), (2, 7, 30, 4, True),
                                              (1, 1, 1, 1, False)])
-def test_direct_three_channel_transposed_convolution(N, Hi, Wi, Co, nchw):
+@pytest.mark.parametrize('bwd', [False, True])
+def test_direct_three_channel_transposed_convolution(N, Hi, Wi, Co, nchw, bwd, monkeypatch):
     """genrl_convt_small_co_fwd: the decoder's last layer (48 -> 3 channels, k 6, stride 2) in gather form on the fp32 matrix cores,
     NCHW frames out -- against torch's conv_transpose2d in float64 (forward) and with every gradient through the unchanged backward;
     widths that are no multiple of the 16-position blocks, the 128 px decoder's 62 x 62 input, NHWC output, 4 and 1 channels"""
@@ -163,6 +164,7 @@ def test_direct_three_channel_transposed_convolution(N, Hi, Wi, Co, nchw):
     def hip(x, W, b):
         return ops.convT2d_s2(x, W, b, out_nchw=nchw)
     assert ops.CONVT_DIRECT
+    monkeypatch.setattr(ops, 'CONVT_DIRECT_BWD', bwd)       # (the direct backward kernels are opt-in: measured slower; parity is pinned all the same)
     y = hip(x.cuda(), W.cuda(), b.cuda())
     r = ref(x.double(), W.double(), b.double())
     assert y.shape == r.shape
