@@ -29,7 +29,9 @@ timeout 300 bash scripts/phase_prof.sh 32 14 > $O/phase_b32.txt 2>&1
 timeout 300 bash scripts/phase_prof.sh 4 14 > $O/phase_b4.txt 2>&1
 # (6) micro-benchmarks: weight-gradient kernel (XCD-aware order), the 64x64 tile's ablations
 timeout 200 python scripts/tn_bench.py > $O/tn_bench.txt 2>&1
-{ python scripts/abl64.py 0; for a in 1 2 3 4; do [ -f gpurun_abl$a.so ] && GENRL_HIP_SO=$PWD/gpurun_abl$a.so python scripts/abl64.py $a; done; } > $O/abl64.txt 2>&1
+# (the 64x64 tile's ablations need the -DPLANES_ABL builds: scripts/build_abl.sh 1 2 3 4, then scripts/abl64.py -- profiles/r04_abl64.txt)
+timeout 200 python scripts/fused_small_time.py > $O/fused_small_time.txt 2>&1
+timeout 200 python scripts/convt_direct_time.py > $O/convt_direct_time.txt 2>&1
 # (7) in-step time of the plane GEMM per shape; PMC passes; the full default bench line (with CPU baseline and traffic)
 timeout 300 bash scripts/inshape.sh > $O/inshape.txt 2>&1
 timeout 600 bash scripts/pmc.sh > $O/pmc.txt 2>&1; cp gpurun_out/pmc/pmc_summary.json $O/pmc.json 2>/dev/null
