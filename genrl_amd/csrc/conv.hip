@@ -473,31 +473,35 @@ extern "C" int genrl_convt_small_co_fwd(const float* x, const float* Wp, const f
 // dWp[ci][k'] = sum_m x[m][ci] dy-patch[m][k'].  Both used to read a materialised patch matrix (im2col: 400 MB written, read twice);
 // here the MFMA operands are gathered from dy itself (4-byte loads, L1-resident: every element serves 9 patches), fp32 MFMAs.
 namespace {
-// dgrad: a wave owns 16 consecutive input pixels of one image row (MFMA rows), the Ci = 16 CB channels are CB column blocks,
-// K = 36 Co in steps of 4 with k' = 4 s + lane / 16 (= the weight matrix's own column order); weights in registers.
-template <int CB, int NS>
+// dgrad: a wave owns 16 consecutive input pixels of one image row (MFMA rows), the Ci = 16 CB channels are CB column blocks.  K = 36 Co is
+// walked in GROUPS g = (c, kh, kw pair p): lane (r, kq) of round t takes group 4 t + kq and loads the float2 dy[c][2 iy + kh][2 ix + 2 p ..]
+// -- 8-byte loads that are CONTIGUOUS across the 16 pixels of the block (the first version's 4-byte loads at an 8-byte lane stride ran the
+// kernel at a fifth of the matrix rate) -- and the two floats are the A operands of two MFMA steps (kw = 2 p, 2 p + 1); weights in registers.
+template <int CB, int NR>      // NR rounds of 4 groups >= 18 Co groups
 __global__ __launch_bounds__(256) void convt_small_co_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ Wp,
                                                                    float* __restrict__ dx, int Nimg, int Hi, int Wi, int Co) {
   constexpr int Ci = 16 * CB, k = 6;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
-  const int Ho = 2 * (Hi - 1) + k, Wo = 2 * (Wi - 1) + k, K = k * k * Co;
+  const int Ho = 2 * (Hi - 1) + k, Wo = 2 * (Wi - 1) + k, K = k * k * Co, NG = 3 * k * Co;
   const int bpr = (Wi + 15) / 16;
   const long nblk = (long)Nimg * Hi * bpr;
-  float bf[NS][CB];
-  int aoff[NS];
+  float bf[NR][2][CB];
+  int aoff[NR];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const int kk = 4 * s + kq;
-    const bool kv = kk < K;
-    const int kc = kv ? kk : 0;
-    const int tap = kc / Co, c = kc - tap * Co, kh = tap / k, kw = tap - kh * k;
-    aoff[s] = kv ? (c * Ho + kh) * Wo + kw : -1;
+  for (int t = 0; t < NR; ++t) {
+    const int g = 4 * t + kq;
+    const bool gv = g < NG;
+    const int gc = gv ? g : 0;
+    const int c = gc / (3 * k), rem = gc - c * (3 * k), kh = rem / 3, p = rem - kh * 3;
+    aoff[t] = gv ? (c * Ho + kh) * Wo + 2 * p : -1;
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) bf[s][cb] = kv ? Wp[(long)(16 * cb + r) * K + kc] : 0.f;
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) bf[t][e][cb] = gv ? Wp[(long)(16 * cb + r) * K + (kh * k + 2 * p + e) * Co + c] : 0.f;
   }
   for (int blk = blockIdx.x * 4 + wave; blk < (int)nblk; blk += gridDim.x * 4) {        // (nblk < 2^31: checked by the host)
-    const int bx = blk % bpr, t = blk / bpr;
-    const int iy = t % Hi, img = t / Hi;
+    const int bx = blk % bpr, t0 = blk / bpr;
+    const int iy = t0 % Hi, img = t0 / Hi;
     const int ix = bx * 16 + r;
     const bool pv = ix < Wi;
     const float* base = dy + (long)img * Co * Ho * Wo + (long)(2 * iy) * Wo + 2 * (pv ? ix : 0);
@@ -505,11 +509,13 @@ __global__ __launch_bounds__(256) void convt_small_co_dgrad_kernel(const float* 
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      float a = base[aoff[s] >= 0 ? aoff[s] : 0];
-      if (!pv || aoff[s] < 0) a = 0.f;
+    for (int t = 0; t < NR; ++t) {
+      float2 a = *reinterpret_cast<const float2*>(base + (aoff[t] >= 0 ? aoff[t] : 0));
+      if (!pv || aoff[t] < 0) a = make_float2(0.f, 0.f);
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[s][cb], acc[cb], 0, 0, 0);
+      for (int cb = 0; cb < CB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bf[t][0][cb], acc[cb], 0, 0, 0);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bf[t][1][cb], acc[cb], 0, 0, 0);
     }
     // D[i = 4 kq + v][j = r]: pixel bx 16 + i, channel 16 cb + r
 #pragma unroll
@@ -536,13 +542,16 @@ __global__ __launch_bounds__(256) void convt_small_co_wgrad_kernel(const float* 
   const int Ho = 2 * (Hi - 1) + k, Wo = 2 * (Wi - 1) + k, K = k * k * Co;
   const int gpr = (Wi + 3) / 4;                            // groups of 4 pixels per image row
   const long ngrp = (long)Nimg * Hi * gpr;
+  // internal column order j = (c, kh, kw), kw fastest: the 16 lanes of a column block then read 6-float runs of dy rows instead of 16
+  // scattered words (the weight matrix's own order has c fastest: a stride of a whole image plane between neighbours); the epilogue maps
+  // internal column j back to the weight matrix's column (kh k + kw) Co + c
   int boff[NCB];
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) {
-    const int kk = 16 * cb + r;
-    const bool kv = kk < K;
-    const int kc = kv ? kk : 0;
-    const int tap = kc / Co, c = kc - tap * Co, kh = tap / k, kw = tap - kh * k;
+    const int j = 16 * cb + r;
+    const bool kv = j < K;
+    const int jc = kv ? j : 0;
+    const int c = jc / (k * k), rem = jc - c * (k * k), kh = rem / k, kw = rem - kh * k;
     boff[cb] = kv ? (c * Ho + kh) * Wo + kw : -1;
   }
   f32x4 acc[RB][NCB];
@@ -554,9 +563,11 @@ __global__ __launch_bounds__(256) void convt_small_co_wgrad_kernel(const float* 
   // contiguous share of the groups per wave (row-major: neighbouring groups share dy rows in L1); the operands of group g + 1 are
   // requested before the MFMAs of group g (two register sets)
   const int per = (int)((ngrp + nw - 1) / nw), g0 = wid * per, g1 = (int)min(ngrp, (long)g0 + per);
+  // (img, iy, gx) of the NEXT group to load walk along incrementally: three integer divisions per 21 MFMAs cost as much as the MFMAs
+  int ngx = g0 % gpr, nt = g0 / gpr, niy = nt % Hi, nimg = nt / Hi;
   auto load = [&](int g, float (&a)[RB], float (&b)[NCB]) __attribute__((always_inline)) {
-    const int gx = g % gpr, t = g / gpr;
-    const int iy = t % Hi, img = t / Hi;
+    const int gx = ngx, iy = niy, img = nimg;
+    if (++ngx == gpr) { ngx = 0; if (++niy == Hi) { niy = 0; ++nimg; } }
     const int ix = 4 * gx + kq;
     const bool pv = ix < Wi;
     const float* xp = x + (((long)img * Hi + iy) * Wi + (pv ? ix : 0)) * Ci + r;
@@ -594,8 +605,12 @@ __global__ __launch_bounds__(256) void convt_small_co_wgrad_kernel(const float* 
     for (int idx = threadIdx.x; idx < NCB * 4 * 64; idx += 256) {
       const int l = idx & 63, cv = idx >> 6, cb = cv >> 2, v = cv & 3;
       const float sum = red[0][cv][l] + red[1][cv][l] + red[2][cv][l] + red[3][cv][l];
-      // D[i = 4 (l / 16) + v][j = l % 16]
-      out[(long)(16 * rb + 4 * (l >> 4) + v) * (16 * NCB) + 16 * cb + (l & 15)] = sum;
+      // D[i = 4 (l / 16) + v][j = l % 16]; internal column j -> the weight matrix's column 
+      const int j = 16 * cb + (l & 15);
+      if (j < K) {
+        const int c = j / (k * k), rem = j - c * (k * k), kh = rem / k, kw = rem - kh * k;
+        out[(long)(16 * rb + 4 * (l >> 4) + v) * (16 * NCB) + (kh * k + kw) * Co + c] = sum;
+      }
     }
   }
 }
@@ -631,7 +646,7 @@ extern "C" int genrl_convt_small_co_bwd(const float* x, const float* Wp, const f
   if (dx) {
     const long nblk = (long)Nimg * Hi * ((Wi + 15) / 16);
     const int blocks = (int)(cdiv(nblk, 4) < 768 ? cdiv(nblk, 4) : 768);
-    hipLaunchKernelGGL((convt_small_co_dgrad_kernel<3, 27>), dim3(blocks), dim3(256), 0, s, dy, Wp, dx, Nimg, Hi, Wi, Co);
+    hipLaunchKernelGGL((convt_small_co_dgrad_kernel<3, 14>), dim3(blocks), dim3(256), 0, s, dy, Wp, dx, Nimg, Hi, Wi, Co);
     GENRL_CHECK_LAUNCH();
   }
   if (dWp) {

@@ -1369,10 +1369,9 @@ def conv2d_s2(x, W, b, ln=None):
 
 
 CONVT_DIRECT = os.environ.get('GENRL_CONVT_DIRECT', '1') != '0'
-# the same layer's backward with the patch operands gathered from dy itself (genrl_convt_small_co_bwd): parity-tested, measured SLOWER than
-# im2col + the two thin GEMMs it replaces (dgrad 358 + wgrad 202 + reduce 23 us against 180 + 147 + 133 + 32 us: 4-byte gather loads feed
-# 81 MFMAs per 16 pixels at a fifth of the matrix rate) -- opt-in
-CONVT_DIRECT_BWD = os.environ.get('GENRL_CONVT_DIRECT_BWD', '0') != '0'
+# the same layer's backward with the patch operands gathered from dy itself (genrl_convt_small_co_bwd): dgrad 175 + wgrad 185 + reduce 23 us
+# against im2col 180 + 147 + 133 + 32 us (the first version, with 4-byte gather loads at an 8-byte lane stride, took 358 + 202 + 62)
+CONVT_DIRECT_BWD = os.environ.get('GENRL_CONVT_DIRECT_BWD', '1') != '0'
 
 
 class _ConvT2dS2(Function):
