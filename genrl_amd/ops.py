@@ -1634,6 +1634,9 @@ def gru_step(x, h, W, gamma, beta):
     return _GRUStep.apply(x, h, W, gamma, beta)
 
 
+SEQ_C = os.environ.get('GENRL_SEQ_C', '1') != '0'      # the scans' per-step launch loops run in C (csrc/seq.hip); 0: from Python
+
+
 def scan_coop_variant(B, D, T, I=0):
     """0: the per-step launches (default); 1 / 2: the persistent scan kernel with one / two grid barriers per step
     (GENRL_SCAN_COOP=1|2|auto; auto = one barrier where it exists (B <= 8), else two).  I: width of the input half of the GRU
@@ -1689,7 +1692,14 @@ class _GRUSeq(Function):
                 off = (wsp - ws.data_ptr()) // 4
                 if int(ws.view(torch.int32)[off + 416].item()) != 0:
                     raise GenrlHipError('gru_scan_coop: a grid barrier timed out (workgroups not co-resident); unset GENRL_SCAN_COOP')
-        for t in (range(T) if not variant else ()):
+        seq_c = SEQ_C and not variant and gemm_profile is None
+        if seq_c:
+            # the T-step launch loop in C (csrc/seq.hip: same launches, same order -- one host call instead of 2 T)
+            nws = lib().genrl_gru_seq_ws_floats(B, D)
+            ws = torch.empty(nws, device=dev) if nws > 0 else None
+            check(lib().genrl_gru_seq_fwd(_p(pre), W.data_ptr() + 4 * I, K, _p(gamma), _p(beta), _p(h0), _p(mask), _p(out), _p(hm), _p(mean),
+                                          _p(rstd), _p(ws), nws, T, B, D, 1e-5, _stream()), 'gru_seq_fwd')
+        for t in (range(T) if not (variant or seq_c) else ()):
             if hm is not None:
                 hprev, hoff = hm, t * BD
             else:
@@ -1730,7 +1740,18 @@ class _GRUSeq(Function):
         pa = torch.empty(S, B, D, device=dev) if S else None
         pb = torch.empty(S, B, D, device=dev) if S else None
         cur, nxt, pcur, pnxt = dha, None, pa, None
-        for t in range(T - 1, -1, -1):
+        seq_c = SEQ_C and gemm_profile is None
+        if seq_c:
+            nws = lib().genrl_gru_seq_ws_floats(B, D)
+            ws2 = torch.empty(nws, device=dev) if nws > 0 else None
+            fin = (ctypes.c_int * 2)(0, -1)
+            check(lib().genrl_gru_seq_bwd(_p(dout), _p(pre), W.data_ptr() + 4 * I, K, _p(gamma), _p(beta), _p(h0),
+                                          _p(mask) if ctx.has_mask else None, _p(out), _p(hm) if ctx.has_mask else None, _p(mean), _p(rstd),
+                                          _p(dpre), _p(dha), _p(dhb), _p(pa), _p(pb), S, _p(gb[0]), _p(gb[1]), int(direct), _p(ws), _p(ws2), nws,
+                                          T, B, D, ctypes.addressof(fin), ctypes.addressof(fin) + 4, _stream()), 'gru_seq_bwd')
+            nxt = dha if fin[0] == 0 else dhb
+            pnxt = (pa if fin[1] == 0 else pb) if S else None
+        for t in (() if seq_c else range(T - 1, -1, -1)):
             if ctx.has_mask:
                 hprev, hoff = hm, t * BD
             else:

@@ -185,6 +185,21 @@ int genrl_actor_head_ln_linear_fwd(const float* y, long ldy, const float* stats,
 long genrl_convt_small_co_bwd_ws_floats(int Ci, int Co);
 int genrl_convt_small_co_bwd(const float* x, const float* Wp, const float* dy, float* dx, float* dWp, float* ws, int Nimg, int Hi, int Wi,
                              int Ci, int Co, int k, void* stream);
+/* ---- sequence-level entry points (csrc/seq.hip; SURVEY 8b rssm_observe_seq): the per-step launch loops of the RSSM scans
+ * (EnsembleRSSM.observe, agent/dreamer_utils.py:362-371, 425-457; VideoSSM.update, agent/video_utils.py:150-187) run from ONE call --
+ * the same launches in the same order as the per-step entry points above (bit-identical), without ~20 us of host work per launch.
+ * forward: pre (T, B, 3D) holds x_t W_x^T on entry, the full pre-activations on return; Wh = the recurrent block of the (3D, I + D)
+ * weight (row stride ldw); mask (T, B) or NULL with hm (T, B, D) = masked previous states (hm[0] prepared by the caller).
+ * backward: dha / dhb ping-pong d(hm_t); pa / pb (S, B, D) K-split slabs (S = 0: none); *final_dh / *final_parts (host ints) name the
+ * buffers that hold d(hm_0)'s direct part / remaining slabs.  ws: genrl_gru_seq_ws_floats(B, D); gws: genrl_gru_ws_floats(B, D). */
+long genrl_gru_seq_ws_floats(int B, int D);
+int genrl_gru_seq_fwd(float* pre, const float* Wh, long ldw, const float* gamma, const float* beta, const float* h0, const float* mask,
+                      float* out, float* hm, float* mean, float* rstd, float* ws, long ws_floats, int T, int B, int D, float eps,
+                      void* stream);
+int genrl_gru_seq_bwd(const float* dout, const float* pre, const float* Wh, long ldw, const float* gamma, const float* beta, const float* h0,
+                      const float* mask, const float* out, const float* hm, const float* mean, const float* rstd, float* dpre, float* dha,
+                      float* dhb, float* pa, float* pb, int S, float* dgamma, float* dbeta, int direct, float* gws, float* ws,
+                      long ws_floats, int T, int B, int D, int* final_dh, int* final_parts, void* stream);
 /* Weight-gradient product on the SAME planes (csrc/gemm_planes_tn.hip):  C[i, j] (+)= sum_m A(m, i) B(m, j) for h2 planes
  * A [2][M][a_ld] (columns i < NI) and B [2][M][b_ld] (columns j < NJ) with per-row inverse scales a_inv[M], b_inv[M] -- dW = dY^T X
  * (agent/dreamer_utils.py:739-747 backward) read against the planes' storage order through the transposing LDS read

@@ -225,6 +225,25 @@ def test_gru_seq_and_step(ops, T, B, I, D, masked):
     compare(ops.gru_step, cell, [x[0], h0, W, ga, be], rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize('T,B,I,D,masked', [(5, 3, 8, 12, True), (8, 32, 64, 1024, True), (6, 4, 16, 32, False), (4, 64, 64, 512, True)])
+def test_gru_seq_c_loop_is_the_python_loop(ops, T, B, I, D, masked, monkeypatch):
+    """genrl_gru_seq_fwd / _bwd (csrc/seq.hip): the scans' per-step launch loops run from ONE C call -- the same launches in the same
+    order, so outputs and every gradient are bit-identical to the per-step launches from Python (B = 64: the tile + split-K products
+    with a workspace; B <= 32: the weight-streaming kernel with K-split slabs in the backward)"""
+    def run(flag):
+        monkeypatch.setattr(ops, 'SEQ_C', flag)
+        ts = [t.clone().cuda().requires_grad_(True) for t in (torch.randn(T, B, I, generator=g(1)), torch.randn(B, D, generator=g(2)),
+                                                             torch.randn(3 * D, I + D, generator=g(3)) / (I + D) ** .5,
+                                                             1 + 0.1 * torch.randn(3 * D, generator=g(4)), 0.1 * torch.randn(3 * D, generator=g(5)))]
+        mask = (torch.rand(T, B, generator=g(6)) > 0.3).float().cuda() if masked else None
+        y = ops.gru_seq(ts[0], mask, ts[1], ts[2], ts[3], ts[4])
+        (y * torch.randn(y.shape, generator=g(7)).cuda()).sum().backward()
+        return [y.detach()] + [t.grad for t in ts]
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
 @pytest.mark.parametrize('R,S,K', [(9, 4, 4), (64, 32, 32), (5, 3, 7)])
 def test_onehot_and_kl(ops, R, S, K):
     lg = torch.randn(R, S, K, generator=g(1)) * 2; lq = torch.randn(R, S, K, generator=g(2)) * 2
