@@ -65,4 +65,67 @@ int genrl_gru_seq_bwd(const float* dout, const float* pre, const float* Wh, long
   return GENRL_OK;
 }
 
+// ---- imagination rollout, forward (genrl_amd/ops_planes.py::_RolloutPlanes.forward is the Python twin and the documentation of the order)
+static inline int gemm2(const genrl_planes_ref& a, long ar, const genrl_planes_ref& b, const genrl_planes_ref* a1, long a1r,
+                        const genrl_planes_ref* b1, float* C, long ldc, const float* bias, int M, int N, void* st) {
+  const bool two = a1 && a1->p;
+  return genrl_gemm_h2(a.p + ar * a.ld, a.ld, a.plane, a.inv + ar, b.p, b.ld, b.plane, b.inv, (int)a.ld,
+                       two ? a1->p + a1r * a1->ld : nullptr, two ? a1->ld : 0, two ? a1->plane : 0, two ? a1->inv + a1r : nullptr,
+                       two ? b1->p : nullptr, two ? b1->ld : 0, two ? b1->plane : 0, two ? b1->inv : nullptr, two ? (int)a1->ld : 0,
+                       C, ldc, bias, M, N, 0, st);
+}
+static inline int ln_h2(const float* pre, const float* g, const float* be, float* y, float* mean, float* rstd, int M, int N, float eps,
+                        const genrl_planes_ref& P, long row0, void* st) {
+  return genrl_ln_act_fwd_h2(pre, N, g, be, y, N, mean, rstd, M, N, eps, 1, const_cast<uint16_t*>(P.p) + row0 * P.ld, P.ld, P.plane,
+                             const_cast<float*>(P.inv) + row0, st);
+}
+#define RC(x) do { const int rc_ = (x); if (rc_) return rc_; } while (0)
+
+int genrl_imagine_seq_fwd(const genrl_rollout* r, void* st) {
+  if (!r || r->H <= 0 || r->N <= 0 || r->L < 1 || r->L > 8) return GENRL_EINVAL;
+  const int H = r->H, N = r->N, D = r->D, A = r->A, AP = r->AP, U = r->U, L = r->L;
+  const long SK = (long)r->S * r->K;
+  for (int h = 0; h < H; ++h) {
+    const long r0 = (long)h * N, r1 = r0 + N;
+    // policy trunk on sg([stoch_h, deter_h]), then output layer + Normal head -> action_{h+1}
+    for (int l = 0; l < L; ++l) {
+      const int Ul = r->pU[l];
+      float* pre = r->ppre[l] + r0 * Ul;
+      if (l == 0) RC(gemm2(r->stoch_p, r0, r->pw0s, &r->deter_p, r0, &r->pw0d, pre, Ul, r->pb[0], N, Ul, st));
+      else RC(gemm2(r->pyp[l - 1], r0, r->pw[l], nullptr, 0, nullptr, pre, Ul, r->pb[l], N, Ul, st));
+      RC(ln_h2(pre, r->pg[l], r->pbe[l], r->py[l] + r0 * Ul, r->pmean[l] + r0, r->prstd[l] + r0, N, Ul, r->peps[l], r->pyp[l], r0, st));
+    }
+    {
+      const int Ul = r->pU[L - 1];
+      RC(genrl_actor_head_linear_fwd(r->py[L - 1] + r0 * Ul, Ul, r->head_w, r->head_b, r->eps + r0 * A, r->raws + r0 * 2 * A,
+                                     r->action + r1 * AP, N, Ul, A, r->min_std, r->max_std, AP,
+                                     const_cast<uint16_t*>(r->act_p.p) + r1 * r->act_p.ld, r->act_p.ld, r->act_p.plane,
+                                     const_cast<float*>(r->act_p.inv) + r1, st));
+    }
+    // img_in: [stoch_h | action_{h+1}] -> hidden, LN + SiLU
+    RC(gemm2(r->stoch_p, r0, r->w_in_s, &r->act_p, r1, &r->w_in_a, r->x_pre + r0 * U, U, r->in_b, N, U, st));
+    RC(ln_h2(r->x_pre + r0 * U, r->in_g, r->in_be, r->x, r->xm + r0, r->xr + r0, N, U, r->in_eps, r->x_p, 0, st));
+    // GRU: [x | deter_h] W_g^T -> LN + gates -> deter_{h+1}
+    RC(gemm2(r->x_p, 0, r->w_g_x, &r->deter_p, r0, &r->w_g_h, r->g_pre + r0 * 3 * D, 3 * D, nullptr, N, 3 * D, st));
+    RC(genrl_gru_gates_fwd_h2(r->g_pre + r0 * 3 * D, r->deter + r0 * D, D, r->gru_g, r->gru_be, r->deter + r1 * D, D, nullptr, nullptr,
+                              r->gm + r0, r->gr + r0, N, D, 1e-5f, const_cast<uint16_t*>(r->deter_p.p) + r1 * r->deter_p.ld, r->deter_p.ld,
+                              r->deter_p.plane, const_cast<float*>(r->deter_p.inv) + r1, st));
+    // prior head: img_out (+ LN + SiLU), logits, sample
+    RC(gemm2(r->deter_p, r1, r->w_out, nullptr, 0, nullptr, r->o_pre + r0 * U, U, r->out_b, N, U, st));
+    RC(ln_h2(r->o_pre + r0 * U, r->out_g, r->out_be, r->o, r->om + r0, r->orr + r0, N, U, r->out_eps, r->o_p, 0, st));
+    if (r->K == 32 && r->dist_b) {
+      RC(genrl_gemm_h2_sample(r->o_p.p, r->o_p.ld, r->o_p.plane, r->o_p.inv, r->w_dist.p, r->w_dist.ld, r->w_dist.plane, r->w_dist.inv,
+                              (int)r->o_p.ld, r->logit + r1 * SK, SK, r->dist_b, N, (int)SK, r->q + r0 * SK, SK, r->unimix,
+                              r->stoch + r1 * SK, SK, const_cast<uint16_t*>(r->stoch_p.p) + r1 * r->stoch_p.ld, r->stoch_p.ld,
+                              r->stoch_p.plane, const_cast<float*>(r->stoch_p.inv) + r1, st));
+    } else {
+      RC(gemm2(r->o_p, 0, r->w_dist, nullptr, 0, nullptr, r->logit + r1 * SK, SK, r->dist_b, N, (int)SK, st));
+      RC(genrl_onehot_fwd_h2(r->logit + r1 * SK, r->q + r0 * SK, r->stoch + r1 * SK, nullptr, (long)N * r->S, r->K, r->unimix,
+                             const_cast<uint16_t*>(r->stoch_p.p) + r1 * r->stoch_p.ld, (int)SK, r->stoch_p.ld, r->stoch_p.plane,
+                             const_cast<float*>(r->stoch_p.inv) + r1, st));
+    }
+  }
+  return GENRL_OK;
+}
+
 }  // extern "C"

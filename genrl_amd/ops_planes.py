@@ -18,6 +18,34 @@ from .ops import _p, _f32, _grad_buf, _ws, sgemm, colsum, UNIMIX
 _stream = ops._stream
 
 
+# ---- genrl_rollout (include/genrl_hip.h): the arguments of the rollout's launch loop in C (csrc/seq.hip: genrl_imagine_seq_fwd)
+import ctypes as _ct
+
+
+class _PRef(_ct.Structure):
+    _fields_ = [('p', _ct.c_void_p), ('ld', _ct.c_long), ('plane', _ct.c_long), ('inv', _ct.c_void_p)]
+
+
+_FP, _F, _I = _ct.c_void_p, _ct.c_float, _ct.c_int
+
+
+class _RolloutArgs(_ct.Structure):
+    _fields_ = ([(n, _I) for n in ('H', 'N', 'S', 'K', 'D', 'A', 'AP', 'U', 'L')] + [(n, _F) for n in ('unimix', 'min_std', 'max_std')]
+                + [(n, _FP) for n in ('stoch', 'deter', 'logit', 'action', 'raws', 'eps', 'q')]
+                + [(n, _PRef) for n in ('stoch_p', 'deter_p', 'act_p', 'x_p', 'o_p')]
+                + [(n, _FP) for n in ('x_pre', 'x', 'g_pre', 'o_pre', 'o', 'xm', 'xr', 'gm', 'gr', 'om', 'orr')]
+                + [(n, _PRef) for n in ('w_in_s', 'w_in_a', 'w_g_x', 'w_g_h', 'w_out', 'w_dist')]
+                + [('in_b', _FP), ('in_g', _FP), ('in_be', _FP), ('in_eps', _F), ('gru_g', _FP), ('gru_be', _FP),
+                   ('out_b', _FP), ('out_g', _FP), ('out_be', _FP), ('out_eps', _F), ('dist_b', _FP),
+                   ('pw0s', _PRef), ('pw0d', _PRef), ('pw', _PRef * 8), ('pb', _FP * 8), ('pg', _FP * 8), ('pbe', _FP * 8),
+                   ('peps', _F * 8), ('pU', _I * 8), ('ppre', _FP * 8), ('py', _FP * 8), ('pmean', _FP * 8), ('prstd', _FP * 8),
+                   ('pyp', _PRef * 8), ('head_w', _FP), ('head_b', _FP)])
+
+
+def _pref(P):
+    return _PRef(P.t.data_ptr(), P.ld, P.plane, P.inv.data_ptr())
+
+
 def _ln_fwd(pre_ptr, gamma, beta, y_ptr, mean_ptr, rstd_ptr, M, N, eps, P, row0):
     check(lib().genrl_ln_act_fwd_h2(pre_ptr, N, _p(gamma), _p(beta), y_ptr, N, mean_ptr, rstd_ptr, M, N, eps, 1,
                                     P.ptr(row0), P.ld, P.plane, P.inv_ptr(row0), _stream()), 'ln_act_fwd_h2')
@@ -162,7 +190,32 @@ class _RolloutPlanes(Function):
         w_out, w_dist = planes.weight(sp.out_w), planes.weight(sp.dist_w)
         pt = lambda t, off: t.data_ptr() + 4 * off
         L = lib()
-        for h in range(H):
+        seq_c = ops.SEQ_C and planes.gemm_profile is None and len(tape.layers) <= 8
+        if seq_c:
+            # the H-step launch loop in C (csrc/seq.hip: genrl_imagine_seq_fwd -- the loop below, launch for launch, from one host call)
+            a = _RolloutArgs()
+            a.H, a.N, a.S, a.K, a.D, a.A, a.AP, a.U, a.L = H, N, S, K, D, A, AP, U, len(tape.layers)
+            a.unimix, a.min_std, a.max_std = UNIMIX, sp.min_std, sp.max_std
+            for n_, t_ in (('stoch', stoch), ('deter', deter), ('logit', logit), ('action', action), ('raws', raws), ('eps', eps), ('q', q),
+                           ('x_pre', x_pre), ('x', x), ('g_pre', g_pre), ('o_pre', o_pre), ('o', o), ('xm', st['xm']), ('xr', st['xr']),
+                           ('gm', st['gm']), ('gr', st['gr']), ('om', st['om']), ('orr', st['or']), ('in_b', sp.in_b), ('in_g', sp.in_g),
+                           ('in_be', sp.in_be), ('gru_g', sp.gru_g), ('gru_be', sp.gru_be), ('out_b', sp.out_b), ('out_g', sp.out_g),
+                           ('out_be', sp.out_be), ('dist_b', sp.dist_b), ('head_w', tape.head_w), ('head_b', tape.head_b)):
+                setattr(a, n_, _p(t_))
+            a.in_eps, a.out_eps = sp.in_eps, sp.out_eps
+            for n_, P_ in (('stoch_p', stoch_p), ('deter_p', deter_p), ('act_p', act_p), ('x_p', x_p), ('o_p', o_p), ('w_in_s', w_in_s),
+                           ('w_in_a', w_in_a), ('w_g_x', w_g_x), ('w_g_h', w_g_h), ('w_out', w_out), ('w_dist', w_dist)):
+                setattr(a, n_, _pref(P_))
+            for l, (W_, b_, ga_, be_, eps_) in enumerate(tape.layers):
+                if l == 0:
+                    a.pw0s, a.pw0d = _pref(planes.weight(W_, c0=0, c1=SK)), _pref(planes.weight(W_, c0=SK))
+                else:
+                    a.pw[l] = _pref(planes.weight(W_))
+                a.pb[l], a.pg[l], a.pbe[l], a.peps[l], a.pU[l] = _p(b_), _p(ga_), _p(be_), eps_, W_.shape[0]
+                a.ppre[l], a.py[l], a.pmean[l], a.prstd[l] = _p(tape.pre[l]), _p(tape.y[l]), _p(tape.mean[l]), _p(tape.rstd[l])
+                a.pyp[l] = _pref(tape.yp[l])
+            check(L.genrl_imagine_seq_fwd(_ct.addressof(a), _stream()), 'imagine_seq_fwd')
+        for h in (() if seq_c else range(H)):
             r0, r1 = h * N, (h + 1) * N
             tape._forward_planes(h, stoch_p, deter_p, None)
             tape.head_fused(h, pt(eps, h * N * A), pt(raws, h * N * 2 * A), pt(action, r1 * AP), AP, sp.min_std, sp.max_std, act_p, r1)

@@ -200,6 +200,31 @@ int genrl_gru_seq_bwd(const float* dout, const float* pre, const float* Wh, long
                       const float* mask, const float* out, const float* hm, const float* mean, const float* rstd, float* dpre, float* dha,
                       float* dhb, float* pa, float* pb, int S, float* dgamma, float* dbeta, int direct, float* gws, float* ws,
                       long ws_floats, int T, int B, int D, int* final_dh, int* final_parts, void* stream);
+/* The imagination rollout's H-step launch loop in C (csrc/seq.hip; SURVEY 8b imagine_seq; WorldModel.imagine, agent/dreamer.py:254-287,
+ * with the policy of ActorCritic, :323-350): per step the policy's L Dense + LayerNorm + SiLU layers and its output layer + Normal head,
+ * then img_step -- [stoch | action] -> hidden, [hidden | deter] -> GRU gates, deter -> hidden -> prior logits + categorical sample -- on
+ * plane operands: 16 launches per step, exactly those of genrl_amd/ops_planes.py::_RolloutPlanes.forward in the same order (bit-identical),
+ * from ONE host call.  All buffers are the caller's (genrl_rollout names them); time-major rows h N + n; planes rows likewise. */
+typedef struct { const uint16_t* p; long ld, plane; const float* inv; } genrl_planes_ref;    /* h2 planes [2][rows][ld] + inverse row scales */
+typedef struct {
+  int H, N, S, K, D, A, AP, U, L;                 /* horizon, rows, latents, classes, deter, action dim (AP: padded to 4), hidden, policy layers (<= 8) */
+  float unimix, min_std, max_std;
+  float* stoch; float* deter; float* logit; float* action; float* raws;      /* (H+1,N,S K) (H+1,N,D) (H+1,N,S K) (H+1,N,AP) (H,N,2A) */
+  const float* eps; const float* q;                                           /* policy noise (H,N,A), sampling noise (H,N,S K) */
+  genrl_planes_ref stoch_p, deter_p, act_p, x_p, o_p;                          /* (H+1) N rows each for the states / actions; N rows for x, o */
+  float* x_pre; float* x; float* g_pre; float* o_pre; float* o;                /* (H,N,U) (N,U) (H,N,3D) (H,N,U) (N,U) */
+  float* xm; float* xr; float* gm; float* gr; float* om; float* orr;           /* LayerNorm statistics, (H,N) each */
+  genrl_planes_ref w_in_s, w_in_a, w_g_x, w_g_h, w_out, w_dist;               /* frozen world-model weights as planes */
+  const float* in_b; const float* in_g; const float* in_be; float in_eps;
+  const float* gru_g; const float* gru_be;
+  const float* out_b; const float* out_g; const float* out_be; float out_eps;
+  const float* dist_b;
+  genrl_planes_ref pw0s, pw0d;                                                /* policy layer 0: the stoch / deter column blocks of its weight */
+  genrl_planes_ref pw[8]; const float* pb[8]; const float* pg[8]; const float* pbe[8]; float peps[8]; int pU[8];
+  float* ppre[8]; float* py[8]; float* pmean[8]; float* prstd[8]; genrl_planes_ref pyp[8];
+  const float* head_w; const float* head_b;
+} genrl_rollout;
+int genrl_imagine_seq_fwd(const genrl_rollout* r, void* stream);
 /* Weight-gradient product on the SAME planes (csrc/gemm_planes_tn.hip):  C[i, j] (+)= sum_m A(m, i) B(m, j) for h2 planes
  * A [2][M][a_ld] (columns i < NI) and B [2][M][b_ld] (columns j < NJ) with per-row inverse scales a_inv[M], b_inv[M] -- dW = dY^T X
  * (agent/dreamer_utils.py:739-747 backward) read against the planes' storage order through the transposing LDS read

@@ -514,3 +514,54 @@ def test_gemm_h2_tn_all_zero_gradient_gives_exact_zero(env):
     ref = dY.double().t() @ X.double()
     asum = dY.double().abs().t() @ X.double().abs()
     assert ((C.double() - ref).abs() <= 1e-6 * asum + 1e-8 * asum.mean()).all()
+
+
+@pytest.mark.parametrize('tiny', [True, False])
+def test_rollout_c_loop_is_the_python_loop(tiny, monkeypatch):
+    """genrl_imagine_seq_fwd (csrc/seq.hip): the plane rollout's H-step launch loop from ONE C call -- the same 16 launches per step in the
+    same order, so the imagination update's metrics and every actor / critic gradient are bit-identical to the per-launch Python loop
+    (tiny widths: 4-class latents, the separate sampling kernel; full width: 32 classes, the sample in the product's epilogue)"""
+    import detgen
+    from param_shapes import agent_param_shapes
+    from oracle import genrl_oracle as O
+    from genrl_amd import config, noise as gnoise, ops
+    from genrl_amd.agent import dreamer_utils as common
+    from test_gpu_iteration import FakeClip
+    BS, BL, A, H, seed = 4, 16, 10, 15, 3
+    S, K = (4, 4) if tiny else (32, 32)
+    wid = dict(deter=32, hidden=32, units=32, cnn_depth=4) if tiny else {}
+    ocfg = O.make_cfg(stoch=S, discrete=K, act_dim=A, horizon=H, **wid)
+    p = detgen.det_state_dict(agent_param_shapes(ocfg), seed)
+    gen = torch.Generator().manual_seed(seed)
+    Dd = 32 if tiny else 1024
+    idx = torch.randint(0, K, (BS, BL, S), generator=gen)
+    post = dict(stoch=torch.nn.functional.one_hot(idx, K).float(), deter=torch.tanh(torch.randn(BS, BL, Dd, generator=gen)),
+                logit=torch.randn(BS, BL, S, K, generator=gen))
+    nz = detgen.iteration_noise(BS, BL, S, K, A, H, seed=seed)['imag']
+
+    def run(flag):
+        monkeypatch.setattr(ops, 'SEQ_C', flag)
+        zero = dict(lr=0.0, wd=0.0)
+        cfg = config.default_cfg(BS, BL, device='cuda', imag_horizon=H, model_opt=zero, actor_opt=zero, critic_opt=zero,
+                                 **(config.tiny_overrides() if tiny else {}))
+        ag = config.make_agent(cfg, act_dim=A)
+        ag.load_state_dict({k: v.cuda() for k, v in p.items()})
+        ag.wm.viclip_model = FakeClip()
+        grads = {}
+        names = {id(q): n for n, q in ag.named_parameters()}
+        common.Optimizer.grad_hook = lambda opt, params: grads.__setitem__(opt, {names[id(q)]: q.grad.detach().clone() for q in params})
+        try:
+            with gnoise.inject({'imag.act_eps': nz['act_eps'], 'imag.step_q': nz['step_q'], 'imag.target_init_q': nz['target_init_q']}):
+                outputs = dict(post={k: v.cuda() for k, v in post.items()}, is_terminal=torch.zeros(BS, BL, device='cuda'))
+                _, mets = ag.update_imag_behavior(state=None, outputs=outputs, metrics={}, seq_data=None)
+        finally:
+            common.Optimizer.grad_hook = None
+        return {k: float(v) for k, v in mets.items()}, grads
+    seen = []
+    from genrl_amd._lib import lib
+    m1, g1 = run(True)
+    m0, g0 = run(False)
+    assert m1 == m0, {k: (m1[k], m0[k]) for k in m0 if m1[k] != m0[k]}
+    for ph in g0:
+        for n in g0[ph]:
+            assert torch.equal(g1[ph][n], g0[ph][n]), (ph, n)
