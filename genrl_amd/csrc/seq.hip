@@ -128,4 +128,45 @@ int genrl_imagine_seq_fwd(const genrl_rollout* r, void* st) {
   return GENRL_OK;
 }
 
+static inline int gemm1(const genrl_planes_ref& a, const genrl_planes_ref& b, float* C, long ldc, int M, int N, int accumulate, void* st) {
+  return genrl_gemm_h2(a.p, a.ld, a.plane, a.inv, b.p, b.ld, b.plane, b.inv, (int)a.ld, nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr, 0, C,
+                       ldc, nullptr, M, N, accumulate, st);
+}
+static inline int lnb_h2(const float* dy, const float* pre, const float* g, const float* be, const float* mean, const float* rstd, float* dpre,
+                         int M, int N, const genrl_planes_ref& P, void* st) {
+  return genrl_ln_act_bwd_h2(dy, N, pre, N, g, be, mean, rstd, dpre, N, nullptr, nullptr, nullptr, nullptr, M, N, 1, 0,
+                             const_cast<uint16_t*>(P.p), P.ld, P.plane, const_cast<float*>(P.inv), st);
+}
+
+int genrl_imagine_seq_bwd(const genrl_rollout_bwd* r, void* st) {
+  if (!r || r->H <= 0 || r->N <= 0) return GENRL_EINVAL;
+  const int H = r->H, N = r->N, D = r->D, A = r->A, AP = r->AP, U = r->U;
+  const long SK = (long)r->S * r->K;
+  float* cur = r->dha; float* nxt = nullptr;
+  for (int h = H - 1; h >= 0; --h) {
+    const long r0 = (long)h * N, r1 = r0 + N;
+    // grad wrt stoch_{h+1} (complete in ds[h+1]) -> logits (straight-through), plus any direct logit gradient
+    if (r->dl_in && hipMemcpyAsync(r->dlg, r->dl_in + r1 * SK, sizeof(float) * N * SK, hipMemcpyDeviceToDevice, (hipStream_t)st) != hipSuccess)
+      return GENRL_ELAUNCH;
+    RC(genrl_onehot_bwd_h2(r->logit + r1 * SK, r->ds + r1 * SK, r->dlg, (long)N * r->S, r->K, r->unimix, r->dl_in ? 1 : 0,
+                           const_cast<uint16_t*>(r->dlg_p.p), (int)SK, r->dlg_p.ld, r->dlg_p.plane, const_cast<float*>(r->dlg_p.inv), st));
+    RC(gemm1(r->dlg_p, r->wt_dist, r->dov, U, N, U, 0, st));
+    RC(lnb_h2(r->dov, r->o_pre + r0 * U, r->out_g, r->out_be, r->om + r0, r->orr + r0, r->do_pre, N, U, r->dop_p, st));
+    RC(gemm1(r->dop_p, r->wt_out, r->dd + r1 * D, D, N, D, 1, st));
+    // GRU: upstream = dd[h+1] (+ the recurrent part from step h+1's GRU, held in `nxt`)
+    RC(genrl_gru_gates_bwd_h2(r->dd + r1 * D, D, nxt, nullptr, r->g_pre + r0 * 3 * D, r->deter + r0 * D, D, r->gru_g, r->gru_be, r->gm + r0,
+                              r->gr + r0, r->dg_pre, cur, D, nullptr, nullptr, nullptr, N, D, 0, nullptr, 0, 0,
+                              const_cast<uint16_t*>(r->dg_p.p), r->dg_p.ld, r->dg_p.plane, const_cast<float*>(r->dg_p.inv), st));
+    RC(gemm1(r->dg_p, r->wt_g_h, cur, D, N, D, 1, st));
+    RC(gemm1(r->dg_p, r->wt_g_x, r->dx, U, N, U, 0, st));
+    RC(lnb_h2(r->dx, r->x_pre + r0 * U, r->in_g, r->in_be, r->xm + r0, r->xr + r0, r->dx_pre, N, U, r->dxp_p, st));
+    RC(gemm1(r->dxp_p, r->wt_in_s, r->ds + r0 * SK, SK, N, (int)SK, 1, st));
+    // d action_{h+1} = dx_pre W_a (+ upstream) and the head's backward -> d raw_h: one launch
+    RC(genrl_actor_head_linear_bwd(r->dx_pre, U, r->waT, r->dact_all ? r->dact_all + r1 * AP : nullptr, AP, r->raws + r0 * 2 * A,
+                                   r->eps + r0 * A, r->d_raw + r0 * 2 * A, N, U, A, r->min_std, r->max_std, st));
+    nxt = cur; cur = (cur == r->dha) ? r->dhb : r->dha;
+  }
+  return GENRL_OK;
+}
+
 }  // extern "C"

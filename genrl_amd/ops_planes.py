@@ -42,6 +42,14 @@ class _RolloutArgs(_ct.Structure):
                    ('pyp', _PRef * 8), ('head_w', _FP), ('head_b', _FP)])
 
 
+class _RolloutBwdArgs(_ct.Structure):
+    _fields_ = ([(n, _I) for n in ('H', 'N', 'S', 'K', 'D', 'A', 'AP', 'U')] + [(n, _F) for n in ('unimix', 'min_std', 'max_std')]
+                + [(n, _FP) for n in ('logit', 'deter', 'raws', 'eps', 'x_pre', 'g_pre', 'o_pre', 'xm', 'xr', 'gm', 'gr', 'om', 'orr',
+                                      'ds', 'dd', 'dl_in', 'dact_all', 'd_raw', 'dlg', 'dov', 'do_pre', 'dg_pre', 'dx', 'dx_pre', 'dha', 'dhb')]
+                + [(n, _PRef) for n in ('dlg_p', 'dop_p', 'dg_p', 'dxp_p', 'wt_dist', 'wt_out', 'wt_g_x', 'wt_g_h', 'wt_in_s')]
+                + [(n, _FP) for n in ('waT', 'out_g', 'out_be', 'gru_g', 'gru_be', 'in_g', 'in_be')])
+
+
 def _pref(P):
     return _PRef(P.t.data_ptr(), P.ld, P.plane, P.inv.data_ptr())
 
@@ -277,7 +285,24 @@ class _RolloutPlanes(Function):
         if da_in is not None:                 # upstream action gradients, once, in rows padded like the forward's actions
             dact_all = torch.zeros(H + 1, N, AP, device=dev)
             dact_all[:, :, :A].copy_(da_in)
-        for h in range(H - 1, -1, -1):
+        seq_c = ops.SEQ_C and planes.gemm_profile is None
+        if seq_c:
+            # the dgrad chain's launch loop in C (csrc/seq.hip: genrl_imagine_seq_bwd -- the loop below, launch for launch)
+            a = _RolloutBwdArgs()
+            a.H, a.N, a.S, a.K, a.D, a.A, a.AP, a.U = H, N, S, K, D, A, AP, U
+            a.unimix, a.min_std, a.max_std = UNIMIX, sp.min_std, sp.max_std
+            for n_, t_ in (('logit', logit), ('deter', deter), ('raws', raws), ('eps', eps), ('x_pre', x_pre), ('g_pre', g_pre), ('o_pre', o_pre),
+                           ('xm', st['xm']), ('xr', st['xr']), ('gm', st['gm']), ('gr', st['gr']), ('om', st['om']), ('orr', st['or']),
+                           ('ds', ds), ('dd', dd), ('dl_in', dl_in), ('dact_all', dact_all), ('d_raw', tape.d_raw), ('dlg', dlg), ('dov', do),
+                           ('do_pre', do_pre), ('dg_pre', dg_pre), ('dx', dx), ('dx_pre', dx_pre), ('dha', dha), ('dhb', dhb), ('waT', waT),
+                           ('out_g', sp.out_g), ('out_be', sp.out_be), ('gru_g', sp.gru_g), ('gru_be', sp.gru_be), ('in_g', sp.in_g),
+                           ('in_be', sp.in_be)):
+                setattr(a, n_, _p(t_))
+            for n_, P_ in (('dlg_p', dlg_p), ('dop_p', dop_p), ('dg_p', dg_p), ('dxp_p', dxp_p), ('wt_dist', wt_dist), ('wt_out', wt_out),
+                           ('wt_g_x', wt_g_x), ('wt_g_h', wt_g_h), ('wt_in_s', wt_in_s)):
+                setattr(a, n_, _pref(P_))
+            check(L.genrl_imagine_seq_bwd(_ct.addressof(a), _stream()), 'imagine_seq_bwd')
+        for h in (() if seq_c else range(H - 1, -1, -1)):
             r0, r1 = h * N, (h + 1) * N
             if dl_in is not None:
                 dlg.copy_(dl_in[h + 1])

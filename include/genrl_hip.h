@@ -225,6 +225,23 @@ typedef struct {
   const float* head_w; const float* head_b;
 } genrl_rollout;
 int genrl_imagine_seq_fwd(const genrl_rollout* r, void* stream);
+/* ... and its backward through the frozen dynamics (the dgrad chain of _RolloutPlanes.backward, 10 launches per step, same order): ds / dd
+ * (H+1,N,S K) / (H+1,N,D) hold the upstream state gradients on entry and the complete ones on return; dl_in: upstream logit gradients
+ * (H+1,N,S K) or NULL; dact_all: upstream action gradients in padded rows (H+1,N,AP) or NULL; d_raw (H,N,2A): the policy output's
+ * gradient per step (handed to the policy's batched backward).  Scratch: dlg, dov, do_pre, dg_pre, dx, dx_pre + their planes, dha / dhb. */
+typedef struct {
+  int H, N, S, K, D, A, AP, U;
+  float unimix, min_std, max_std;
+  const float* logit; const float* deter; const float* raws; const float* eps; const float* x_pre; const float* g_pre; const float* o_pre;
+  const float* xm; const float* xr; const float* gm; const float* gr; const float* om; const float* orr;
+  float* ds; float* dd; const float* dl_in; const float* dact_all; float* d_raw;
+  float* dlg; float* dov; float* do_pre; float* dg_pre; float* dx; float* dx_pre; float* dha; float* dhb;
+  genrl_planes_ref dlg_p, dop_p, dg_p, dxp_p;
+  genrl_planes_ref wt_dist, wt_out, wt_g_x, wt_g_h, wt_in_s;
+  const float* waT;
+  const float* out_g; const float* out_be; const float* gru_g; const float* gru_be; const float* in_g; const float* in_be;
+} genrl_rollout_bwd;
+int genrl_imagine_seq_bwd(const genrl_rollout_bwd* r, void* stream);
 /* Weight-gradient product on the SAME planes (csrc/gemm_planes_tn.hip):  C[i, j] (+)= sum_m A(m, i) B(m, j) for h2 planes
  * A [2][M][a_ld] (columns i < NI) and B [2][M][b_ld] (columns j < NJ) with per-row inverse scales a_inv[M], b_inv[M] -- dW = dY^T X
  * (agent/dreamer_utils.py:739-747 backward) read against the planes' storage order through the transposing LDS read
