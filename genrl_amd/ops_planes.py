@@ -254,7 +254,9 @@ class _RolloutPlanes(Function):
         ctx.bufs = (stoch, deter, logit, raws, eps, x_pre, g_pre, o_pre, st)
         ctx.nparams = len(actor_params)
         ctx.dims = (H, N, S, K, D, A, U)
-        return stoch.reshape(H + 1, N, S, K), deter, logit.reshape(H + 1, N, S, K), action[:, :, :A], raws
+        # (views, never the buffers themselves: ctx.bufs holds `deter` and `raws`, and an OUTPUT tensor kept on ctx is a reference cycle
+        # through its grad_fn that Python's collector cannot see -- every eager iteration's rollout buffers, 1.4 GiB, stayed alive)
+        return stoch.reshape(H + 1, N, S, K), deter.view(H + 1, N, D), logit.reshape(H + 1, N, S, K), action[:, :, :A], raws.view(H, N, 2 * A)
 
     @staticmethod
     def backward(ctx, d_stoch, d_deter, d_logit, d_action, d_raws):
