@@ -169,4 +169,79 @@ int genrl_imagine_seq_bwd(const genrl_rollout_bwd* r, void* st) {
   return GENRL_OK;
 }
 
+// ---- the fp32-operand rollout (genrl_amd/ops.py::_Rollout is the Python twin)
+static inline int sg(const genrl_rollout_f32* r, const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks, float* C, long ldc,
+                     const float* bias, int M, int N, int K, int acc, void* st) {
+  if (genrl_sgemm_ws_floats(M, N, K) > r->ws_floats) return GENRL_EINVAL;
+  return genrl_sgemm(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, acc, r->ws, r->ws_floats, st);
+}
+
+int genrl_imagine_seq_f32_fwd(const genrl_rollout_f32* r, void* st) {
+  if (!r || r->H <= 0 || r->N <= 0 || r->L < 1 || r->L > 8) return GENRL_EINVAL;
+  const int H = r->H, N = r->N, D = r->D, A = r->A, AP = r->AP, U = r->U, L = r->L;
+  const int SK = r->S * r->K, Kg = U + D;
+  for (int h = 0; h < H; ++h) {
+    const long r0 = (long)h * N, r1 = r0 + N;
+    const float* prev = nullptr; int Kx = 0;
+    for (int l = 0; l < L; ++l) {
+      const int Ul = r->pU[l];
+      float* pre = r->ppre[l] + r0 * Ul;
+      if (l == 0) {
+        const int K0 = SK + D;
+        RC(sg(r, r->stoch + r0 * SK, SK, 1, r->pw[0], K0, 1, pre, Ul, r->pb[0], N, Ul, SK, 0, st));
+        RC(sg(r, r->deter + r0 * D, D, 1, r->pw[0] + SK, K0, 1, pre, Ul, nullptr, N, Ul, D, 1, st));
+      } else {
+        RC(sg(r, prev, Kx, 1, r->pw[l], Kx, 1, pre, Ul, r->pb[l], N, Ul, Kx, 0, st));
+      }
+      RC(genrl_ln_act_fwd(pre, Ul, r->pg[l], r->pbe[l], r->py[l] + r0 * Ul, Ul, r->pmean[l] + r0, r->prstd[l] + r0, N, Ul, r->peps[l], 1, st));
+      prev = r->py[l] + r0 * Ul; Kx = Ul;
+    }
+    RC(genrl_actor_head_linear_fwd(prev, Kx, r->head_w, r->head_b, r->eps + r0 * A, r->raws + r0 * 2 * A, r->action + r1 * AP, N, Kx, A,
+                                   r->min_std, r->max_std, AP, nullptr, 0, 0, nullptr, st));
+    // img_in: [stoch_h | action_{h+1}] -> hidden, LN + SiLU
+    RC(sg(r, r->stoch + r0 * SK, SK, 1, r->ws_in, SK, 1, r->x_pre + r0 * U, U, r->in_b, N, U, SK, 0, st));
+    RC(sg(r, r->action + r1 * AP, AP, 1, r->wa, AP, 1, r->x_pre + r0 * U, U, nullptr, N, U, AP, 1, st));
+    RC(genrl_ln_act_fwd(r->x_pre + r0 * U, U, r->in_g, r->in_be, r->x + r0 * U, U, r->xm + r0, r->xr + r0, N, U, r->in_eps, 1, st));
+    // GRU
+    RC(sg(r, r->x + r0 * U, U, 1, r->gru_w, Kg, 1, r->g_pre + r0 * 3 * D, 3 * D, nullptr, N, 3 * D, U, 0, st));
+    RC(sg(r, r->deter + r0 * D, D, 1, r->gru_w + U, Kg, 1, r->g_pre + r0 * 3 * D, 3 * D, nullptr, N, 3 * D, D, 1, st));
+    RC(genrl_gru_gates_fwd(r->g_pre + r0 * 3 * D, r->deter + r0 * D, D, r->gru_g, r->gru_be, r->deter + r1 * D, D, nullptr, nullptr, r->gm + r0,
+                           r->gr + r0, N, D, 1e-5f, st));
+    // prior head: img_out (+ LN + SiLU), dist, sample
+    RC(sg(r, r->deter + r1 * D, D, 1, r->out_w, D, 1, r->o_pre + r0 * U, U, r->out_b, N, U, D, 0, st));
+    RC(genrl_ln_act_fwd(r->o_pre + r0 * U, U, r->out_g, r->out_be, r->o + r0 * U, U, r->om + r0, r->orr + r0, N, U, r->out_eps, 1, st));
+    RC(sg(r, r->o + r0 * U, U, 1, r->dist_w, U, 1, r->logit + r1 * SK, SK, r->dist_b, N, SK, U, 0, st));
+    RC(genrl_onehot_fwd(r->logit + r1 * SK, r->q + r0 * SK, r->stoch + r1 * SK, nullptr, (long)N * r->S, r->K, r->unimix, st));
+  }
+  return GENRL_OK;
+}
+
+int genrl_imagine_seq_f32_bwd(const genrl_rollout_f32* r, void* st) {
+  if (!r || r->H <= 0 || r->N <= 0) return GENRL_EINVAL;
+  const int H = r->H, N = r->N, D = r->D, A = r->A, AP = r->AP, U = r->U;
+  const int SK = r->S * r->K, Kg = U + D;
+  float* cur = r->dha; float* nxt = nullptr;
+  for (int h = H - 1; h >= 0; --h) {
+    const long r0 = (long)h * N, r1 = r0 + N;
+    if (r->dl_in && hipMemcpyAsync(r->dlg, r->dl_in + r1 * SK, sizeof(float) * (size_t)N * SK, hipMemcpyDeviceToDevice, (hipStream_t)st) != hipSuccess)
+      return GENRL_ELAUNCH;
+    RC(genrl_onehot_bwd(r->logit + r1 * SK, r->ds + r1 * SK, r->dlg, (long)N * r->S, r->K, r->unimix, r->dl_in ? 1 : 0, st));
+    RC(sg(r, r->dlg, SK, 1, r->dist_w, 1, U, r->dov, U, nullptr, N, U, SK, 0, st));
+    RC(genrl_ln_act_bwd(r->dov, U, r->o_pre + r0 * U, U, r->out_g, r->out_be, r->om + r0, r->orr + r0, r->do_pre, U, nullptr, nullptr, nullptr,
+                        nullptr, N, U, 1, 0, st));
+    RC(sg(r, r->do_pre, U, 1, r->out_w, 1, D, r->dd + r1 * D, D, nullptr, N, D, U, 1, st));
+    RC(genrl_gru_gates_bwd(r->dd + r1 * D, D, nxt, nullptr, r->g_pre + r0 * 3 * D, r->deter + r0 * D, D, r->gru_g, r->gru_be, r->gm + r0, r->gr + r0,
+                           r->dg_pre, cur, D, nullptr, nullptr, nullptr, N, D, 0, nullptr, 0, 0, st));
+    RC(sg(r, r->dg_pre, 3 * D, 1, r->gru_w + U, 1, Kg, cur, D, nullptr, N, D, 3 * D, 1, st));
+    RC(sg(r, r->dg_pre, 3 * D, 1, r->gru_w, 1, Kg, r->dx, U, nullptr, N, U, 3 * D, 0, st));
+    RC(genrl_ln_act_bwd(r->dx, U, r->x_pre + r0 * U, U, r->in_g, r->in_be, r->xm + r0, r->xr + r0, r->dx_pre, U, nullptr, nullptr, nullptr, nullptr,
+                        N, U, 1, 0, st));
+    RC(sg(r, r->dx_pre, U, 1, r->ws_in, 1, SK, r->ds + r0 * SK, SK, nullptr, N, SK, U, 1, st));
+    RC(genrl_actor_head_linear_bwd(r->dx_pre, U, r->waT, r->dact_all ? r->dact_all + r1 * AP : nullptr, AP, r->raws + r0 * 2 * A, r->eps + r0 * A,
+                                   r->d_raw + r0 * 2 * A, N, U, A, r->min_std, r->max_std, st));
+    nxt = cur; cur = (cur == r->dha) ? r->dhb : r->dha;
+  }
+  return GENRL_OK;
+}
+
 }  // extern "C"

@@ -865,6 +865,48 @@ def fused_small_ok(N, U, dims4=()):
             and lib().genrl_gemm_precision() != 1)
 
 
+# ---- genrl_rollout_f32 (include/genrl_hip.h): the arguments of the fp32-operand rollout's launch loops in C (csrc/seq.hip)
+_FP, _CF, _CI = ctypes.c_void_p, ctypes.c_float, ctypes.c_int
+
+
+class _RolloutF32Args(ctypes.Structure):
+    _fields_ = ([(n, _CI) for n in ('H', 'N', 'S', 'K', 'D', 'A', 'AP', 'U', 'L')] + [(n, _CF) for n in ('unimix', 'min_std', 'max_std')]
+                + [(n, _FP) for n in ('stoch', 'deter', 'logit', 'action', 'raws', 'eps', 'q', 'x_pre', 'x', 'g_pre', 'o_pre', 'o',
+                                      'xm', 'xr', 'gm', 'gr', 'om', 'orr', 'ws_in', 'wa', 'gru_w', 'out_w', 'dist_w')]
+                + [('in_b', _FP), ('in_g', _FP), ('in_be', _FP), ('in_eps', _CF), ('gru_g', _FP), ('gru_be', _FP),
+                   ('out_b', _FP), ('out_g', _FP), ('out_be', _FP), ('out_eps', _CF), ('dist_b', _FP),
+                   ('pw', _FP * 8), ('pb', _FP * 8), ('pg', _FP * 8), ('pbe', _FP * 8), ('peps', _CF * 8), ('pU', _CI * 8),
+                   ('ppre', _FP * 8), ('py', _FP * 8), ('pmean', _FP * 8), ('prstd', _FP * 8), ('head_w', _FP), ('head_b', _FP),
+                   ('ws', _FP), ('ws_floats', ctypes.c_long)]
+                + [(n, _FP) for n in ('ds', 'dd', 'dl_in', 'dact_all', 'd_raw', 'dlg', 'dov', 'do_pre', 'dg_pre', 'dx', 'dx_pre', 'dha', 'dhb', 'waT')])
+
+
+def _rollout_f32_args(sp, tape, dims, bufs, ws_in, wa, x=None, o=None, eps=None, q=None):
+    """the fields both directions share; -> (args, the workspace tensor that must outlive the call)"""
+    H, N, S, K, D, A, U, AP = dims
+    stoch, deter, logit, action, raws, x_pre, g_pre, o_pre, st = bufs
+    a = _RolloutF32Args()
+    a.H, a.N, a.S, a.K, a.D, a.A, a.AP, a.U, a.L = H, N, S, K, D, A, AP, U, len(tape.layers)
+    a.unimix, a.min_std, a.max_std = UNIMIX, sp.min_std, sp.max_std
+    for n_, t_ in (('stoch', stoch), ('deter', deter), ('logit', logit), ('action', action), ('raws', raws), ('eps', eps), ('q', q), ('x_pre', x_pre),
+                   ('x', x), ('g_pre', g_pre), ('o_pre', o_pre), ('o', o), ('xm', st['xm']), ('xr', st['xr']), ('gm', st['gm']), ('gr', st['gr']),
+                   ('om', st['om']), ('orr', st['or']), ('ws_in', ws_in), ('wa', wa), ('gru_w', sp.gru_w), ('out_w', sp.out_w), ('dist_w', sp.dist_w),
+                   ('in_b', sp.in_b), ('in_g', sp.in_g), ('in_be', sp.in_be), ('gru_g', sp.gru_g), ('gru_be', sp.gru_be), ('out_b', sp.out_b),
+                   ('out_g', sp.out_g), ('out_be', sp.out_be), ('dist_b', sp.dist_b), ('head_w', tape.head_w), ('head_b', tape.head_b)):
+        setattr(a, n_, _p(t_))
+    a.in_eps, a.out_eps = sp.in_eps, sp.out_eps
+    for l, (W_, b_, ga_, be_, eps_) in enumerate(tape.layers):
+        a.pw[l], a.pb[l], a.pg[l], a.pbe[l], a.peps[l], a.pU[l] = _p(W_), _p(b_), _p(ga_), _p(be_), eps_, W_.shape[0]
+        a.ppre[l], a.py[l], a.pmean[l], a.prstd[l] = _p(tape.pre[l]), _p(tape.y[l]), _p(tape.mean[l]), _p(tape.rstd[l])
+    SK = S * K
+    shapes = [(N, U, SK), (N, U, D), (N, U, U), (N, U, AP), (N, 3 * D, U), (N, 3 * D, D), (N, SK, U), (N, D, U), (N, D, 3 * D), (N, U, 3 * D)]
+    shapes += [(N, l_[0].shape[0], l_[0].shape[0]) for l_ in tape.layers]
+    nws = max(lib().genrl_sgemm_ws_floats(*s_) for s_ in shapes)
+    ws = torch.empty(max(nws, 1), device=deter.device)
+    a.ws, a.ws_floats = ws.data_ptr(), nws
+    return a, ws
+
+
 # ------------------------------------------------------------------ policy over an imagination rollout
 
 class ActorTape:
@@ -1128,7 +1170,13 @@ class _Rollout(Function):
                         ln=(so.data_ptr(), U // 16, sp.out_g, sp.out_be, sp.out_eps), bias=sp.dist_b)
             check(lib().genrl_onehot_fwd(pt(logit, sN + N * SK), pt(q, h * N * SK), pt(stoch, sN + N * SK), None, N * S, K,
                                          UNIMIX, _stream()), 'onehot_fwd')
-        for h in (() if fused else range(H)):
+        seq_c = SEQ_C and not fused and gemm_profile is None and len(tape.layers) <= 8
+        if seq_c:
+            # the H-step launch loop in C (csrc/seq.hip: genrl_imagine_seq_f32_fwd -- the loop below, launch for launch)
+            a, ws_keep = _rollout_f32_args(sp, tape, (H, N, S, K, D, A, U, AP), (stoch, deter, logit, action, raws, x_pre, g_pre, o_pre, st),
+                                           ws_in, wa, x=x, o=o, eps=eps, q=q)
+            check(lib().genrl_imagine_seq_f32_fwd(ctypes.addressof(a), _stream()), 'imagine_seq_f32_fwd')
+        for h in (() if (fused or seq_c) else range(H)):
             sN, dN = h * N * SK, h * N * D
             tape._forward(h, stoch[h], deter[h], head=False)
             tape.head_fused(h, pt(eps, h * N * A), pt(raws, h * N * 2 * A), pt(action, (h + 1) * N * AP), AP, sp.min_std, sp.max_std)
@@ -1189,7 +1237,15 @@ class _Rollout(Function):
             scratch = f(H * N, U)
             _ln_fwd_raw(_p(x_pre), sp.in_g, sp.in_be, _p(scratch), _p(st['xm']), _p(st['xr']), H * N, U, sp.in_eps)
             _ln_fwd_raw(_p(o_pre), sp.out_g, sp.out_be, _p(scratch), _p(st['om']), _p(st['or']), H * N, U, sp.out_eps)
-        for h in range(H - 1, -1, -1):
+        seq_c = SEQ_C and gemm_profile is None and len(tape.layers) <= 8
+        if seq_c:
+            a, ws_keep = _rollout_f32_args(sp, tape, (H, N, S, K, D, A, U, AP), (None, deter, logit, None, raws, x_pre, g_pre, o_pre, st),
+                                           ws_in, wa, eps=eps)
+            for n_, t_ in (('ds', ds), ('dd', dd), ('dl_in', dl_in), ('dact_all', dact_all), ('d_raw', tape.d_raw), ('dlg', dlg), ('dov', do),
+                           ('do_pre', do_pre), ('dg_pre', dg_pre), ('dx', dx), ('dx_pre', dx_pre), ('dha', dha), ('dhb', dhb), ('waT', waT)):
+                setattr(a, n_, _p(t_))
+            check(lib().genrl_imagine_seq_f32_bwd(ctypes.addressof(a), _stream()), 'imagine_seq_f32_bwd')
+        for h in (() if seq_c else range(H - 1, -1, -1)):
             sN, dN = h * N * SK, h * N * D
             # grad wrt stoch_{h+1} (complete in ds[h+1]) -> logits (straight-through), plus any direct logit gradient
             if dl_in is not None:

@@ -242,6 +242,30 @@ typedef struct {
   const float* out_g; const float* out_be; const float* gru_g; const float* gru_be; const float* in_g; const float* in_be;
 } genrl_rollout_bwd;
 int genrl_imagine_seq_bwd(const genrl_rollout_bwd* r, void* stream);
+/* The same two loops for the fp32-OPERAND rollout (genrl_amd/ops.py::_Rollout: fewer than GENRL_PLANES_MIN_ROWS rows -- the per-GPU sizes
+ * under data parallelism): 20 launches per step forward, 14 backward, launch for launch what the Python loops issue (bit-identical).
+ * Weights are fp32 matrices here: ws_in (U, S K) / wa (U, AP) = the stoch / padded-action column blocks of img_in's weight, gru_w (3D, U + D),
+ * out_w (U, D), dist_w (S K, U), policy layers pw[l] (pU[l], K_l; layer 0: (U, S K + D)), waT (A, U).  ws / ws_floats: workspace for the
+ * split-K products (>= the largest genrl_sgemm_ws_floats of the loop's shapes; checked).  Backward fields as in genrl_rollout_bwd. */
+typedef struct {
+  int H, N, S, K, D, A, AP, U, L;
+  float unimix, min_std, max_std;
+  float* stoch; float* deter; float* logit; float* action; float* raws; const float* eps; const float* q;
+  float* x_pre; float* x; float* g_pre; float* o_pre; float* o;                        /* (H,N,U) (H,N,U) (H,N,3D) (H,N,U) (H,N,U) */
+  float* xm; float* xr; float* gm; float* gr; float* om; float* orr;
+  const float* ws_in; const float* wa; const float* gru_w; const float* out_w; const float* dist_w;
+  const float* in_b; const float* in_g; const float* in_be; float in_eps; const float* gru_g; const float* gru_be;
+  const float* out_b; const float* out_g; const float* out_be; float out_eps; const float* dist_b;
+  const float* pw[8]; const float* pb[8]; const float* pg[8]; const float* pbe[8]; float peps[8]; int pU[8];
+  float* ppre[8]; float* py[8]; float* pmean[8]; float* prstd[8];
+  const float* head_w; const float* head_b;
+  float* ws; long ws_floats;
+  /* backward only */
+  float* ds; float* dd; const float* dl_in; const float* dact_all; float* d_raw;
+  float* dlg; float* dov; float* do_pre; float* dg_pre; float* dx; float* dx_pre; float* dha; float* dhb; const float* waT;
+} genrl_rollout_f32;
+int genrl_imagine_seq_f32_fwd(const genrl_rollout_f32* r, void* stream);
+int genrl_imagine_seq_f32_bwd(const genrl_rollout_f32* r, void* stream);
 /* Weight-gradient product on the SAME planes (csrc/gemm_planes_tn.hip):  C[i, j] (+)= sum_m A(m, i) B(m, j) for h2 planes
  * A [2][M][a_ld] (columns i < NI) and B [2][M][b_ld] (columns j < NJ) with per-row inverse scales a_inv[M], b_inv[M] -- dW = dY^T X
  * (agent/dreamer_utils.py:739-747 backward) read against the planes' storage order through the transposing LDS read

@@ -516,11 +516,16 @@ def test_gemm_h2_tn_all_zero_gradient_gives_exact_zero(env):
     assert ((C.double() - ref).abs() <= 1e-6 * asum + 1e-8 * asum.mean()).all()
 
 
+@pytest.mark.parametrize('fp32_path', [False, True])
 @pytest.mark.parametrize('tiny', [True, False])
-def test_rollout_c_loop_is_the_python_loop(tiny, monkeypatch):
+def test_rollout_c_loop_is_the_python_loop(tiny, fp32_path, monkeypatch):
     """genrl_imagine_seq_fwd (csrc/seq.hip): the plane rollout's H-step launch loop from ONE C call -- the same 16 launches per step in the
     same order, so the imagination update's metrics and every actor / critic gradient are bit-identical to the per-launch Python loop
-    (tiny widths: 4-class latents, the separate sampling kernel; full width: 32 classes, the sample in the product's epilogue)"""
+    (tiny widths: 4-class latents, the separate sampling kernel; full width: 32 classes, the sample in the product's epilogue).
+    fp32_path: the fp32-operand rollout of the product's default policy below 512 rows (genrl_imagine_seq_f32_fwd / _bwd, 20 + 14 launches
+    per step) instead of the plane rollout the suite forces on everywhere else"""
+    if fp32_path:
+        monkeypatch.delenv('GENRL_PLANES_MIN_ROWS', raising=False)
     import detgen
     from param_shapes import agent_param_shapes
     from oracle import genrl_oracle as O
