@@ -11,8 +11,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(extra, port):
-    env = dict(os.environ, GENRL_DP_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1')
+def _launch(extra, port, **more_env):
+    env = dict(os.environ, GENRL_DP_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1', **more_env)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
            '--batch', '4', '--length', '16', '--no-cpu-baseline'] + extra
@@ -39,3 +39,19 @@ def test_bench_two_ranks_on_one_gpu(graph):
     else:
         assert launch == 'eager', launch
     assert 'ranks disagree' not in err, err[-2000:]
+
+
+@pytest.mark.parametrize('watchdog_s', ['240', '0.001'])
+def test_bench_in_graph_attempt_cannot_lose_the_line(watchdog_s):
+    """With RCCL the bench measures the cut mode first and THEN tries the collectives inside the graph, under a watchdog.  Forced here on
+    the gloo rig (GENRL_BENCH_FORCE_INGRAPH=1), where an in-graph collective cannot work: either the attempt raises and the cut-mode line
+    is printed as usual, or gloo's worker thread ABORTS the process (what happens on this ROCm build) and the C-level last-line handler writes the
+    cut-mode line (watchdog 240 s); or the watchdog fires first (1 ms) and rank 0 prints the cut-mode line it holds; every rank exits 0."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs MI355X')
+    out, err = _launch(['--graph', 'auto'], 29830 + os.getpid() % 50 + (0 if watchdog_s == '240' else 60),
+                       GENRL_BENCH_FORCE_INGRAPH='1', GENRL_INGRAPH_WATCHDOG_S=watchdog_s)
+    assert out['n_gpus'] == 2 and out['value'] > 0
+    assert 'collectives cut' in out['config']['launch'], out['config']['launch']
+    if watchdog_s != '240':
+        assert 'in-graph' in out.get('note', ''), out.get('note')
