@@ -424,6 +424,16 @@ class Decoder(Module):  # ref :631-715
 
 # ----------------------------------------------------------------------------- RSSM
 
+def _scan_noise(site, step_site, T, rows, K, dev):
+    """Exp(1) noise of a whole scan, (T, rows, K).  Tests that replay the reference's per-step draws inject them under the step
+    site's name (one tensor per obs_step call, `rssm.post` / `rssm.prior`): those are stacked in call order."""
+    inj = noise._injected
+    if inj is not None and site not in inj and step_site in inj:
+        return torch.stack([noise.draw('exp', step_site, (rows, K), dev) for _ in range(T)], 0)
+    return noise.draw('exp', site, (T, rows, K), dev)
+
+
+
 class EnsembleRSSM(Module):  # ref :302-555
     def __init__(self, ensemble=5, stoch=30, deter=200, hidden=200, discrete=False, act='SiLU', norm='none',
                  std_act='softplus', min_std=0.1, action_dim=None, embed_dim=1536, device='cuda',
@@ -524,7 +534,9 @@ class EnsembleRSSM(Module):  # ref :302-555
         sequential (ops.gru_seq).  Without it, falls back to the step-by-step form."""
         B, T = action.shape[:2]
         if not self.single_obs_posterior:
-            return self._observe_stepwise(embed, action, is_first, state)
+            if os.environ.get('GENRL_OBSERVE_SEQ', '1') == '0':
+                return self._observe_stepwise(embed, action, is_first, state)
+            return self._observe_scan(embed, action, is_first, state)
         S, K = self._stoch, self._discrete
         dev = embed.device
         tm = lambda x: x.transpose(0, 1).contiguous()                          # (B,T,..) -> (T,B,..)
@@ -553,6 +565,33 @@ class EnsembleRSSM(Module):  # ref :302-555
         prior = {'stoch': bm(qst), 'deter': bm(deter), 'logit': bm(qlog)}
         return post, prior
 
+    def _observe_scan(self, embed, action, is_first, state=None):
+        """ref :362-371 with the posterior on [deter, embed] (`single_obs_posterior: false`, conf/defaults/dreamer_v3.yaml:5): the
+        sampled latent is inside the recurrence.  ONE autograd node (ops.observe_seq): the action half of `_img_in` and the embed half
+        of `_obs_out` are batched over T, the remaining chain is eight launches per step each way from C (csrc/seq.hip); the prior head
+        does not feed the recurrence and runs on all T * B rows afterwards."""
+        B, T = action.shape[:2]
+        S, K = self._stoch, self._discrete
+        dev = embed.device
+        tm = lambda x: x.transpose(0, 1).contiguous()                          # (B,T,..) -> (T,B,..)
+        emb, act, first = tm(embed), tm(action), tm(is_first)
+        mask = (1.0 - first.float()).contiguous()                              # (T,B)
+        st0 = state if state is not None else self.initial(B)
+        q_post = _scan_noise('wm.post_q', 'rssm.post', T, B * S, K, dev)
+        q_prior = _scan_noise('wm.prior_q', 'rssm.prior', T, B * S, K, dev)
+        lin_i, ln_i = self._img_in[0], self._img_in[1]._layer
+        lin_o, ln_o = self._obs_out[0], self._obs_out[1]._layer
+        deter, plog, pst = ops.observe_seq(
+            emb, act, mask, st0['stoch'].reshape(B, S * K), st0['deter'], q_post,
+            lin_i.weight, lin_i.bias, ln_i.weight, ln_i.bias, self._cell._layer.weight, self._cell._norm.weight, self._cell._norm.bias,
+            lin_o.weight, lin_o.bias, ln_o.weight, ln_o.bias, self._obs_dist.weight, self._obs_dist.bias, ln_i.eps, ln_o.eps)
+        qlog = self._prior_logits(deter.reshape(T * B, -1)).reshape(T, B, S, K)
+        qst = ops.onehot_sample(qlog, q_prior)
+        bm = lambda x: x.transpose(0, 1)
+        post = {'stoch': bm(pst.reshape(T, B, S, K)), 'deter': bm(deter), 'logit': bm(plog.reshape(T, B, S, K))}
+        prior = {'stoch': bm(qst), 'deter': bm(deter), 'logit': bm(qlog)}
+        return post, prior
+
     def _observe_stepwise(self, embed, action, is_first, state=None):
         B, T = action.shape[:2]
         state = state if state is not None else self.initial(B)
@@ -567,6 +606,20 @@ class EnsembleRSSM(Module):  # ref :302-555
         """ref :373-381: prior rollout for given actions (B,T,A)."""
         B, T = action.shape[:2]
         state = state if state is not None else self.initial(B)
+        if not torch.is_grad_enabled() and action.is_cuda and os.environ.get('GENRL_OBSERVE_SEQ', '1') != '0':
+            # forward only (the data-free block's warm-up rollouts, report, video_imagine all run under no_grad): the action half of
+            # `_img_in` batched over T, the eight launches per step of the remaining chain from ONE host call (csrc/seq.hip)
+            S, K = self._stoch, self._discrete
+            lin_i, ln_i = self._img_in[0], self._img_in[1]._layer
+            lin_o, ln_o = self._ensemble_img_out[0][0], self._ensemble_img_out[0][1]._layer
+            q = _scan_noise('rssm.imagine_q', 'rssm.prior', T, B * S, K, action.device) if sample else None
+            deter, logit, stoch = ops.rssm_imagine_seq(
+                action.transpose(0, 1), state['stoch'].reshape(B, S * K), state['deter'], q, S, K,
+                lin_i.weight, lin_i.bias, ln_i.weight, ln_i.bias, self._cell._layer.weight, self._cell._norm.weight,
+                self._cell._norm.bias, lin_o.weight, lin_o.bias, ln_o.weight, ln_o.bias, self._ensemble_img_dist[0].weight,
+                self._ensemble_img_dist[0].bias, ln_i.eps, ln_o.eps)
+            bm = lambda x: x.transpose(0, 1)
+            return {'stoch': bm(stoch.reshape(T, B, S, K)), 'deter': bm(deter), 'logit': bm(logit.reshape(T, B, S, K))}
         outs = []
         for t in range(T):
             state = self.img_step(state, action[:, t], sample)

@@ -55,12 +55,15 @@ __device__ __forceinline__ int group_argmax(float v, int idx) {
   return idx;
 }
 
+struct MaskedCopy { float* out2; const float* scale; int S; };            // forward: out2 = scale[g / S] * sample
+struct MaskedGrad { const float* g2; const float* scale; int S; };      // backward: upstream = gsample + scale[g / S] * g2
+
 // sample[g,k] = onehot(argmax_k pn/q) (q == nullptr: mode = argmax pn).  Also optionally writes pn.
 template <int W>
 __global__ __launch_bounds__(256) void onehot_fwd_kernel(const float* __restrict__ logits,
                                                          const float* __restrict__ q, float* __restrict__ sample,
                                                          float* __restrict__ probs, long G, int K, float a, PlaneOut xo,
-                                                         int rowlen) {
+                                                         int rowlen, MaskedCopy mc) {
   const long g = ((long)blockIdx.x * 256 + threadIdx.x) / W;
   const int k = threadIdx.x % W;
   const bool valid = (g < G) && (k < K);
@@ -78,6 +81,8 @@ __global__ __launch_bounds__(256) void onehot_fwd_kernel(const float* __restrict
       if (e % rowlen == 0) xo.inv[e / rowlen] = 1.f / 16384.f;
     }
     if (probs) probs[gi * K + k] = c.pn;
+    // second copy scaled per sequence row (the is_first reset of the NEXT scan step's previous latent, agent/dreamer_utils.py:433-434)
+    if (mc.out2) mc.out2[gi * K + k] = (k == best) ? (mc.scale ? mc.scale[gi / mc.S] : 1.0f) : 0.0f;
   }
 }
 
@@ -87,7 +92,7 @@ template <int W>
 __global__ __launch_bounds__(1024) void onehot_bwd_kernel(const float* __restrict__ logits,
                                                           const float* __restrict__ gsample,
                                                           float* __restrict__ dlogits, long G, int K, float a,
-                                                          int accumulate, PlaneOut xo, int rowlen) {
+                                                          int accumulate, PlaneOut xo, int rowlen, MaskedGrad mg) {
   __shared__ float redm[16];
   const long g = ((long)blockIdx.x * blockDim.x + threadIdx.x) / W;
   const int k = threadIdx.x % W;
@@ -96,7 +101,9 @@ __global__ __launch_bounds__(1024) void onehot_bwd_kernel(const float* __restric
   const float l = valid ? logits[gi * K + k] : 0.f;
   Cat<W> c;
   c.init(l, valid, K, a);
-  const float d = c.backward(valid ? gsample[gi * K + k] : 0.f, valid, a);
+  float gs = (valid && gsample) ? gsample[gi * K + k] : 0.f;
+  if (valid && mg.g2) gs += (mg.scale ? mg.scale[gi / mg.S] : 1.0f) * mg.g2[gi * K + k];
+  const float d = c.backward(gs, valid, a);
   float o = 0.f;
   if (valid) {
     o = accumulate ? dlogits[gi * K + k] + d : d;
@@ -528,14 +535,15 @@ int genrl_split_h2(const float* x, long ldx, int R, int Cn, uint16_t* out, long 
                    void* stream);
 
 static int onehot_fwd_impl(const float* logits, const float* q, float* sample, float* probs, long G, int K, float unimix,
-                     PlaneOut xo, int rowlen, void* stream) {
+                     PlaneOut xo, int rowlen, void* stream, MaskedCopy mc = MaskedCopy{nullptr, nullptr, 1}) {
   GENRL_ENTER();
   if (G <= 0) return GENRL_OK;
+  if (mc.out2 && mc.S <= 0) return GENRL_EINVAL;
   if (xo.p && (rowlen <= 0 || xo.ld < rowlen || !xo.inv)) return GENRL_EINVAL;
   return dispatch_w(K, [&](auto w) {
     constexpr int W = decltype(w)::value;
     hipLaunchKernelGGL((onehot_fwd_kernel<W>), dim3(cdiv(G * W, 256)), dim3(256), 0, (hipStream_t)stream, logits, q,
-                       sample, probs, G, K, unimix, xo, rowlen);
+                       sample, probs, G, K, unimix, xo, rowlen, mc);
     GENRL_CHECK_LAUNCH();
     return GENRL_OK;
   });
@@ -551,9 +559,10 @@ int genrl_onehot_fwd_h2(const float* logits, const float* q, float* sample, floa
 }
 
 static int onehot_bwd_impl(const float* logits, const float* gsample, float* dlogits, long G, int K, float unimix,
-                     int accumulate, PlaneOut xo, int rowlen, void* stream) {
+                     int accumulate, PlaneOut xo, int rowlen, void* stream, MaskedGrad mg = MaskedGrad{nullptr, nullptr, 1}) {
   GENRL_ENTER();
   if (G <= 0) return GENRL_OK;
+  if ((!gsample && !mg.g2) || (mg.g2 && mg.S <= 0)) return GENRL_EINVAL;
   if (xo.p && (rowlen <= 0 || xo.ld < rowlen || !xo.inv || rowlen % K || (G * K) % rowlen)) return GENRL_EINVAL;
   return dispatch_w(K, [&](auto w) {
     constexpr int W = decltype(w)::value;
@@ -562,10 +571,10 @@ static int onehot_bwd_impl(const float* logits, const float* gsample, float* dlo
     const bool rowblk = xo.p && W == K && rowlen % 64 == 0 && rowlen <= 1024;
     if (rowblk)
       hipLaunchKernelGGL((onehot_bwd_kernel<W>), dim3((G * K) / rowlen), dim3(rowlen), 0, (hipStream_t)stream, logits,
-                         gsample, dlogits, G, K, unimix, accumulate, xo, rowlen);
+                         gsample, dlogits, G, K, unimix, accumulate, xo, rowlen, mg);
     else
       hipLaunchKernelGGL((onehot_bwd_kernel<W>), dim3(cdiv(G * W, 256)), dim3(256), 0, (hipStream_t)stream, logits,
-                         gsample, dlogits, G, K, unimix, accumulate, PlaneOut{nullptr, 0, 0, nullptr}, rowlen);
+                         gsample, dlogits, G, K, unimix, accumulate, PlaneOut{nullptr, 0, 0, nullptr}, rowlen, mg);
     GENRL_CHECK_LAUNCH();
     if (xo.p && !rowblk)
       return genrl_split_h2(dlogits, rowlen, (int)((G * K) / rowlen), rowlen, xo.p, xo.ld, xo.plane, xo.inv, 0, stream);
@@ -579,6 +588,20 @@ int genrl_onehot_bwd(const float* logits, const float* gsample, float* dlogits, 
 int genrl_onehot_bwd_h2(const float* logits, const float* gsample, float* dlogits, long G, int K, float unimix,
                         int accumulate, uint16_t* dp, int rowlen, long ldp, long plane, float* inv, void* stream) {
   return onehot_bwd_impl(logits, gsample, dlogits, G, K, unimix, accumulate, PlaneOut{dp, ldp, plane, inv}, rowlen, stream);
+}
+
+/* the scan forms (EnsembleRSSM.observe without single_obs_posterior, csrc/seq.hip): the sample plus a copy scaled per sequence row
+ * (G = rows * S groups; sample2 = scale2[g / S] * sample: the next step's reset previous latent), and the straight-through backward of
+ * upstream = gsample (may be NULL) + scale2[g / S] * g2 */
+int genrl_onehot_fwd_masked(const float* logits, const float* q, float* sample, float* sample2, const float* scale2, int S, long G,
+                            int K, float unimix, void* stream) {
+  return onehot_fwd_impl(logits, q, sample, nullptr, G, K, unimix, PlaneOut{nullptr, 0, 0, nullptr}, 1, stream,
+                         MaskedCopy{sample2, scale2, S});
+}
+int genrl_onehot_bwd_masked(const float* logits, const float* gsample, const float* g2, const float* scale2, int S, float* dlogits,
+                            long G, int K, float unimix, int accumulate, void* stream) {
+  return onehot_bwd_impl(logits, gsample, dlogits, G, K, unimix, accumulate, PlaneOut{nullptr, 0, 0, nullptr}, 1, stream,
+                         MaskedGrad{g2, scale2, S});
 }
 
 int genrl_cat_kl_fwd(const float* lp, const float* lq, float* kl, float* ent_p, float* ent_q, long R, int S, int K,

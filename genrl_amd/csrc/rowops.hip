@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(256) void gru_gates_fwd_blk_kernel(
     const float* __restrict__ pre, const float* __restrict__ h, long ldh, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ hout, long ldo, float* __restrict__ hout2,
     const float* __restrict__ hout2_scale, float* __restrict__ mean_out, float* __restrict__ rstd_out, int R, int D,
-    float eps, PlaneOut xo) {
+    float eps, PlaneOut xo, long ldo2) {
   __shared__ float red[8];
   const int dv = D >> 2, N = 3 * D;
   for (int row = blockIdx.x; row < R; row += gridDim.x) {
@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(256) void gru_gates_fwd_blk_kernel(
         on[i] = o;
         if (hout2) {
           o.x *= sc2; o.y *= sc2; o.z *= sc2; o.w *= sc2;
-          reinterpret_cast<float4*>(hout2 + (long)row * D)[j] = o;
+          reinterpret_cast<float4*>(hout2 + (long)row * ldo2)[j] = o;
         }
       }
     }
@@ -1129,7 +1129,7 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_blk_kernel(
     const float* __restrict__ dhout2_scale, const float* __restrict__ pre, const float* __restrict__ h, long ldh, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in, float* __restrict__ dpre,
     float* __restrict__ dh, long lddh, float* __restrict__ part, int R, int D,
-    const float* __restrict__ d2parts, int nparts, long part_stride, int part_acc, PlaneOut xo) {
+    const float* __restrict__ d2parts, int nparts, long part_stride, int part_acc, PlaneOut xo, long ldpart) {
   __shared__ float red[8];
   const int dv = D >> 2, N = 3 * D;
   float4 ag[3][DV], ab[3][DV];
@@ -1170,7 +1170,7 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_blk_kernel(
             float4 pq[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-              pq[u] = reinterpret_cast<const float4*>(d2parts + (long)min(q0 + u, nparts - 1) * part_stride + (long)row * D)[j];
+              pq[u] = reinterpret_cast<const float4*>(d2parts + (long)min(q0 + u, nparts - 1) * part_stride + (long)row * ldpart)[j];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
               if (q0 + u < nparts) { g2.x += pq[u].x; g2.y += pq[u].y; g2.z += pq[u].z; g2.w += pq[u].w; }
@@ -1582,9 +1582,11 @@ int genrl_colsum(const float* x, long ldx, float* out, float* ws, int M, int N, 
 // step's is_first-reset state of a sequence scan; scale may be NULL = 1).  D % 4 == 0, D <= 4096.
 static int gru_gates_fwd_impl(const float* pre, const float* h, long ldh, const float* gamma, const float* beta,
                         float* hout, long ldo, float* hout2, const float* hout2_scale, float* mean, float* rstd,
-                        int R, int D, float eps, PlaneOut xo, void* stream) {
+                        int R, int D, float eps, PlaneOut xo, void* stream, long ldo2 = 0) {
   GENRL_ENTER();
   if (R <= 0) return GENRL_OK;
+  if (ldo2 <= 0) ldo2 = D;
+  if ((ldo2 & 3) || ldo2 < D) return GENRL_EINVAL;
   if (xo.p && (!xo.inv || (xo.ld & 3) || xo.ld < D)) return GENRL_EINVAL;
   if ((D & 3) || D > 4096 || (ldh & 3) || (ldo & 3) || !aligned16(pre) || !aligned16(h) || !aligned16(hout) ||
       !aligned16(gamma) || !aligned16(beta) || (hout2 && !aligned16(hout2)))
@@ -1592,7 +1594,7 @@ static int gru_gates_fwd_impl(const float* pre, const float* h, long ldh, const 
   hipStream_t s = (hipStream_t)stream;
   const int grid = R < 4 * BLK_GRID ? R : 4 * BLK_GRID;
   const int dvn = cdiv(D, 1024);
-#define GO(DV) hipLaunchKernelGGL((gru_gates_fwd_blk_kernel<DV>), dim3(grid), dim3(256), 0, s, pre, h, ldh, gamma, beta, hout, ldo, hout2, hout2_scale, mean, rstd, R, D, eps, xo)
+#define GO(DV) hipLaunchKernelGGL((gru_gates_fwd_blk_kernel<DV>), dim3(grid), dim3(256), 0, s, pre, h, ldh, gamma, beta, hout, ldo, hout2, hout2_scale, mean, rstd, R, D, eps, xo, ldo2)
   if (dvn == 1) GO(1); else if (dvn == 2) GO(2); else if (dvn == 3) GO(3); else GO(4);
 #undef GO
   GENRL_CHECK_LAUNCH();
@@ -1611,6 +1613,14 @@ int genrl_gru_gates_fwd_h2(const float* pre, const float* h, long ldh, const flo
                             PlaneOut{hp, ldp, plane, inv}, stream);
 }
 
+/* the same with hout2's rows ldo2 floats apart (the state half of a concatenated [x | h] operand of the next step's product) */
+int genrl_gru_gates_fwd_ld2(const float* pre, const float* h, long ldh, const float* gamma, const float* beta,
+                            float* hout, long ldo, float* hout2, long ldo2, const float* hout2_scale, float* mean, float* rstd,
+                            int R, int D, float eps, void* stream) {
+  return gru_gates_fwd_impl(pre, h, ldh, gamma, beta, hout, ldo, hout2, hout2_scale, mean, rstd, R, D, eps,
+                            PlaneOut{nullptr, 0, 0, nullptr}, stream, ldo2);
+}
+
 long genrl_gru_ws_floats(int R, int D) { return (long)(blk_grid_for(R) + 16) * 2 * 3 * D; }
 
 // Backward of the gate block *including* its LayerNorm: dpre[R,3D] is the gradient w.r.t. the
@@ -1626,9 +1636,11 @@ static int gru_gates_bwd_impl(const float* dhout, long lddo, const float* dhout2
                         const float* pre, const float* h, long ldh, const float* gamma, const float* beta,
                         const float* mean, const float* rstd, float* dpre, float* dh, long lddh, float* dgamma,
                         float* dbeta, float* ws, int R, int D, int accumulate_params, const float* dhout2_parts,
-                        int nparts, long part_stride, PlaneOut xo, void* stream) {
+                        int nparts, long part_stride, PlaneOut xo, void* stream, long ldpart = 0) {
   GENRL_ENTER();
   if (R <= 0) return GENRL_OK;
+  if (ldpart <= 0) ldpart = D;
+  if ((ldpart & 3) || ldpart < D) return GENRL_EINVAL;
   if (xo.p && (!xo.inv || (xo.ld & 3) || xo.ld < 3 * D)) return GENRL_EINVAL;
   if (!dhout2_parts) nparts = 0;
   if (nparts > 0 && (!dhout2 || !aligned16(dhout2_parts) || (part_stride & 3))) return GENRL_EINVAL;
@@ -1642,7 +1654,7 @@ static int gru_gates_bwd_impl(const float* dhout, long lddo, const float* dhout2
   const int defer = accumulate_params & 4, part_acc = (accumulate_params & 2) ? 1 : 0;
   if (defer && !ws) return GENRL_EINVAL;
   float* part = (dgamma || defer) ? ws : nullptr;
-#define GO(DV) hipLaunchKernelGGL((gru_gates_bwd_blk_kernel<DV>), dim3(grid), dim3(256), 0, s, dhout, lddo, dhout2, dhout2_scale, pre, h, ldh, gamma, beta, mean, rstd, dpre, dh, lddh, part, R, D, dhout2_parts, nparts, part_stride, part_acc, xo)
+#define GO(DV) hipLaunchKernelGGL((gru_gates_bwd_blk_kernel<DV>), dim3(grid), dim3(256), 0, s, dhout, lddo, dhout2, dhout2_scale, pre, h, ldh, gamma, beta, mean, rstd, dpre, dh, lddh, part, R, D, dhout2_parts, nparts, part_stride, part_acc, xo, ldpart)
   if (dvn == 1) GO(1); else if (dvn == 2) GO(2); else if (dvn == 3) GO(3); else GO(4);
 #undef GO
   if (dgamma && !defer) reduce_params(ws, ws + (long)grid * 6 * D, dgamma, dbeta, grid, 3 * D, accumulate_params & 1, s);
@@ -1666,6 +1678,17 @@ int genrl_gru_gates_bwd_h2(const float* dhout, long lddo, const float* dhout2, c
   return gru_gates_bwd_impl(dhout, lddo, dhout2, dhout2_scale, pre, h, ldh, gamma, beta, mean, rstd, dpre, dh, lddh,
                             dgamma, dbeta, ws, R, D, accumulate_params, dhout2_parts, nparts, part_stride,
                             PlaneOut{dprep, ldp, plane, inv}, stream);
+}
+
+/* the same with the slabs' rows ldpart floats apart (a slab that is a column block of a wider product's output) */
+int genrl_gru_gates_bwd_ldp(const float* dhout, long lddo, const float* dhout2, const float* dhout2_scale,
+                            const float* pre, const float* h, long ldh, const float* gamma, const float* beta,
+                            const float* mean, const float* rstd, float* dpre, float* dh, long lddh, float* dgamma,
+                            float* dbeta, float* ws, int R, int D, int accumulate_params, const float* dhout2_parts,
+                            int nparts, long part_stride, long ldpart, void* stream) {
+  return gru_gates_bwd_impl(dhout, lddo, dhout2, dhout2_scale, pre, h, ldh, gamma, beta, mean, rstd, dpre, dh, lddh,
+                            dgamma, dbeta, ws, R, D, accumulate_params, dhout2_parts, nparts, part_stride,
+                            PlaneOut{nullptr, 0, 0, nullptr}, stream, ldpart);
 }
 
 static int actor_head_fwd_impl(const float* raw, const float* eps, float* action, float* mean, float* std, long R, int A,

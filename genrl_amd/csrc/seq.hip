@@ -276,4 +276,76 @@ int genrl_imagine_seq_f32_bwd(const genrl_rollout_f32* r, void* st) {
   return GENRL_OK;
 }
 
+// ---- EnsembleRSSM.observe WITHOUT single_obs_posterior (conf/defaults/dreamer_v3.yaml:5; agent/dreamer_utils.py:362-371, 425-457): the posterior
+// reads [deter_t, embed_t], so the sampled latent sits inside the recurrence.  What does not feed the recurrence is batched over T by the
+// caller (genrl_amd/ops.py::_ObserveSeq): the action half of _img_in (+ bias) is already in xpre, the embed half of _obs_out (+ bias) already
+// in opre, the prior head runs on all deter afterwards.  Per step, eight dependent launches:
+//   xpre_t += sm_t W_s^T -> LN + SiLU -> x_t (left half of xh_t) -> gpre_t = [x_t | hm_t] W_g^T -> LN + gates -> deter_t (and hm_{t+1} =
+//   mask_{t+1} deter_t into the right half of xh_{t+1}) -> opre_t += deter_t W_od^T -> LN + SiLU -> o_t -> plog_t = o_t W_d^T + b -> sample
+//   -> pst_t (and sm_{t+1} = mask_{t+1} pst_t).
+// sm_0 = mask_0 stoch_0 and the right half of xh_0 = mask_0 deter_0 are the caller's.
+static inline int osg(const genrl_observe* r, const float* A, long a_rs, long a_ks, const float* B, long b_rs, long b_ks, float* C, long ldc,
+                      const float* bias, int M, int N, int K, int acc, void* st) {
+  if (genrl_sgemm_ws_floats(M, N, K) > r->ws_floats) return GENRL_EINVAL;
+  return genrl_sgemm(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, acc, r->ws, r->ws_floats, st);
+}
+
+int genrl_observe_seq_fwd(const genrl_observe* r, void* st) {
+  if (!r || r->T <= 0 || r->B <= 0 || r->S <= 0 || r->K <= 0) return GENRL_EINVAL;
+  const int T = r->T, B = r->B, D = r->D, U = r->U;
+  const int SK = r->S * r->K, X = U + D;
+  for (int t = 0; t < T; ++t) {
+    const long b0 = (long)t * B;
+    const bool nxt = t + 1 < T;
+    RC(osg(r, r->sm + b0 * SK, SK, 1, r->w_in_s, r->ld_in_s, 1, r->xpre + b0 * U, U, nullptr, B, U, SK, 1, st));
+    RC(genrl_ln_act_fwd(r->xpre + b0 * U, U, r->in_g, r->in_be, r->xh + b0 * X, X, r->xm + b0, r->xr + b0, B, U, r->in_eps, 1, st));
+    RC(osg(r, r->xh + b0 * X, X, 1, r->w_g, r->ld_g, 1, r->gpre + b0 * 3 * D, 3 * D, nullptr, B, 3 * D, X, 0, st));
+    RC(genrl_gru_gates_fwd_ld2(r->gpre + b0 * 3 * D, r->xh + b0 * X + U, X, r->gru_g, r->gru_be, r->deter + b0 * D, D,
+                               nxt ? r->xh + (b0 + B) * X + U : nullptr, X, (nxt && r->mask) ? r->mask + b0 + B : nullptr, r->gm + b0,
+                               r->gr + b0, B, D, 1e-5f, st));
+    RC(osg(r, r->deter + b0 * D, D, 1, r->w_o, r->ld_o, 1, r->opre + b0 * U, U, r->opre_acc ? nullptr : r->out_b, B, U, D,
+           r->opre_acc ? 1 : 0, st));
+    RC(genrl_ln_act_fwd(r->opre + b0 * U, U, r->out_g, r->out_be, r->o + b0 * U, U, r->om + b0, r->orr + b0, B, U, r->out_eps, 1, st));
+    RC(osg(r, r->o + b0 * U, U, 1, r->w_d, U, 1, r->plog + b0 * SK, SK, r->dist_b, B, SK, U, 0, st));
+    RC(genrl_onehot_fwd_masked(r->plog + b0 * SK, r->q ? r->q + b0 * SK : nullptr, r->pst + b0 * SK, nxt ? r->sm + (b0 + B) * SK : nullptr,
+                               (nxt && r->mask) ? r->mask + b0 + B : nullptr, r->S, (long)B * r->S, r->K, r->unimix, st));
+  }
+  return GENRL_OK;
+}
+
+// backward of the same scan, eight dependent launches per step.  On entry dlg (T, B, SK) holds the direct logit gradient (KL term) and dd
+// (T, B, D) the direct deter gradient (heads + prior head); d_pst (T, B, SK; may be NULL) is the direct gradient of the samples.  On return:
+// dlg / dov / dopre / dgpre / dxh (left half) / dxpre hold every step's gradients for the caller's batched weight-gradient and LayerNorm
+// parameter passes; dsa / dsb and dhd_a / dhd_b are ping-pong buffers -- *final (0 / 1) names the pair member that holds step 0's
+// d(sm_0) and the direct part of d(hm_0) (its product part is the right half of dxh_0).
+int genrl_observe_seq_bwd(const genrl_observe* r, int* final, void* st) {
+  if (!r || r->T <= 0 || r->B <= 0 || !r->dlg || !r->dd || !r->mask || !r->opre_acc) return GENRL_EINVAL;
+  const int T = r->T, B = r->B, D = r->D, U = r->U;
+  const int SK = r->S * r->K, X = U + D;
+  float* dsm_cur = r->dsa; float* dsm_nxt = nullptr;         // d(sm_{t+1}) consumed by step t
+  float* dhd_cur = r->dhd_a; float* dhd_nxt = nullptr;       // direct part of d(hm_{t+1})
+  for (int t = T - 1; t >= 0; --t) {
+    const long b0 = (long)t * B;
+    const float* m1 = r->mask + b0 + B;                      // mask_{t+1} (only read when t + 1 < T)
+    RC(genrl_onehot_bwd_masked(r->plog + b0 * SK, r->d_pst ? r->d_pst + b0 * SK : nullptr, dsm_nxt, dsm_nxt ? m1 : nullptr, r->S,
+                               r->dlg + b0 * SK, (long)B * r->S, r->K, r->unimix, 1, st));
+    RC(osg(r, r->dlg + b0 * SK, SK, 1, r->w_d, 1, U, r->dov + b0 * U, U, nullptr, B, U, SK, 0, st));
+    RC(genrl_ln_act_bwd(r->dov + b0 * U, U, r->opre + b0 * U, U, r->out_g, r->out_be, r->om + b0, r->orr + b0, r->dopre + b0 * U, U, nullptr,
+                        nullptr, nullptr, nullptr, B, U, 1, 0, st));
+    RC(osg(r, r->dopre + b0 * U, U, 1, r->w_o, 1, r->ld_o, r->dd + b0 * D, D, nullptr, B, D, U, 1, st));
+    const int acc = (t == T - 1 ? 0 : 2) | (t > 0 ? 4 : 0) | ((r->direct && t == 0) ? 1 : 0);
+    RC(genrl_gru_gates_bwd_ldp(r->dd + b0 * D, D, dhd_nxt, dhd_nxt ? m1 : nullptr, r->gpre + b0 * 3 * D, r->xh + b0 * X + U, X, r->gru_g,
+                               r->gru_be, r->gm + b0, r->gr + b0, r->dgpre + b0 * 3 * D, dhd_cur, D, r->dgamma, r->dbeta, r->gws, B, D, acc,
+                               dhd_nxt ? r->dxh + (b0 + B) * X + U : nullptr, dhd_nxt ? 1 : 0, 0, X, st));
+    RC(osg(r, r->dgpre + b0 * 3 * D, 3 * D, 1, r->w_g, 1, r->ld_g, r->dxh + b0 * X, X, nullptr, B, X, 3 * D, 0, st));
+    RC(genrl_ln_act_bwd(r->dxh + b0 * X, X, r->xpre + b0 * U, U, r->in_g, r->in_be, r->xm + b0, r->xr + b0, r->dxpre + b0 * U, U, nullptr,
+                        nullptr, nullptr, nullptr, B, U, 1, 0, st));
+    RC(osg(r, r->dxpre + b0 * U, U, 1, r->w_in_s, 1, r->ld_in_s, dsm_cur, SK, nullptr, B, SK, U, 0, st));
+    dsm_nxt = dsm_cur; dsm_cur = (dsm_cur == r->dsa) ? r->dsb : r->dsa;
+    dhd_nxt = dhd_cur; dhd_cur = (dhd_cur == r->dhd_a) ? r->dhd_b : r->dhd_a;
+  }
+  if (final) *final = (dsm_nxt == r->dsa) ? 0 : 1;
+  return GENRL_OK;
+}
+
 }  // extern "C"

@@ -103,7 +103,7 @@ def inject(sites):
 _static_seed = 0
 _static_dp = (0, 1)
 # sites whose tensors are time-major (T or H first): their rows (b-major) sit in dimension 1; everywhere else in 0
-_ROWS_DIM1 = {'wm.post_q', 'wm.prior_q', 'imag.act_eps', 'imag.step_q'}
+_ROWS_DIM1 = {'wm.post_q', 'wm.prior_q', 'imag.act_eps', 'imag.step_q', 'rssm.imagine_q'}
 
 
 @contextlib.contextmanager

@@ -1946,3 +1946,324 @@ class _DenseLNAct(Function):
 
 def dense_ln_act(x1, x2, W, b, gamma, beta, eps=1e-5):
     return _DenseLNAct.apply(x1, x2, W, b, gamma, beta, float(eps))
+
+
+# ------------------------------------------------------------------ RSSM observe scan with the posterior inside the recurrence
+
+class _ObserveArgs(ctypes.Structure):          # genrl_observe (include/genrl_hip.h)
+    _fields_ = ([(n, _CI) for n in ('T', 'B', 'S', 'K', 'D', 'U')] + [(n, _CF) for n in ('unimix', 'in_eps', 'out_eps')]
+                + [('w_in_s', _FP), ('ld_in_s', ctypes.c_long), ('w_g', _FP), ('ld_g', ctypes.c_long), ('w_o', _FP),
+                   ('ld_o', ctypes.c_long), ('w_d', _FP)]
+                + [(n, _FP) for n in ('in_g', 'in_be', 'gru_g', 'gru_be', 'out_g', 'out_be', 'dist_b', 'mask', 'q')]
+                + [('out_b', _FP), ('opre_acc', _CI)]
+                + [(n, _FP) for n in ('sm', 'xpre', 'xh', 'gpre', 'deter', 'opre', 'o', 'plog', 'pst',
+                                      'xm', 'xr', 'gm', 'gr', 'om', 'orr', 'ws')]
+                + [('ws_floats', ctypes.c_long)]
+                + [(n, _FP) for n in ('d_pst', 'dlg', 'dd', 'dov', 'dopre', 'dgpre', 'dxh', 'dxpre', 'dsa', 'dsb', 'dhd_a', 'dhd_b',
+                                      'dgamma', 'dbeta', 'gws')]
+                + [('direct', _CI)])
+
+
+def _sgemm_ptr(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, acc, ws, nws):
+    """genrl_sgemm on raw addresses (the Python twins of the C launch loops; timed like sgemm() under bench.py's event pass)"""
+    if gemm_profile is not None:
+        e0 = torch.cuda.Event(enable_timing=True); e0.record()
+    check(lib().genrl_sgemm(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, int(acc), ws, nws, _stream()), 'sgemm')
+    if gemm_profile is not None:
+        e1 = torch.cuda.Event(enable_timing=True); e1.record()
+        gemm_profile.append((M, N, K, e0, e1, ('k' if a_ks == 1 else 'r') + ('k' if b_ks == 1 else 'r') +
+                             ('/skinny' if (M <= 32 and a_ks == 1) else f'/pipe{lib().genrl_sgemm_last_pipe()}')))
+
+
+def _observe_fwd_py(a):
+    """csrc/seq.hip::genrl_observe_seq_fwd, launch for launch (a: _ObserveArgs)"""
+    L, st = lib(), _stream()
+    T, B, D, U, S, K = a.T, a.B, a.D, a.U, a.S, a.K
+    SK, X, f = S * K, U + D, 4
+    for t in range(T):
+        b0 = t * B
+        nxt = t + 1 < T
+        _sgemm_ptr(a.sm + f * b0 * SK, SK, 1, a.w_in_s, a.ld_in_s, 1, a.xpre + f * b0 * U, U, None, B, U, SK, 1, a.ws, a.ws_floats)
+        check(L.genrl_ln_act_fwd(a.xpre + f * b0 * U, U, a.in_g, a.in_be, a.xh + f * b0 * X, X, a.xm + f * b0, a.xr + f * b0, B, U,
+                                 a.in_eps, 1, st), 'ln_act_fwd')
+        _sgemm_ptr(a.xh + f * b0 * X, X, 1, a.w_g, a.ld_g, 1, a.gpre + f * b0 * 3 * D, 3 * D, None, B, 3 * D, X, 0, a.ws, a.ws_floats)
+        check(L.genrl_gru_gates_fwd_ld2(a.gpre + f * b0 * 3 * D, a.xh + f * (b0 * X + U), X, a.gru_g, a.gru_be, a.deter + f * b0 * D, D,
+                                        (a.xh + f * ((b0 + B) * X + U)) if nxt else None, X,
+                                        (a.mask + f * (b0 + B)) if (nxt and a.mask) else None,
+                                        a.gm + f * b0, a.gr + f * b0, B, D, 1e-5, st), 'gru_gates_fwd')
+        _sgemm_ptr(a.deter + f * b0 * D, D, 1, a.w_o, a.ld_o, 1, a.opre + f * b0 * U, U, None if a.opre_acc else a.out_b, B, U, D,
+                   1 if a.opre_acc else 0, a.ws, a.ws_floats)
+        check(L.genrl_ln_act_fwd(a.opre + f * b0 * U, U, a.out_g, a.out_be, a.o + f * b0 * U, U, a.om + f * b0, a.orr + f * b0, B, U,
+                                 a.out_eps, 1, st), 'ln_act_fwd')
+        _sgemm_ptr(a.o + f * b0 * U, U, 1, a.w_d, U, 1, a.plog + f * b0 * SK, SK, a.dist_b, B, SK, U, 0, a.ws, a.ws_floats)
+        check(L.genrl_onehot_fwd_masked(a.plog + f * b0 * SK, (a.q + f * b0 * SK) if a.q else None, a.pst + f * b0 * SK,
+                                        (a.sm + f * (b0 + B) * SK) if nxt else None, (a.mask + f * (b0 + B)) if (nxt and a.mask) else None,
+                                        S, B * S, K, a.unimix, st), 'onehot_fwd')
+
+
+def _observe_bwd_py(a):
+    """csrc/seq.hip::genrl_observe_seq_bwd, launch for launch; -> index (0 / 1) of the ping-pong pair that holds step 0's results"""
+    L, st = lib(), _stream()
+    T, B, D, U, S, K = a.T, a.B, a.D, a.U, a.S, a.K
+    SK, X, f = S * K, U + D, 4
+    dsm_cur, dsm_nxt, dhd_cur, dhd_nxt = a.dsa, None, a.dhd_a, None
+    for t in range(T - 1, -1, -1):
+        b0 = t * B
+        m1 = a.mask + f * (b0 + B)
+        check(L.genrl_onehot_bwd_masked(a.plog + f * b0 * SK, (a.d_pst + f * b0 * SK) if a.d_pst else None, dsm_nxt, m1 if dsm_nxt else None,
+                                        S, a.dlg + f * b0 * SK, B * S, K, a.unimix, 1, st), 'onehot_bwd')
+        _sgemm_ptr(a.dlg + f * b0 * SK, SK, 1, a.w_d, 1, U, a.dov + f * b0 * U, U, None, B, U, SK, 0, a.ws, a.ws_floats)
+        check(L.genrl_ln_act_bwd(a.dov + f * b0 * U, U, a.opre + f * b0 * U, U, a.out_g, a.out_be, a.om + f * b0, a.orr + f * b0,
+                                 a.dopre + f * b0 * U, U, None, None, None, None, B, U, 1, 0, st), 'ln_act_bwd')
+        _sgemm_ptr(a.dopre + f * b0 * U, U, 1, a.w_o, 1, a.ld_o, a.dd + f * b0 * D, D, None, B, D, U, 1, a.ws, a.ws_floats)
+        acc = (0 if t == T - 1 else 2) | (4 if t > 0 else 0) | (1 if (a.direct and t == 0) else 0)
+        check(L.genrl_gru_gates_bwd_ldp(a.dd + f * b0 * D, D, dhd_nxt, m1 if dhd_nxt else None, a.gpre + f * b0 * 3 * D,
+                                        a.xh + f * (b0 * X + U), X, a.gru_g, a.gru_be, a.gm + f * b0, a.gr + f * b0, a.dgpre + f * b0 * 3 * D,
+                                        dhd_cur, D, a.dgamma, a.dbeta, a.gws, B, D, acc,
+                                        (a.dxh + f * ((b0 + B) * X + U)) if dhd_nxt else None, 1 if dhd_nxt else 0, 0, X, st), 'gru_gates_bwd')
+        _sgemm_ptr(a.dgpre + f * b0 * 3 * D, 3 * D, 1, a.w_g, 1, a.ld_g, a.dxh + f * b0 * X, X, None, B, X, 3 * D, 0, a.ws, a.ws_floats)
+        check(L.genrl_ln_act_bwd(a.dxh + f * b0 * X, X, a.xpre + f * b0 * U, U, a.in_g, a.in_be, a.xm + f * b0, a.xr + f * b0,
+                                 a.dxpre + f * b0 * U, U, None, None, None, None, B, U, 1, 0, st), 'ln_act_bwd')
+        _sgemm_ptr(a.dxpre + f * b0 * U, U, 1, a.w_in_s, 1, a.ld_in_s, dsm_cur, SK, None, B, SK, U, 0, a.ws, a.ws_floats)
+        dsm_nxt, dsm_cur = dsm_cur, (a.dsb if dsm_cur == a.dsa else a.dsa)
+        dhd_nxt, dhd_cur = dhd_cur, (a.dhd_b if dhd_cur == a.dhd_a else a.dhd_a)
+    return 0 if dsm_nxt == a.dsa else 1
+
+
+def _ln_params_batched(dy, lddy, pre, gamma, beta, bias, mean, rstd, M, N):
+    """dgamma / dbeta / bias gradient of a LayerNorm(+SiLU) layer over all M rows at once (the scan's per-step backward launches ask
+    for dx only); added straight into the flat gradient buffers under the Optimizer, else returned as (dgamma, dbeta, dbias)"""
+    dev = pre.device
+    tg, tb, tc = _grad_buf(gamma), _grad_buf(beta), _grad_buf(bias)
+    direct = tg is not None and tb is not None and tc is not None
+    if direct:
+        g0, g1, g2, acc_p = tg, tb, tc, 1
+    else:
+        gb = torch.empty(3, N, device=dev)
+        g0, g1, g2, acc_p = gb[0], gb[1], gb[2], 0
+    ws = _ws(lib().genrl_ln_ws_floats(M, N), dev)
+    if direct:
+        acc_p |= defer_reduce(M, N, ws, g0, g1, g2)
+    scratch = torch.empty(M, N, device=dev)
+    check(lib().genrl_ln_act_bwd(dy.data_ptr(), lddy, _p(pre), N, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(scratch), N,
+                                 _p(g0), _p(g1), _p(g2), _p(ws), M, N, 1, acc_p, _stream()), 'ln_act_bwd')
+    return (None, None, None) if direct else (g0, g1, g2)
+
+
+class _ObserveSeq(Function):
+    """EnsembleRSSM.observe WITHOUT single_obs_posterior (conf/defaults/dreamer_v3.yaml:5; agent/dreamer_utils.py:362-371 static_scan over
+    obs_step :432-441): the posterior reads [deter_t, embed_t], so the latent sample is part of the recurrence.  ONE autograd node:
+    what does not feed the recurrence is batched over T (the action half of _img_in, the embed half of _obs_out; the prior head runs on the
+    returned deter outside); the remaining chain is eight dependent launches per step each way, run from C (csrc/seq.hip:
+    genrl_observe_seq_fwd / _bwd).  emb (T,B,E), act (T,B,A), mask (T,B) = 1 - is_first, stoch0 (B,S*K), deter0 (B,D), q (T,B*S,K) Exp(1) noise.
+    -> deter (T,B,D), post logits (T,B,S*K), post sample (T,B,S*K)."""
+    @staticmethod
+    def forward(ctx, emb, act, mask, stoch0, deter0, q, W_in, b_in, g_in, be_in, W_g, g_g, be_g, W_o, b_o, g_o, be_o, W_d, b_d,
+                eps_in, eps_o):
+        emb = _f32(emb).contiguous(); act = _f32(act).contiguous(); mask = _f32(mask).contiguous()
+        stoch0 = _f32(stoch0).contiguous(); deter0 = _f32(deter0).contiguous(); q = _f32(q).contiguous()
+        T, B, E = emb.shape
+        A = act.shape[2]
+        D = deter0.shape[1]
+        U, Kin = W_in.shape
+        SK = Kin - A
+        K = q.shape[-1]
+        S = SK // K
+        X = U + D
+        dev = emb.device
+        assert W_g.shape == (3 * D, X) and W_o.shape == (U, D + E) and W_d.shape == (SK, U) and stoch0.shape == (B, SK), 'observe_seq shapes'
+        assert q.numel() == T * B * SK and U % 4 == 0 and D % 4 == 0 and SK % 4 == 0
+        # batched over T: action half of _img_in (+ bias), embed half of _obs_out (+ bias)
+        am = torch.empty(T * B, A, device=dev)
+        copy2d(act, A, am, A, T * B, A, mask.reshape(T * B))
+        xpre = torch.empty(T, B, U, device=dev)
+        sgemm(am, A, 1, W_in, Kin, 1, xpre, U, b_in, T * B, U, A, b_off=SK)
+        opre = torch.empty(T, B, U, device=dev)
+        sgemm(emb, E, 1, W_o, D + E, 1, opre, U, b_o, T * B, U, E, b_off=D)
+        # the latent block of _img_in, rows 16-byte aligned (SK + A is not a multiple of 4 with 6 or 10 actions)
+        if Kin % 4:
+            w_s = torch.empty(U, SK, device=dev)
+            copy2d(W_in, Kin, w_s, SK, U, SK)
+            ld_s = SK
+        else:
+            w_s, ld_s = W_in, Kin
+        sm = torch.empty(T, B, SK, device=dev)
+        copy2d(stoch0, SK, sm, SK, B, SK, mask[0])
+        xh = torch.empty(T, B, X, device=dev)
+        copy2d(deter0, D, xh, X, B, D, mask[0], dst_off=U)
+        gpre = torch.empty(T, B, 3 * D, device=dev)
+        deter = torch.empty(T, B, D, device=dev)
+        o = torch.empty(T, B, U, device=dev)
+        plog = torch.empty(T, B, SK, device=dev)
+        pst = torch.empty(T, B, SK, device=dev)
+        stats = torch.empty(6, T, B, device=dev)
+        a = _ObserveArgs()
+        a.T, a.B, a.S, a.K, a.D, a.U = T, B, S, K, D, U
+        a.unimix, a.in_eps, a.out_eps = UNIMIX, eps_in, eps_o
+        a.w_in_s, a.ld_in_s, a.w_g, a.ld_g, a.w_o, a.ld_o, a.w_d = _p(w_s), ld_s, _p(W_g), X, _p(W_o), D + E, _p(W_d)
+        a.opre_acc = 1
+        for n_, t_ in (('in_g', g_in), ('in_be', be_in), ('gru_g', g_g), ('gru_be', be_g), ('out_g', g_o), ('out_be', be_o), ('dist_b', b_d),
+                       ('mask', mask), ('q', q), ('sm', sm), ('xpre', xpre), ('xh', xh), ('gpre', gpre), ('deter', deter), ('opre', opre),
+                       ('o', o), ('plog', plog), ('pst', pst)):
+            setattr(a, n_, _p(t_))
+        for i, n_ in enumerate(('xm', 'xr', 'gm', 'gr', 'om', 'orr')):
+            setattr(a, n_, stats[i].data_ptr())
+        nws = max(lib().genrl_sgemm_ws_floats(*s_) for s_ in _observe_shapes(B, SK, U, D))
+        ws = torch.empty(max(nws, 1), device=dev)
+        a.ws, a.ws_floats = ws.data_ptr(), nws
+        if SEQ_C and gemm_profile is None:
+            check(lib().genrl_observe_seq_fwd(ctypes.byref(a), _stream()), 'observe_seq_fwd')
+        else:
+            _observe_fwd_py(a)
+        ctx.save_for_backward(emb, am, mask, q, W_in, w_s, b_in, g_in, be_in, W_g, g_g, be_g, W_o, b_o, g_o, be_o, W_d, b_d,
+                              sm, xpre, xh, gpre, deter, opre, o, plog, stats)
+        ctx.dims = (T, B, S, K, D, U, A, E)
+        ctx.eps = (eps_in, eps_o)
+        return deter, plog, pst
+
+    @staticmethod
+    def backward(ctx, d_deter, d_plog, d_pst):
+        (emb, am, mask, q, W_in, w_s, b_in, g_in, be_in, W_g, g_g, be_g, W_o, b_o, g_o, be_o, W_d, b_d,
+         sm, xpre, xh, gpre, deter, opre, o, plog, stats) = ctx.saved_tensors
+        T, B, S, K, D, U, A, E = ctx.dims
+        SK, X, Kin, M = S * K, U + D, S * K + A, T * B
+        dev = emb.device
+        dd = d_deter.contiguous().clone() if d_deter is not None else torch.zeros(T, B, D, device=dev)
+        dlg = d_plog.contiguous().clone() if d_plog is not None else torch.zeros(T, B, SK, device=dev)
+        d_pst = d_pst.contiguous() if d_pst is not None else None
+        dov = torch.empty(T, B, U, device=dev); dopre = torch.empty(T, B, U, device=dev)
+        dgpre = torch.empty(T, B, 3 * D, device=dev); dxh = torch.empty(T, B, X, device=dev); dxpre = torch.empty(T, B, U, device=dev)
+        ds2 = torch.empty(2, B, SK, device=dev); dh2 = torch.empty(2, B, D, device=dev)
+        tg, tb = _grad_buf(g_g), _grad_buf(be_g)
+        direct = tg is not None and tb is not None
+        gb = (tg, tb) if direct else torch.empty(2, 3 * D, device=dev)
+        gws = torch.empty(lib().genrl_gru_ws_floats(B, D), device=dev)
+        a = _ObserveArgs()
+        a.T, a.B, a.S, a.K, a.D, a.U = T, B, S, K, D, U
+        a.unimix, a.in_eps, a.out_eps = UNIMIX, ctx.eps[0], ctx.eps[1]
+        a.w_in_s, a.ld_in_s, a.w_g, a.ld_g, a.w_o, a.ld_o, a.w_d = _p(w_s), w_s.shape[1], _p(W_g), X, _p(W_o), D + E, _p(W_d)
+        a.opre_acc = 1
+        for n_, t_ in (('in_g', g_in), ('in_be', be_in), ('gru_g', g_g), ('gru_be', be_g), ('out_g', g_o), ('out_be', be_o), ('dist_b', b_d),
+                       ('mask', mask), ('q', q), ('sm', sm), ('xpre', xpre), ('xh', xh), ('gpre', gpre), ('deter', deter), ('opre', opre),
+                       ('o', o), ('plog', plog), ('d_pst', d_pst), ('dlg', dlg), ('dd', dd), ('dov', dov), ('dopre', dopre),
+                       ('dgpre', dgpre), ('dxh', dxh), ('dxpre', dxpre), ('dgamma', gb[0]), ('dbeta', gb[1]), ('gws', gws)):
+            setattr(a, n_, _p(t_))
+        for i, n_ in enumerate(('xm', 'xr', 'gm', 'gr', 'om', 'orr')):
+            setattr(a, n_, stats[i].data_ptr())
+        a.dsa, a.dsb, a.dhd_a, a.dhd_b = ds2[0].data_ptr(), ds2[1].data_ptr(), dh2[0].data_ptr(), dh2[1].data_ptr()
+        a.direct = int(direct)
+        nws = max(lib().genrl_sgemm_ws_floats(*s_) for s_ in _observe_shapes(B, SK, U, D))
+        ws = torch.empty(max(nws, 1), device=dev)
+        a.ws, a.ws_floats = ws.data_ptr(), nws
+        if SEQ_C and gemm_profile is None:
+            fin = ctypes.c_int(0)
+            check(lib().genrl_observe_seq_bwd(ctypes.byref(a), ctypes.byref(fin), _stream()), 'observe_seq_bwd')
+            fin = fin.value
+        else:
+            fin = _observe_bwd_py(a)
+        need = ctx.needs_input_grad
+        # ---- batched over T: weight gradients, LayerNorm parameters, the encoder's gradient
+        def wgrad(P, parts):
+            """dP (+)= sum over parts of dY^T X into column blocks: parts = [(dY2d, ldy, N, X2d, ldx, Kx, c_off)]"""
+            if P is None:
+                return None
+            tgt = _grad_buf(P)
+            acc = tgt is not None
+            out = tgt if acc else torch.empty_like(P)
+            for (dy_, ldy_, n_, x_, ldx_, k_, off_) in parts:
+                sgemm(dy_, 1, ldy_, x_, 1, ldx_, out, P.shape[1], None, n_, k_, M, accumulate=acc, c_off=off_)
+            return None if acc else out
+        dW_d = wgrad(W_d if need[17] else None, [(dlg, SK, SK, o, U, U, 0)])
+        db_d = None
+        if need[18]:
+            tgt = _grad_buf(b_d)
+            if tgt is not None:
+                colsum(dlg.reshape(M, SK), out=tgt, accumulate=True)
+            else:
+                db_d = colsum(dlg.reshape(M, SK))
+        dg_o, dbe_o, db_o = _ln_params_batched(dov, U, opre, g_o, be_o, b_o, stats[4], stats[5], M, U)
+        dW_o = wgrad(W_o if need[13] else None, [(dopre, U, U, deter, D, D, 0), (dopre, U, U, emb, E, E, D)])
+        d_emb = None
+        if need[0]:
+            d_emb = torch.empty(T, B, E, device=dev)
+            sgemm(dopre, U, 1, W_o, 1, D + E, d_emb, E, None, M, E, U, b_off=D)
+        dW_g = wgrad(W_g if need[10] else None, [(dgpre, 3 * D, 3 * D, xh, X, X, 0)])
+        dg_i, dbe_i, db_i = _ln_params_batched(dxh, X, xpre, g_in, be_in, b_in, stats[0], stats[1], M, U)
+        dW_in = wgrad(W_in if need[6] else None, [(dxpre, U, U, sm, SK, SK, 0), (dxpre, U, U, am, A, A, SK)])
+        d_act = None
+        if need[1]:
+            d_act = torch.empty(T, B, A, device=dev)
+            sgemm(dxpre, U, 1, W_in, 1, Kin, d_act, A, None, M, A, U, b_off=SK)
+            d_act = d_act * mask.unsqueeze(-1)
+        d_s0 = (ds2[fin] * mask[0].unsqueeze(-1)) if need[3] else None
+        d_h0 = ((dh2[fin] + dxh[0, :, U:]) * mask[0].unsqueeze(-1)) if need[4] else None
+        dgg, dbg = (None, None) if direct else (gb[0], gb[1])
+        return (d_emb, d_act, None, d_s0, d_h0, None, dW_in, db_i, dg_i, dbe_i, dW_g, dgg, dbg, dW_o, db_o, dg_o, dbe_o, dW_d, db_d,
+                None, None)
+
+
+def _observe_shapes(B, SK, U, D):
+    X = U + D
+    return [(B, U, SK), (B, 3 * D, X), (B, U, D), (B, SK, U), (B, D, U), (B, X, 3 * D)]
+
+
+def observe_seq(emb, act, mask, stoch0, deter0, q, W_in, b_in, g_in, be_in, W_g, g_g, be_g, W_o, b_o, g_o, be_o, W_d, b_d,
+                eps_in=1e-5, eps_o=1e-5):
+    return _ObserveSeq.apply(emb, act, mask, stoch0, deter0, q, W_in, b_in, g_in, be_in, W_g, g_g, be_g, W_o, b_o, g_o, be_o, W_d, b_d,
+                             float(eps_in), float(eps_o))
+
+
+def rssm_imagine_seq(act, stoch0, deter0, q, S, K, W_in, b_in, g_in, be_in, W_g, g_g, be_g, W_out, b_out, g_out, be_out, W_dist,
+                     b_dist, eps_in=1e-5, eps_out=1e-5):
+    """EnsembleRSSM.imagine for GIVEN actions (agent/dreamer_utils.py:373-381: static_scan over img_step :459-473), forward only (no
+    autograd graph: the data-free block's warm-up rollouts and the report / video_imagine paths run under no_grad).  The action half
+    of _img_in is batched over T; the remaining chain -- eight launches per step -- runs from ONE host call (genrl_observe_seq_fwd
+    with the prior head in the posterior's place).  act (T,B,A) time-major, stoch0 (B,S*K), deter0 (B,D), q (T,B*S,K) Exp(1) noise or
+    None for mode().  -> deter (T,B,D), logit (T,B,S*K), stoch (T,B,S*K)."""
+    act = _f32(act).contiguous(); stoch0 = _f32(stoch0).contiguous(); deter0 = _f32(deter0).contiguous()
+    q = _f32(q).contiguous() if q is not None else None
+    T, B, A = act.shape
+    D = deter0.shape[1]
+    U, Kin = W_in.shape
+    SK, X = S * K, U + D
+    dev = act.device
+    assert Kin == SK + A and W_g.shape == (3 * D, X) and W_out.shape == (U, D) and W_dist.shape == (SK, U) and stoch0.shape == (B, SK)
+    assert U % 4 == 0 and D % 4 == 0 and SK % 4 == 0 and (q is None or q.numel() == T * B * SK)
+    xpre = torch.empty(T, B, U, device=dev)
+    sgemm(act, A, 1, W_in, Kin, 1, xpre, U, b_in, T * B, U, A, b_off=SK)
+    if Kin % 4:                                   # the latent block of _img_in with 16-byte aligned rows
+        w_s = torch.empty(U, SK, device=dev)
+        copy2d(W_in, Kin, w_s, SK, U, SK)
+        ld_s = SK
+    else:
+        w_s, ld_s = W_in, Kin
+    sm = torch.empty(T, B, SK, device=dev)
+    copy2d(stoch0, SK, sm, SK, B, SK)
+    xh = torch.empty(T, B, X, device=dev)
+    copy2d(deter0, D, xh, X, B, D, dst_off=U)
+    gpre = torch.empty(T, B, 3 * D, device=dev)
+    deter = torch.empty(T, B, D, device=dev)
+    opre = torch.empty(T, B, U, device=dev)
+    o = torch.empty(T, B, U, device=dev)
+    plog = torch.empty(T, B, SK, device=dev)
+    pst = torch.empty(T, B, SK, device=dev)
+    stats = torch.empty(6, T, B, device=dev)
+    a = _ObserveArgs()
+    a.T, a.B, a.S, a.K, a.D, a.U = T, B, S, K, D, U
+    a.unimix, a.in_eps, a.out_eps = UNIMIX, eps_in, eps_out
+    a.w_in_s, a.ld_in_s, a.w_g, a.ld_g, a.w_o, a.ld_o, a.w_d = _p(w_s), ld_s, _p(W_g), X, _p(W_out), D, _p(W_dist)
+    a.opre_acc = 0
+    for n_, t_ in (('in_g', g_in), ('in_be', be_in), ('gru_g', g_g), ('gru_be', be_g), ('out_g', g_out), ('out_be', be_out),
+                   ('dist_b', b_dist), ('out_b', b_out), ('q', q), ('sm', sm), ('xpre', xpre), ('xh', xh), ('gpre', gpre), ('deter', deter),
+                   ('opre', opre), ('o', o), ('plog', plog), ('pst', pst)):
+        setattr(a, n_, _p(t_))
+    for i, n_ in enumerate(('xm', 'xr', 'gm', 'gr', 'om', 'orr')):
+        setattr(a, n_, stats[i].data_ptr())
+    nws = max(lib().genrl_sgemm_ws_floats(*s_) for s_ in _observe_shapes(B, SK, U, D))
+    ws = torch.empty(max(nws, 1), device=dev)
+    a.ws, a.ws_floats = ws.data_ptr(), nws
+    if SEQ_C and gemm_profile is None:
+        check(lib().genrl_observe_seq_fwd(ctypes.byref(a), _stream()), 'observe_seq_fwd')
+    else:
+        _observe_fwd_py(a)
+    return deter, plog, pst

@@ -271,6 +271,40 @@ typedef struct {
 } genrl_rollout_f32;
 int genrl_imagine_seq_f32_fwd(const genrl_rollout_f32* r, void* stream);
 int genrl_imagine_seq_f32_bwd(const genrl_rollout_f32* r, void* stream);
+
+/* EnsembleRSSM.observe WITHOUT single_obs_posterior (conf/defaults/dreamer_v3.yaml:5; agent/dreamer_utils.py:362-371 static_scan over
+ * obs_step :432-441 = img_step :459-473 + get_post_stoch :443-457): the posterior reads [deter_t, embed_t], so the sampled latent is part
+ * of the recurrence.  The caller batches over T what does not feed it (the action half of _img_in + bias: already in xpre; the embed half
+ * of _obs_out + bias: already in opre; the prior head: on all deter afterwards); these entries run the remaining chain, eight dependent
+ * launches per step each way (csrc/seq.hip says which), from ONE host call.  Time-major buffers:
+ *   sm (T, B, SK) masked previous latent of every step (sm_0 = mask_0 stoch_0 is the caller's); xpre / opre / o (T, B, U);
+ *   xh (T, B, U + D) = [x_t | hm_t] (right half of row block 0 = mask_0 deter_0 is the caller's); gpre (T, B, 3D); deter (T, B, D);
+ *   plog / pst (T, B, SK); q (T, B * S, K) Exp(1) noise; mask (T, B) = 1 - is_first; xm .. orr (T, B) LayerNorm statistics.
+ * Weights: w_in_s = the latent block (U x SK, rows ld_in_s apart) of _img_in; w_g (3D x (U + D), ld_g) GRUCell._layer; w_o = the deter
+ * block (U x D, rows ld_o apart) of _obs_out; w_d (SK x U) _obs_dist with bias dist_b.  ws: max genrl_sgemm_ws_floats over the step products.
+ * Backward (see csrc/seq.hip): dlg (T, B, SK) / dd (T, B, D) hold the direct logit / deter gradients on entry; d_pst may be NULL; all
+ * per-step gradients stay in dlg, dov, dopre, dgpre, dxh, dxpre for the caller's batched weight-gradient passes; dgamma / dbeta / gws /
+ * direct as genrl_gru_seq_bwd's. */
+typedef struct {
+  int T, B, S, K, D, U;
+  float unimix, in_eps, out_eps;
+  const float* w_in_s; long ld_in_s; const float* w_g; long ld_g; const float* w_o; long ld_o; const float* w_d;
+  const float* in_g; const float* in_be; const float* gru_g; const float* gru_be; const float* out_g; const float* out_be;
+  const float* dist_b; const float* mask; const float* q;
+  const float* out_b; int opre_acc;   /* opre_acc 1: opre holds the batched half on entry (observe); 0: opre_t = deter_t w_o^T + out_b (imagine) */
+  float* sm; float* xpre; float* xh; float* gpre; float* deter; float* opre; float* o; float* plog; float* pst;
+  float* xm; float* xr; float* gm; float* gr; float* om; float* orr;
+  float* ws; long ws_floats;
+  /* backward only */
+  const float* d_pst; float* dlg; float* dd; float* dov; float* dopre; float* dgpre; float* dxh; float* dxpre;
+  float* dsa; float* dsb; float* dhd_a; float* dhd_b; float* dgamma; float* dbeta; float* gws; int direct;
+} genrl_observe;
+int genrl_observe_seq_fwd(const genrl_observe* r, void* stream);
+int genrl_observe_seq_bwd(const genrl_observe* r, int* final_buf, void* stream);
+/* EnsembleRSSM.imagine (agent/dreamer_utils.py:373-381: static_scan over img_step :459-473 for GIVEN actions -- the data-free block's
+ * warm-up rollouts, train.py:283-340, report / video_imagine) is the same loop with the prior head in the posterior's place: call
+ * genrl_observe_seq_fwd with mask = NULL (no resets), opre_acc = 0, w_o / out_b / out_g / out_be = _ensemble_img_out, w_d / dist_b =
+ * _ensemble_img_dist, q = NULL for mode() instead of sample().  Forward only. */
 /* Weight-gradient product on the SAME planes (csrc/gemm_planes_tn.hip):  C[i, j] (+)= sum_m A(m, i) B(m, j) for h2 planes
  * A [2][M][a_ld] (columns i < NI) and B [2][M][b_ld] (columns j < NJ) with per-row inverse scales a_inv[M], b_inv[M] -- dW = dY^T X
  * (agent/dreamer_utils.py:739-747 backward) read against the planes' storage order through the transposing LDS read
@@ -371,12 +405,22 @@ int genrl_colsum(const float* x, long ldx, float* out, float* ws, int M, int N, 
 int genrl_gru_gates_fwd(const float* pre, const float* h, long ldh, const float* gamma, const float* beta,
                         float* hout, long ldo, float* hout2, const float* hout2_scale, float* mean, float* rstd,
                         int R, int D, float eps, void* stream);
+/* the same with hout2's rows ldo2 floats apart (the state half of a concatenated [x | h] operand of the next step's product) */
+int genrl_gru_gates_fwd_ld2(const float* pre, const float* h, long ldh, const float* gamma, const float* beta,
+                            float* hout, long ldo, float* hout2, long ldo2, const float* hout2_scale, float* mean, float* rstd,
+                            int R, int D, float eps, void* stream);
 long genrl_gru_ws_floats(int R, int D);
 int genrl_gru_gates_bwd(const float* dhout, long lddo, const float* dhout2, const float* dhout2_scale,
                         const float* pre, const float* h, long ldh, const float* gamma, const float* beta,
                         const float* mean, const float* rstd, float* dpre, float* dh, long lddh, float* dgamma,
                         float* dbeta, float* ws, int R, int D, int accumulate_params, const float* dhout2_parts,
                         int nparts, long part_stride, void* stream);
+/* the same with the slabs' rows ldpart floats apart (a slab that is a column block of a wider product's output) */
+int genrl_gru_gates_bwd_ldp(const float* dhout, long lddo, const float* dhout2, const float* dhout2_scale,
+                            const float* pre, const float* h, long ldh, const float* gamma, const float* beta,
+                            const float* mean, const float* rstd, float* dpre, float* dh, long lddh, float* dgamma,
+                            float* dbeta, float* ws, int R, int D, int accumulate_params, const float* dhout2_parts,
+                            int nparts, long part_stride, long ldpart, void* stream);
 
 /* ---- actor Normal head: DistLayer 'normal' + rsample (agent/dreamer_utils.py:814-819) */
 int genrl_actor_head_fwd(const float* raw, const float* eps, float* action, float* mean, float* std, long R, int A,
@@ -406,6 +450,13 @@ int genrl_onehot_fwd(const float* logits, const float* q, float* sample, float* 
                      void* stream);
 int genrl_onehot_bwd(const float* logits, const float* gsample, float* dlogits, long G, int K, float unimix,
                      int accumulate, void* stream);
+/* the scan forms (EnsembleRSSM.observe without single_obs_posterior, genrl_observe_seq_*): G = rows * S groups; the forward also writes
+ * sample2 = scale2[g / S] * sample (the next step's is_first-reset previous latent, agent/dreamer_utils.py:433-434; sample2 may be NULL);
+ * the backward's upstream is gsample (may be NULL) + scale2[g / S] * g2 (g2 may be NULL; scale2 NULL = 1) */
+int genrl_onehot_fwd_masked(const float* logits, const float* q, float* sample, float* sample2, const float* scale2, int S, long G,
+                            int K, float unimix, void* stream);
+int genrl_onehot_bwd_masked(const float* logits, const float* gsample, const float* g2, const float* scale2, int S, float* dlogits,
+                            long G, int K, float unimix, int accumulate, void* stream);
 /* KL(Independent(OneHotDist(lp)) || Independent(OneHotDist(lq))) per row + entropies
  * (EnsembleRSSM.kl_loss, agent/dreamer_utils.py:534-555; agent/dreamer.py:249-250) */
 int genrl_cat_kl_fwd(const float* lp, const float* lq, float* kl, float* ent_p, float* ent_q, long R, int S, int K,
