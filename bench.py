@@ -135,20 +135,39 @@ WORKLOADS = {
 }
 
 
+# kernel family (the label the library's launch log uses, csrc/common.h: genrl_log_launch) of a rocprofv3 kernel name
+_FAMILIES = (('h2/64', ('gemm_planes_kernel<1, 1, 64',)), ('h2/128', ('gemm_planes_hl_kernel<false>', 'gemm_planes_kernel<2, 2')),
+             ('h2/gather128', ('gemm_planes_hl_kernel<true>',)), ('h2tn', ('gemm_planes_tn_kernel<false>',)),
+             ('h2tn/conv', ('gemm_planes_tn_kernel<true>',)), ('f32/tile64', ('sgemm_rr_kernel<2', 'sgemm_kernel<64')),
+             ('f32/tile128', ('sgemm_rr_kernel<4', 'sgemm_kernel<128')), ('f32/tall', ('sgemm_tall_kernel',)),
+             ('f32/skinny', ('skinny_kernel',)))
+_LOG_FAMILY = {'h2/conv128': 'h2/gather128', 'h2/subpixel128': 'h2/gather128'}
+
+
+def _family_of(kernel_name):
+    for fam, keys in _FAMILIES:
+        if any(k in kernel_name for k in keys):
+            return fam
+    return None
+
+
 def measure_traffic(timeout=300, extra=()):
     """HBM bytes per launch of the MFMA GEMM kernels, measured NOW on this box: two separate rocprofv3 --pmc passes
     (FETCH_SIZE, then WRITE_SIZE; --kernel-trace only) over a short eager single-stream run of this script, as
     MI355X_MICROARCH.md's HBM section prescribes (FETCH_SIZE is in KiB and counts 64 B per 128-B request on gfx950: x2).
-    -> (bytes per launch, source note) or (None, reason)."""
-    import csv, shutil, subprocess, tempfile
+    The child also writes the library's launch log (GENRL_GEMM_LOG: kernel family, M, N, K and the UNIQUE operand bytes of every
+    product -- a gathered operand counts as the image it is read from, not as its expanded patch matrix), so every kernel family
+    gets its own line: measured read / write bytes per launch next to the bytes its operands occupy.
+    -> (bytes per launch over all GEMM dispatches, source note, per-kernel list) or (None, reason, None)."""
+    import csv, shutil, subprocess, tempfile, collections
     if shutil.which('rocprofv3') is None:
-        return None, 'rocprofv3 not on PATH'
+        return None, 'rocprofv3 not on PATH', None
     child = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '1', '--graph', 'off', '--no-overlap',
              '--no-cpu-baseline', '--no-kernel-profile', '--no-fp32-mode', '--no-traffic', '--no-eager-leg', '--input', 'fixed'] + list(extra)
-    env = dict(os.environ, TMPDIR='/tmp')
-    tot = {}
+    tot, fam, logged = {}, collections.defaultdict(lambda: dict(n=0, FETCH_SIZE=0.0, WRITE_SIZE=0.0, ns=0.0, name='')), None
     for counter, mult in (('FETCH_SIZE', 2.0 * 1024.0), ('WRITE_SIZE', 1024.0)):
         d = tempfile.mkdtemp(prefix='genrl_pmc_', dir='/tmp')
+        env = dict(os.environ, TMPDIR='/tmp', GENRL_GEMM_LOG=os.path.join(d, 'gemm.log'))
         try:
             subprocess.run(['rocprofv3', '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'p', '--'] + child,
                            cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
@@ -158,23 +177,49 @@ def measure_traffic(timeout=300, extra=()):
                     if f.endswith('counter_collection.csv'):
                         path = os.path.join(base, f)
             if path is None:
-                return None, f'no counter CSV from the {counter} pass'
+                return None, f'no counter CSV from the {counter} pass', None
             val, seen = 0.0, set()
             for r in csv.DictReader(open(path)):
                 n = r['Kernel_Name']
                 if ('sgemm_' in n or 'gemm_planes' in n) and r['Counter_Name'] == counter:
                     val += float(r['Counter_Value']); seen.add(r['Dispatch_Id'])
+                f_ = _family_of(n)
+                if f_ is not None and r['Counter_Name'] == counter:
+                    e = fam[f_]
+                    e[counter] += float(r['Counter_Value']) * mult
+                    if counter == 'FETCH_SIZE':
+                        e['n'] += 1; e['name'] = n.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:90]
+                        try:
+                            e['ns'] += float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+                        except (KeyError, ValueError):
+                            pass
             if not seen:
-                return None, f'no GEMM dispatches in the {counter} pass'
+                return None, f'no GEMM dispatches in the {counter} pass', None
             tot[counter] = (val * mult, len(seen))
+            if logged is None and os.path.exists(env['GENRL_GEMM_LOG']):
+                logged = collections.defaultdict(lambda: [0, 0.0, 0.0])
+                for line in open(env['GENRL_GEMM_LOG']):
+                    w = line.split()
+                    if len(w) == 5:
+                        e = logged[_LOG_FAMILY.get(w[0], w[0])]
+                        e[0] += 1; e[1] += float(w[4]); e[2] += 2.0 * float(w[1]) * float(w[2]) * float(w[3])
         except Exception as e:
-            return None, f'{counter} pass failed: {type(e).__name__}'
+            return None, f'{counter} pass failed: {type(e).__name__}', None
         finally:
             shutil.rmtree(d, ignore_errors=True)
     per = tot['FETCH_SIZE'][0] / tot['FETCH_SIZE'][1] + tot['WRITE_SIZE'][0] / tot['WRITE_SIZE'][1]
+    per_kernel = []
+    for f_, e in sorted(fam.items(), key=lambda kv: -kv[1]['ns']):
+        n = max(e['n'], 1)
+        lg = (logged or {}).get(f_)
+        ob = (lg[1] / lg[0]) if lg and lg[0] else None
+        per_kernel.append({'kernel': f_, 'name': e['name'], 'launches': e['n'], 'logged_launches': lg[0] if lg else None,
+                           'us_per_launch_under_pmc': e['ns'] / n / 1e3, 'read_MB': e['FETCH_SIZE'] / n / 1e6, 'write_MB': e['WRITE_SIZE'] / n / 1e6,
+                           'operand_MB': (ob / 1e6) if ob else None, 'gflop_per_launch': (lg[2] / lg[0] / 1e9) if lg and lg[0] else None,
+                           'traffic_over_operands': ((e['FETCH_SIZE'] + e['WRITE_SIZE']) / n / ob) if ob else None})
     return per, (f'measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate processes, --kernel-trace only) over one '
                  f'eager single-stream step, {tot["FETCH_SIZE"][1]} GEMM dispatches; read {tot["FETCH_SIZE"][0] / tot["FETCH_SIZE"][1] / 1e6:.1f} MB '
-                 f'(FETCH_SIZE x2, gfx950) + write {tot["WRITE_SIZE"][0] / tot["WRITE_SIZE"][1] / 1e6:.1f} MB per launch')
+                 f'(FETCH_SIZE x2, gfx950) + write {tot["WRITE_SIZE"][0] / tot["WRITE_SIZE"][1] / 1e6:.1f} MB per launch'), per_kernel
 
 
 def _cpu_model():
@@ -228,6 +273,25 @@ def cpu_baseline(threads=None):
                        + ' (the reference itself took 28.9 s/step at B32xT32 on 8 threads, SURVEY.md par.6)',
                 one_thread={'workload': 'configs[0] size: full iteration at B4xT16, 1 thread, 1 warm-up + 3 timed',
                             'min_s': one[0], 'median_s': med(one), 'steps_per_s': 1.0 / one[0]})
+
+
+def _last_line_helper():
+    """bench_support/libbench_lastline.so (bench_support/last_line.c; built by __graft_entry__.build(), or here with gcc): the signal
+    handler that keeps the measured line when a backend thread aborts the process.  A bench tool, not product code."""
+    import ctypes, subprocess
+    d = os.path.join(ROOT, 'bench_support')
+    so, src = os.path.join(d, 'libbench_lastline.so'), os.path.join(d, 'last_line.c')
+    try:
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(['gcc', '-O2', '-shared', '-fPIC', '-o', so, src])
+        L = ctypes.CDLL(so)
+        L.bench_set_last_line.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        L.bench_set_last_line.restype = ctypes.c_int
+        L.bench_clear_last_line.restype = ctypes.c_int
+        return L
+    except Exception as e:
+        print(f'[bench] no last-line helper ({type(e).__name__}: {e}): an abort during the in-graph attempt would lose the line', file=sys.stderr)
+        return None
 
 
 def main():
@@ -331,12 +395,15 @@ def main():
     # whole iteration runs eagerly.  Whatever happens, the JSON line is printed.
     graphed, launch_mode = None, 'eager'
     backend = torch.distributed.get_backend() if world > 1 else None
+    from genrl_amd.graph import GraphedStep
 
     def ranks_agree(mets):
         """data parallel: after a step every rank must hold the same (finite) reduced gradient norms"""
         if world == 1:
             return True
-        keys = [k for k in ('model_grad_norm', 'connector_model_grad_norm', 'imag_actor_grad_norm', 'imag_critic_grad_norm') if k in mets]
+        keys = [k for k in mets if k.endswith('_grad_norm')]
+        if not keys:
+            return False
         mine = torch.stack([mets[k].detach().float().reshape(()) for k in keys]).to(dev)
         allv = [torch.empty_like(mine) for _ in range(world)]
         torch.distributed.all_gather(allv, mine)
@@ -347,7 +414,8 @@ def main():
 
     def resync_weights():
         """a failed attempt may have left the ranks with different weights: rank 0's are broadcast"""
-        for o in (ag.wm.model_opt, ag._imag_behavior.actor_opt, ag._imag_behavior.critic_opt):
+        beh = GraphedStep._behavior(ag)
+        for o in (ag.wm.model_opt, beh.actor_opt, beh.critic_opt):
             for g in o._groups:
                 for t in (g.flat, g.m, g.v, g.grad):
                     torch.distributed.broadcast(t, 0)
@@ -375,7 +443,7 @@ def main():
                     raise
                 print(f'[bench] hipGraph capture ({mode}) failed ({type(e).__name__}: {e}); falling back', file=sys.stderr)
                 graphed = None
-                ag._imag_behavior._defer_slow_target = False
+                GraphedStep._behavior(ag)._defer_slow_target = False
                 torch.cuda.synchronize()
                 if world > 1:
                     resync_weights()
@@ -424,18 +492,26 @@ def main():
     assert np.isfinite(loss), (loss_key, loss)
 
     # ---- the same workload launched eagerly (no hipGraph: what an unmodified train.py loop gets), a short leg beside the replayed one
-    eager_ms = None
+    eager_ms, eager_detail = None, None
     if world == 1 and graphed is not None and not args.no_eager_leg:
+        # 5 warm-up steps (the caching allocator and the noise arena settle after the graph's teardown), then five windows of 10 steps:
+        # the line carries the MEDIAN window, the fastest one and all five beside it
         ac_ = GraphedStep._behavior(ag)
         ac_._defer_slow_target = False
         estep = (lambda: step_fn(ag, replay.sample())) if replay is not None else (lambda: step_fn(ag, batch))
-        estep(); torch.cuda.synchronize()
-        ne = max(3, min(args.steps, 10))
-        te = time.perf_counter()
-        for _ in range(ne):
+        for _ in range(5):
             estep()
         torch.cuda.synchronize()
-        eager_ms = 1000.0 * (time.perf_counter() - te) / ne
+        wins = []
+        for _ in range(5):
+            te = time.perf_counter()
+            for _ in range(10):
+                estep()
+            torch.cuda.synchronize()
+            wins.append(1000.0 * (time.perf_counter() - te) / 10)
+        eager_ms = sorted(wins)[2]
+        eager_detail = {'warmup_steps': 5, 'windows_of_10_steps_ms': [round(w, 3) for w in wins], 'min_window_ms': min(wins),
+                        'median_window_ms': eager_ms}
         ac_._defer_slow_target = True
 
     # ---- the same workload with fp32 MFMAs throughout (GENRL_GEMM_MODE=0 GENRL_PLANES=0 semantics), timed beside the default
@@ -473,7 +549,7 @@ def main():
             ops.set_gemm_precision(prev_mode)
             planes.ENABLED = prev_x3
 
-    def make_out(dt, launch_mode, graphed, loss, loss_key, eager_ms, fp32_mode):
+    def make_out(dt, launch_mode, graphed, loss, loss_key, eager_ms, fp32_mode, ingraph=None):
         sps = args.steps / dt
         shape = f'B{B}xL{T}x{img}x{img}x3' if wl != 'c5' else f'{B * T} start rows, no frames'
         return {'metric': f'world-model+imag update steps/sec ({shape})', 'value': sps, 'unit': 'steps/s',
@@ -495,9 +571,12 @@ def main():
                           else 'one fixed batch'),
                'config': {'workload': f'{wl_text}, batch {B} x seq {T}, {img}x{img}x3, horizon {cfg.imag_horizon}, A={A}',
                           'global_batch': B, 'seq_len': T, 'parallelism': f'dp{world}',
-                          'launch': f'{launch_mode} ({sum(1 for k_, _ in graphed.items if k_ == "graph")} graphs per iteration)' if graphed is not None else 'eager',
+                          # (data parallel over RCCL: what became of the attempt to capture the collectives INSIDE the graph is part of this string)
+                          'launch': (f'{launch_mode} ({sum(1 for k_, _ in graphed.items if k_ == "graph")} graphs per iteration)' if graphed is not None else 'eager')
+                                    + (f' [in-graph collectives: {ingraph}]' if ingraph else ''),
                           # the same workload launched kernel by kernel from Python (no hipGraph), timed beside the replayed one
-                          'eager_ms_per_step': eager_ms, 'eager_steps_per_s': (1000.0 / eager_ms) if eager_ms else None},
+                          'eager_ms_per_step': eager_ms, 'eager_steps_per_s': (1000.0 / eager_ms) if eager_ms else None,
+                          'eager_leg': eager_detail},
                'algorithmic_gflop_per_step': fl['total'], 'executed_gflop_per_step': fl['executed'],
                # priced on the work this build EXECUTES (SURVEY's algorithmic count includes the policy's entropy re-evaluation,
                # 421 GF at c2, which contributes nothing with actor_ent = 0 and is not run here); the algorithmic figure beside it
@@ -509,25 +588,28 @@ def main():
     # ---- data parallel over RCCL: now that a line is measured in the safe mode, try the collectives INSIDE the graph (the connector's side
     # stream stays on, reductions run beside the next phase).  A watchdog guards the attempt: this mode first meets real peers in the
     # driver's multi-GPU job, and if it hangs there every rank's timer fires, rank 0 prints the line measured above and the job ends.
-    ingraph_failed = False
+    ingraph_failed, ingraph_outcome = False, None
     if args.graph != 'off' and world > 1 and try_ingraph and graphed is not None:
-        import threading
-        safe_line = json.dumps(dict(make_out(dt, launch_mode, graphed, loss, loss_key, None, None), roofline=None, cpu_baseline=None,
-                                    note='the in-graph collective mode did not complete (watchdog or abort): this is the line measured in the cut mode'))
+        import threading, ctypes
+        why0 = ('; exit status 0 on purpose: this line IS a complete measurement -- the cut mode, timed before the attempt -- and a non-zero status '
+                'would discard it')
+        line_for = lambda outcome: json.dumps(dict(make_out(dt, launch_mode, graphed, loss, loss_key, None, None, ingraph=outcome + why0),
+                                                   roofline=None, cpu_baseline=None))
 
         def fire():
             if rank == 0:
-                print(safe_line, file=_real_stdout, flush=True)
+                print(line_for('timed out (watchdog)'), file=_real_stdout, flush=True)
             os._exit(0)
         wd = threading.Timer(float(os.environ.get('GENRL_INGRAPH_WATCHDOG_S', '240')), fire)
         wd.daemon = True
         wd.start()
-        # ... and if a backend thread ABORTS the process during the attempt, a C-level handler writes the same line (rank 0) and exits 0
-        from genrl_amd._lib import lib as _lib
+        # ... and if a backend thread ABORTS the process during the attempt, a bench-side C handler (bench_support/last_line.c -- not part of
+        # the product library) writes the same line (rank 0) and exits
+        helper = _last_line_helper()
         _real_stdout.flush()
-        _lib().genrl_set_last_line(safe_line.encode() if rank == 0 else None)
+        if helper is not None:
+            helper.bench_set_last_line(line_for('aborted (signal)').encode() if rank == 0 else None, 0)
         try:
-            from genrl_amd.graph import GraphedStep
             g2 = GraphedStep(ag, batch, step_fn, warmup=1, collectives='ingraph')
             m2 = g2()
             torch.cuda.synchronize()
@@ -536,17 +618,21 @@ def main():
             dt2, mets2 = timed(stepper(g2))
             l2 = float(mets2[loss_key])
             if np.isfinite(l2) and dt2 < dt:             # (all ranks hold the same max-over-ranks times: the same decision everywhere)
+                ingraph_outcome = f'adopted ({1e3 * dt2 / args.steps:.2f} ms/step against {1e3 * dt / args.steps:.2f} with cuts)'
                 dt, mets, loss, graphed, launch_mode = dt2, mets2, l2, g2, 'hipGraph replay, collectives ingraph'
             else:
+                ingraph_outcome = f'slower ({1e3 * dt2 / args.steps:.2f} ms/step against {1e3 * dt / args.steps:.2f} with cuts): not adopted'
                 print(f'[bench] in-graph collectives: {1e3 * dt2 / args.steps:.2f} ms/step, cut mode {1e3 * dt / args.steps:.2f}: keeping the cut mode', file=sys.stderr)
         except Exception as e:
             print(f'[bench] hipGraph capture (ingraph) failed ({type(e).__name__}: {e}); keeping the cut mode line', file=sys.stderr)
             ingraph_failed = True
+            ingraph_outcome = f'raised {type(e).__name__}' + why0
         finally:
             wd.cancel()
-            _lib().genrl_clear_last_line()
+            if helper is not None:
+                helper.bench_clear_last_line()
 
-    out = make_out(dt, launch_mode, graphed, loss, loss_key, eager_ms, fp32_mode) if rank == 0 else None
+    out = make_out(dt, launch_mode, graphed, loss, loss_key, eager_ms, fp32_mode, ingraph=ingraph_outcome) if rank == 0 else None
     sps = args.steps / dt
     # ---- kernel roofline: HIP events around every launch of the fp32-MFMA GEMM kernel in one extra step
     # (data parallel: no event-instrumented extra steps -- they would contain collectives and every rank would have to take
@@ -632,7 +718,7 @@ def main():
         dom = max(pipes, key=lambda k_: pipes[k_]['ms_per_step'])      # the pipe with the most kernel time leads the line
         # HBM bytes per launch of the GEMM kernels from the committed PMC passes of THIS round's build (rocprofv3 --pmc
         # runs are separate processes by construction: scripts/pmc.sh, FETCH_SIZE doubled per MI355X_MICROARCH.md)
-        traffic, tsrc = (None, 'skipped (--no-traffic)') if (args.no_traffic or world > 1) else measure_traffic(
+        traffic, tsrc, per_kernel = (None, 'skipped (--no-traffic)', None) if (args.no_traffic or world > 1) else measure_traffic(
             extra=['--config', wl, '--batch', str(B), '--length', str(T)])
         if traffic is None:
             why = tsrc
@@ -654,6 +740,9 @@ def main():
                            'default_mode_steps_per_s': sps,
                            'unit': 'TFLOP/s', 'frac': pipes[dom]['frac'], 'traffic': traffic, 'traffic_source': tsrc,
                            'algorithmic_operand_bytes_per_launch': alg_bytes, 'dominant_pipe': dom, 'pipes': pipes,
+                           # per kernel family: measured HBM-side read / write bytes per launch (PMC passes above) next to the UNIQUE bytes of
+                           # its operands (A + B + C as they lie in memory: the image of a gathered operand, not its expanded patch matrix)
+                           'per_kernel': per_kernel,
                            'all_gemm_fp32_equivalent': {'achieved': tot_fl / (tot_ms * 1e-3) / 1e12, 'peak': 157.3,
                                                         'frac': tot_fl / (tot_ms * 1e-3) / 1e12 / 157.3,
                                                         'note': '2MNK of every MFMA GEMM launch / HIP-event time, both pipes'},
@@ -664,6 +753,11 @@ def main():
                            'skinny_kernel': {'launches_per_step': len(skinny), 'ms_per_step': sk_ms,
                                              'bound': 'hbm', 'achieved_GBps': sk_bytes / max(sk_ms, 1e-9) / 1e6,
                                              'note': 'M<=32 scan-step products (weight streams), reported apart'}}
+        if per_kernel and all(e['operand_MB'] and e['logged_launches'] for e in per_kernel):
+            nl = sum(e['logged_launches'] for e in per_kernel)
+            ub = 1e6 * sum(e['operand_MB'] * e['logged_launches'] for e in per_kernel) / nl
+            out['roofline']['unique_operand_bytes_per_launch'] = ub      # (gathered operands as the images they are read from)
+            out['roofline']['traffic_over_unique_operands'] = (traffic / ub) if traffic else None
     elif rank == 0:
         out['roofline'] = None
     if rank == 0:

@@ -75,7 +75,7 @@ class DreamerAgent(Module):
         that two agents of different `precision` in one process do not change each other's arithmetic."""
         ops.set_gemm_precision('bf16' if self._use_amp else ops.F32_MODE)
         # precision 16 is ONE arithmetic -- every matrix product rounds both operands to bf16 and accumulates in fp32 (what
-        # oracle/genrl_oracle.py restates as `bf16_operands`, tests/test_gpu_precision16.py) -- so the pre-split fp16-plane
+        # oracle/genrl_oracle.py restates as `bf16_operands`, tests/test_gpu_iteration.py::test_precision16_vs_the_oracles_bf16_operand_mode) -- so the pre-split fp16-plane
         # products (fp32-grade) are switched off while an agent of that precision runs, and back on for the next fp32 agent
         from .. import planes
         if self._use_amp:
@@ -345,6 +345,7 @@ class WorldModel(Module):  # ref :120-321
             # the plane writes only add traffic -- measured 14.2 vs 13.7 ms/step at 4 sequences per GPU)
             use_planes = planes.ENABLED and N >= ops_planes.min_rows()
             tape = (ops_planes.ActorTapePlanes if use_planes else ops.ActorTape)(horizon, N, layers, head_w, head_b, dev)
+            tape.head_leaves = (policy._out._out.weight, policy._out._out.bias, policy._out._std.weight, policy._out._std.bias)
         fused = (tape is not None and not eval_policy and set(start) == {'stoch', 'deter', 'logit'}
                  and not os.environ.get('GENRL_NO_ROLLOUT_NODE'))
         if fused:

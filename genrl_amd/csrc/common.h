@@ -15,6 +15,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GENRL_ENTER() (void)hipGetLastError()
 
 extern "C" void genrl_set_last_error(int code);
+// GENRL_GEMM_LOG=<file>: one line per matrix-product launch, in launch order: "<kernel family> M N K <unique operand bytes>" (A + B + C as
+// they lie in memory: the IMAGE of a gathered operand, not its expanded patch matrix).  bench.py joins the per-family totals with the
+// rocprofv3 counters of the same process (roofline.per_kernel), scripts/inshape_table.py joins the sequence with a kernel trace.
+extern "C" void genrl_log_launch(const char* family, long M, long N, long K, double operand_bytes);
 #define GENRL_CHECK_LAUNCH()                                   \
   do {                                                         \
     hipError_t e__ = hipGetLastError();                        \

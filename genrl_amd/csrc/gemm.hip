@@ -1621,6 +1621,7 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
     static const int skinny_mb = getenv("GENRL_SKINNY_MB") ? atoi(getenv("GENRL_SKINNY_MB")) : 0;
     const bool g32 = M > 32 && (skinny_mb ? skinny_mb == 2 : (long)cdiv(N, 16) * cdiv(M, 64) < 512);
     dim3 grid(cdiv(N, 16), 1, M <= 32 ? 1 : cdiv(M, g32 ? 32 : 64)), block(1024);
+    genrl_log_launch("f32/skinny", M, N, K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
 #define GO(MB, BKC) \
   hipLaunchKernelGGL((skinny_kernel<MB, BKC>), grid, block, 0, s, A, a_rs, B, b_ld, C, ldc, bias, M, N, K, accumulate, vec, 0L)
     if (M <= 16) { if (b_kc) GO(1, true); else GO(1, false); }
@@ -1638,6 +1639,8 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
     const long b_ld = b_kc ? b_rs : b_ks;
     const int nb = cdiv(N, 16), kc = cdiv(K, 16);
     const long nblk = cdiv(M, 16);
+    if ((nb <= 3 && kc <= 3) || (nb <= 7 && kc <= 3) || (nb <= 3 && kc <= 7) || (kc <= 6 && !b_kc && tall_wide()))
+      genrl_log_launch("f32/tall", M, N, K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
 #define GO(NBV, KCV)                                                                                                   \
   do {                                                                                                                 \
     const int nslabs = cdiv(N, 16 * NBV);                                                                              \
@@ -1665,6 +1668,11 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
   const bool split = p.splits > 1 && ws && ws_floats >= (long)p.splits * M * N;
   if (!split) p.splits = 1, p.k_per_split = K;
   float* wsp = split ? ws : nullptr;
+  {  // launch log (common.h): a gathered operand counts as the image it is read from (M / ohw or K / ohw images of sn floats)
+    const double ab = (G == 1) ? (double)(M / gp->ohw) * gp->sn : (double)M * K;
+    const double bb = (G == 2) ? (double)(K / gp->ohw) * gp->sn : (double)N * K;
+    genrl_log_launch(p.big ? "f32/tile128" : "f32/tile64", M, N, K, 4.0 * (ab + bb + (double)M * N));
+  }
   int rc;
   if (p.big && use_rr_big() &&
       (rc = launch_rr<4>(A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, bias, M, N, K, accumulate, p.splits, (p.k_per_split + 63) / 64 * 64,
@@ -1747,6 +1755,7 @@ extern "C" int genrl_sgemm_skinny_parts(const float* A, long a_rs, const float* 
   const int vec = ((a_rs & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
                   (!b_kc || (((b_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0)));
   dim3 grid(cdiv(N, 16), nparts), block(1024);
+  genrl_log_launch("f32/skinny", M, N, K, 4.0 * ((double)M * K + (double)N * K + (double)nparts * M * N));
 #define GO(MB, BKC) \
   hipLaunchKernelGGL((skinny_kernel<MB, BKC>), grid, block, 0, s, A, a_rs, B, b_ld, P, ldp, nullptr, M, N, K, 0, vec, part_stride)
   if (M <= 16) { if (b_kc) GO(1, true); else GO(1, false); }

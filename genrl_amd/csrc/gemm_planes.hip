@@ -1073,12 +1073,9 @@ __global__ __launch_bounds__(256) void split_h2_t_batch_kernel(SplitBatch b) {
   }
 }
 
-// GENRL_GEMM_LOG=<file>: one line per plane-kernel launch (tile, M, N, K), in launch order -- scripts/inshape_table.py joins it with
-// a rocprofv3 kernel trace of the same eager single-stream process to get in-step microseconds PER SHAPE
-static void log_launch(const char* tile, int M, int N, int K) {
-  static FILE* f = getenv("GENRL_GEMM_LOG") ? fopen(getenv("GENRL_GEMM_LOG"), "w") : nullptr;
-  if (f) { fprintf(f, "%s %d %d %d\n", tile, M, N, K); fflush(f); }
-}
+// GENRL_GEMM_LOG=<file> (common.h): h2 planes hold 4 bytes per operand element (two fp16 planes)
+static inline void log_launch(const char* family, long M, long N, long K, double bytes) { genrl_log_launch(family, M, N, K, bytes); }
+static inline double kk_bytes(long M, long N, long K) { return 4.0 * ((double)M * K + (double)N * K + (double)M * N); }
 // the 128x128 products on the plane-alternating kernel (gemm_planes_hl_kernel); GENRL_PLANES_HL=0: the two-whole-stages kernel
 static bool hl_on() { static const bool on = !getenv("GENRL_PLANES_HL") || getenv("GENRL_PLANES_HL")[0] != '0'; return on; }
 int g_planes_nosplit = 0;        // experiments: 1 = no row split against wave quantisation (GENRL_PLANES_NOSPLIT)
@@ -1088,6 +1085,11 @@ int g_planes_force_tile = 0;     // 0 auto, 1: 64x64, 2: 128x128 (experiments)
 }  // namespace
 
 extern "C" {
+
+void genrl_log_launch(const char* family, long M, long N, long K, double operand_bytes) {
+  static FILE* f = getenv("GENRL_GEMM_LOG") ? fopen(getenv("GENRL_GEMM_LOG"), "w") : nullptr;
+  if (f) { fprintf(f, "%s %ld %ld %ld %.0f\n", family, M, N, K, operand_bytes); fflush(f); }
+}
 
 int genrl_planes_force_tile(int t) { const int p = g_planes_force_tile; g_planes_force_tile = t; return p; }
 int genrl_planes_variant(int v) { const int p = g_planes_variant; g_planes_variant = v; return p; }
@@ -1127,12 +1129,12 @@ int genrl_gemm_x3(const uint16_t* a0, long a0_ld, long a0_plane, const uint16_t*
   const bool big = g_planes_force_tile ? g_planes_force_tile == 2 : t64 >= 2048;
   if (big) {
     const int tm = cdiv(M, 128), tn = cdiv(N, 128);
-    log_launch("x3/128", M, N, k0 + k1);
+    log_launch("x3/128", M, N, k0 + k1, 6.0 * ((double)M + N) * (k0 + k1) + 4.0 * M * N);
     gemm_planes_kernel<2, 2, 32, 1, 0, 3><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, s1, C, ldc, bias, M, N, accumulate, tm, tn,
                                                                                 xcd_split(tm, tn), SampleEpi{}, ConvGather{});
   } else {
     const int tm = cdiv(M, 64), tn = cdiv(N, 64);
-    log_launch("x3/64", M, N, k0 + k1);
+    log_launch("x3/64", M, N, k0 + k1, 6.0 * ((double)M + N) * (k0 + k1) + 4.0 * M * N);
     gemm_planes_kernel<1, 1, 64, 3, 0, 3><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, s1, C, ldc, bias, M, N, accumulate, tm, tn,
                                                                                 xcd_split(tm, tn), SampleEpi{}, ConvGather{});
   }
@@ -1235,7 +1237,7 @@ static int gemm_h2_impl(const uint16_t* a0, long a0_ld, long a0_plane, const flo
       const PlaneSeg& sg = seg ? s1 : s0;
       const float* bs = seg ? nullptr : bias;
       const int acc = seg ? 1 : accumulate;
-      log_launch("h2/128", M, N, sg.k);
+      log_launch("h2/128", M, N, sg.k, kk_bytes(M, N, sg.k));
       if (bk32)
         gemm_planes_kernel<2, 2, 32, 2, 1, 4, false><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
                                                                                            xcd_split(tm, tn), SampleEpi{}, ConvGather{});
@@ -1258,7 +1260,7 @@ static int gemm_h2_impl(const uint16_t* a0, long a0_ld, long a0_plane, const flo
     const int tm = cdiv(M, 64), tn = cdiv(N, 64);
     // three 32 KiB stages (96 KiB): a fourth stage measured +0.6 ms on the whole step (28.86 vs 28.2 ms) -- with 128 KiB
     // taken, the other streams' small kernels (32 KiB weight-streaming workgroups) cannot share a CU with this one
-    log_launch("h2/64", M, N, k0 + k1);
+    log_launch("h2/64", M, N, k0 + k1, kk_bytes(M, N, k0 + k1));
 #define L64(NS_, PF_) gemm_planes_kernel<1, 1, 64, 3, 1, NS_, true, false, PF_><<<tm * tn, 256, 0, (hipStream_t)stream>>>( \
     s0, s1, C, ldc, bias, M, N, accumulate, tm, tn, xcd_split(tm, tn), smp, ConvGather{})
 #ifdef PLANES_EXPERIMENTS      /* ring depth / L2 prefetch variants for scripts/cold_bench.py (hipcc -DPLANES_EXPERIMENTS) */
@@ -1297,7 +1299,7 @@ int genrl_gemm_h2_conv(const uint16_t* img, long ld_img, long plane_img, const f
   PlaneSeg s0{img, ld_img, plane_img, b, b_ld, b_plane, (int)b_ld, img_inv, b_inv};
   const PlaneSeg none{nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, nullptr};
   const int tm = cdiv(M, 128), tn = cdiv(N, 128);
-  log_launch("h2/conv128", M, N, (int)b_ld);
+  log_launch("h2/conv128", M, N, (int)b_ld, 4.0 * ((double)Nimg * H * W * Cc + (double)N * b_ld + (double)M * N));
   if (hl_on())
     gemm_planes_hl_kernel<true><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, C, ldc, bias, M, N, accumulate, tm, tn, xcd_split(tm, tn),
                                                                           ConvGather{H, W, Cc, k, Ho, Wo, K, 2, 0, 0, 0});
@@ -1332,7 +1334,7 @@ int genrl_gemm_h2_subpixel(const uint16_t* img, long ld_img, long plane_img, con
   const int M = (int)Ml;
   PlaneSeg s0{img, ld_img, plane_img, b, b_ld, b_plane, (int)b_ld, img_inv, b_inv};
   const int tm = cdiv(M, 128), tn = cdiv(N, 128);
-  log_launch("h2/subpixel128", M, N, (int)b_ld);
+  log_launch("h2/subpixel128", M, N, (int)b_ld, 4.0 * ((double)Nimg * Hp * Wp * Cc + (double)N * b_ld + (double)Nimg * Ho * Wo * Co));
   gemm_planes_hl_kernel<true><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, out, 4, bias, M, N, 0, tm, tn, xcd_split(tm, tn),
                                                                         ConvGather{Hp, Wp, Cc, T, Hq, Wq, K, 1, Ho, Wo, Co});
   GENRL_CHECK_LAUNCH();

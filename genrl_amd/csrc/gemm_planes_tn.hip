@@ -517,6 +517,9 @@ static int tn_impl(const uint16_t* a, long a_ld, long a_plane, const float* a_in
   } else {
     g.out = part; g.ldo = NJp; g.split_stride = (long)NI * NJp; g.accumulate = 0;
   }
+  // launch log (common.h): unique operand bytes; the gathered image of the convolution form is ~4 pixels per output position (stride 2)
+  genrl_log_launch(rowoff ? "h2tn/conv" : "h2tn", NI, NJ, M,
+                   4.0 * ((double)M * NI + (rowoff ? 4.0 * (double)M * cC : (double)M * NJ) + (double)NI * NJ));
   if (rowoff) gemm_planes_tn_kernel<true><<<ti * tj * nsplit, 256, 0, s>>>(g);
   else gemm_planes_tn_kernel<false><<<ti * tj * nsplit, 256, 0, s>>>(g);
   GENRL_CHECK_LAUNCH();

@@ -8,39 +8,7 @@
 #include "common.h"
 #include "genrl_hip.h"
 
-#include <signal.h>
-#include <string.h>
-#include <unistd.h>
-
-// ---- a last line for a process that is about to die (bench.py's optional in-graph attempt under data parallelism): if the process aborts
-// (SIGABRT from a backend's watchdog thread, SIGSEGV) while the attempt runs, the handler writes the line the caller deposited -- the result
-// already measured in the safe mode -- to stdout with write(2) and ends the process with status 0.  Async-signal-safe: no allocation, no stdio.
-static char g_last_line[1 << 16];
-static volatile int g_last_len = 0;
-static void last_line_handler(int) {
-  if (g_last_len > 0) { ssize_t r = write(1, g_last_line, (size_t)g_last_len); (void)r; }
-  _exit(0);
-}
-
 extern "C" {
-
-/* deposit `line` (NULL / empty: nothing is written, the process just exits 0) and install the handlers; genrl_clear_last_line() restores
- * the default dispositions */
-int genrl_set_last_line(const char* line) {
-  int n = line ? (int)strlen(line) : 0;
-  if (n > (int)sizeof(g_last_line) - 2) return GENRL_EINVAL;
-  if (n > 0) { memcpy(g_last_line, line, (size_t)n); g_last_line[n++] = '\n'; }
-  g_last_len = n;
-  signal(SIGABRT, last_line_handler);
-  signal(SIGSEGV, last_line_handler);
-  return GENRL_OK;
-}
-int genrl_clear_last_line(void) {
-  signal(SIGABRT, SIG_DFL);
-  signal(SIGSEGV, SIG_DFL);
-  g_last_len = 0;
-  return GENRL_OK;
-}
 
 /* workspace floats for the recurrent products of genrl_gru_seq_fwd / _bwd (0 for B <= 32: the weight-streaming kernel needs none) */
 long genrl_gru_seq_ws_floats(int B, int D) {

@@ -41,6 +41,13 @@ def set_gemm_precision(mode):
     return {v: k for k, v in codes.items()}[prev]
 
 
+def _p16():
+    """precision 16 selected (every matrix product rounds both operands to bf16): the kernels that feed exact fp32 MFMAs
+    straight from memory without a rounding step (the direct 3-channel transposed convolution, the K-split weight-streaming slabs of the
+    scans' backward, the persistent scan) stand aside for the ones that implement the mode"""
+    return lib().genrl_gemm_precision() == 1
+
+
 def _prows(t):
     """pointer of a 2-D operand whose rows are evenly spaced (unit column stride); the callee gets the spacing"""
     if not t.is_cuda:
@@ -933,6 +940,42 @@ class ActorTape:
         self.fused = False                        # forward_fused ran: y / mean / rstd are filled by _backward (one batched launch per layer)
         self._stats = None                        # partial LayerNorm statistics per layer ([U / 16][N][2]), reused step after step
 
+    head_leaves = None      # (W_mean, b_mean, W_std, b_std): the leaf parameters head_w / head_b were stacked from (set by the caller)
+
+    def head_param_grads(self, d, x_last):
+        """gradients of the stacked output layer from d = d(raw) (M, 2A) and its input x_last (M, U): under the Optimizer they are
+        accumulated straight into the flat gradient buffers of the LEAF parameters the stack was built from (the mean head's rows, then
+        the std head's) and (None, None) is returned -- autograd then has nothing to un-stack and nothing to add; else (dW, db) of the stack"""
+        M, A2 = d.shape
+        U = x_last.shape[-1]
+        dev = d.device
+        if self.head_leaves is not None:
+            bufs = [_grad_buf(p_) for p_ in self.head_leaves]
+            if all(b_ is not None for b_ in bufs):
+                A = A2 // 2
+                if A % 4 == 0:          # (both halves of d start on 16-byte boundaries: two products straight into the buffers)
+                    for i in range(2):
+                        sgemm(d, 1, A2, x_last, 1, U, bufs[2 * i], U, None, A, U, M, accumulate=True, a_off=i * A)
+                        colsum(d[:, i * A:(i + 1) * A], out=bufs[2 * i + 1], accumulate=True, ld=A2)
+                    return None, None
+                dWh = torch.empty(A2, U, device=dev)
+                sgemm(d, 1, A2, x_last, 1, U, dWh, U, None, A2, U, M)
+                dbh = colsum(d)
+                for i in range(2):
+                    copy2d(dWh, U, bufs[2 * i], U, A, U, None, True, src_off=i * A * U)
+                    copy2d(dbh, A2, bufs[2 * i + 1], A, 1, A, None, True, src_off=i * A)
+                return None, None
+        tgt = _grad_buf(self.head_w)
+        dWh = None if tgt is not None else torch.empty(A2, U, device=dev)
+        sgemm(d, 1, A2, x_last, 1, U, tgt if tgt is not None else dWh, U, None, A2, U, M, accumulate=tgt is not None)
+        tb = _grad_buf(self.head_b)
+        dbh = None
+        if tb is not None:
+            colsum(d, out=tb, accumulate=True)
+        else:
+            dbh = colsum(d)
+        return dWh, dbh
+
     def forward_fused(self, t, x1_ptr, K1, x2_ptr, K2, eps_ptr, raw_ptr, action_ptr, ld_action, min_std, max_std):
         """one policy evaluation at step t with the LayerNorms in the consumers' loaders (csrc/fused_small.hip): L products + the
         head kernel = L + 1 launches instead of 2 L + 2; only the RAW pre-activations are written (self.pre)"""
@@ -1024,15 +1067,7 @@ class ActorTape:
         # parameter gradients go straight into the optimiser's flat gradient buffers (GEMM / reduction epilogues
         # with accumulate) when the parameters have them -- autograd then has nothing to add (one elementwise
         # launch per parameter otherwise); the returned gradient is None for those
-        tgt = _grad_buf(self.head_w)
-        dWh = None if tgt is not None else torch.empty(A2, U, device=dev)
-        sgemm(d, 1, A2, x_last, 1, U, tgt if tgt is not None else dWh, U, None, A2, U, M, accumulate=tgt is not None)
-        tb = _grad_buf(self.head_b)
-        dbh = None
-        if tb is not None:
-            colsum(d, out=tb, accumulate=True)
-        else:
-            dbh = colsum(d)
+        dWh, dbh = self.head_param_grads(d, x_last)
         dy = torch.empty(M, U, device=dev)
         sgemm(d, A2, 1, self.head_w, 1, U, dy, U, None, M, U, A2)
         grads = [None] * len(self.layers)
@@ -1432,6 +1467,17 @@ CONVT_DIRECT = os.environ.get('GENRL_CONVT_DIRECT', '1') != '0'
 CONVT_DIRECT_BWD = os.environ.get('GENRL_CONVT_DIRECT_BWD', '1') != '0'
 
 
+def _nchw_bias_grad(dy, bias):
+    """bias gradient of an NCHW output (the decoder's frames): per-channel sum; under the Optimizer it is added straight into the
+    parameter's flat gradient buffer (-> None: autograd's AccumulateGrad then has nothing to do for it)"""
+    db = dy.sum((0, 2, 3))
+    tgt = _grad_buf(bias)
+    if tgt is None:
+        return db
+    copy2d(db, db.numel(), tgt, db.numel(), 1, db.numel(), None, True)
+    return None
+
+
 class _ConvT2dS2(Function):
     """nn.ConvTranspose2d(k, stride 2) as GEMM + gather-form col2im.  x NHWC (N,Hi,Wi,Ci);
     Wp (Ci, k*k*Co) = weight permuted to (ci, kh, kw, co); returns NHWC."""
@@ -1443,7 +1489,7 @@ class _ConvT2dS2(Function):
         Co = Nw // (k * k)
         M = Nimg * Hi * Wi
         assert not (out_nchw and gamma is not None)
-        if Co <= 4 and k == 6 and Ci == 48 and CONVT_DIRECT and Wp.is_contiguous():
+        if Co <= 4 and k == 6 and Ci == 48 and CONVT_DIRECT and Wp.is_contiguous() and not _p16():
             # the 3-channel end of the decoder: gather form on the fp32 matrix cores, no cols matrix (genrl_convt_small_co_fwd)
             Ho, Wo = 2 * (Hi - 1) + k, 2 * (Wi - 1) + k
             y = torch.empty((Nimg, Co, Ho, Wo) if out_nchw else (Nimg, Ho, Wo, Co), device=x.device)
@@ -1483,7 +1529,8 @@ class _ConvT2dS2(Function):
             dy = dy.reshape(Nimg, Ho, Wo, Co)
         implicit = _implicit_conv(dy, Co) and Ci % 4 == 0 and not ctx.out_nchw
         dx = dW = db = None
-        if CONVT_DIRECT_BWD and ctx.out_nchw and not ctx.fused_ln and Co == 3 and k == 6 and Ci == 48 and Wp.is_contiguous():
+        if (CONVT_DIRECT_BWD and ctx.out_nchw and not ctx.fused_ln and Co == 3 and k == 6 and Ci == 48 and Wp.is_contiguous()
+                and not _p16()):
             # the decoder's 3-channel end: both gradients gather their patch operands from dy itself (genrl_convt_small_co_bwd), no im2col
             if ctx.needs_input_grad[0]:
                 dx = torch.empty(Nimg, Hi, Wi, Ci, device=dy.device)
@@ -1499,7 +1546,7 @@ class _ConvT2dS2(Function):
                 e1 = torch.cuda.Event(enable_timing=True); e1.record()
                 gemm_profile.append((M, Ci, Nw, e0, e1, 'kk/convt_direct_bwd'))
             if ctx.needs_input_grad[2]:
-                db = dy.sum((0, 2, 3))
+                db = _nchw_bias_grad(dy, ctx.bias)
             return dx, dW, db, None, None, None, None, None
         dcols = None if implicit else _im2col(dy, Nimg, Ho, Wo, Co, k, 1 if ctx.out_nchw else 0)   # (M, Nw) patch matrix of dy
         if ctx.needs_input_grad[0]:
@@ -1519,7 +1566,7 @@ class _ConvT2dS2(Function):
             if ctx.fused_ln:
                 db = db_ln
             elif ctx.out_nchw:
-                db = dy.sum((0, 2, 3))
+                db = _nchw_bias_grad(dy, ctx.bias)
             else:
                 db = colsum(dy.reshape(-1, Co))
         return dx, dW, db, None, dg, dbe, None, None
@@ -1700,7 +1747,7 @@ def scan_coop_variant(B, D, T, I=0):
     (GENRL_SCAN_COOP=1|2|auto; auto = one barrier where it exists (B <= 8), else two).  I: width of the input half of the GRU
     weight (the W_h block starts at column I of each row: 16-byte aligned only when I % 4 == 0)."""
     mode = os.environ.get('GENRL_SCAN_COOP', '0').strip().lower()
-    if mode in ('', '0', 'off') or D % 4 or I % 4 or not (8 <= D // 4 <= 256) or B not in (4, 8, 16, 32):
+    if mode in ('', '0', 'off') or _p16() or D % 4 or I % 4 or not (8 <= D // 4 <= 256) or B not in (4, 8, 16, 32):
         return 0
     if mode == 'auto':
         return 1 if B <= 8 else 2
@@ -1794,7 +1841,7 @@ class _GRUSeq(Function):
         BD, B3D = B * D, B * 3 * D
         # few sequences per GPU: the recurrent dgrad d(hm_t) += dpre_t W_h is a weight stream with only D/16
         # column blocks -> K-split into slabs that the next step's gate backward sums (no reduce launch)
-        S = 4 if (B <= 32 and not os.environ.get('GENRL_NO_SCAN_PARTS')) else 0
+        S = 4 if (B <= 32 and not os.environ.get('GENRL_NO_SCAN_PARTS') and not _p16()) else 0
         pa = torch.empty(S, B, D, device=dev) if S else None
         pb = torch.empty(S, B, D, device=dev) if S else None
         cur, nxt, pcur, pnxt = dha, None, pa, None

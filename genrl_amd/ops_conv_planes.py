@@ -157,8 +157,15 @@ def subpixel_ok(xp, Nimg, Hi, Wi, Cs, Cp, k):
     """may genrl_gemm_h2_subpixel take this layer?  xp: planes of the [Nimg Hi Wi][Cs] input (must be uniform-scale); Cs summed
     channels, Cp produced channels, k the stride-2 kernel"""
     T = (k + 1) // 2
-    return (SUBPIXEL and _hl_on() and xp is not None and xp.uniform and (k % 2 == 0 or SUBPIXEL_ODD) and Cs % 8 == 0 and Cs >= 48 and Cp % 4 == 0
-            and xp.cols == Cs and T * T * Cs >= 64 and Nimg * (Hi + T - 1) * (Wi + T - 1) >= min_rows() // 4)
+    if not (SUBPIXEL and _hl_on() and xp is not None and xp.uniform and (k % 2 == 0 or SUBPIXEL_ODD) and Cs % 8 == 0 and Cs >= 48 and Cp % 4 == 0
+            and xp.cols == Cs and T * T * Cs >= 64 and Nimg * (Hi + T - 1) * (Wi + T - 1) >= min_rows() // 4):
+        return False
+    # the kernel's own size limits (genrl_gemm_h2_subpixel: 32-bit byte offsets into the padded planes, 31-bit row count): a layer beyond
+    # them -- larger frames at a larger per-GPU batch -- keeps the GEMM -> col2im form instead of failing
+    Hp, Wp = Hi + 2 * (T - 1), Wi + 2 * (T - 1)
+    ld = (Cs + 63) // 64 * 64
+    plane = Nimg * Hp * Wp * ld
+    return (Nimg * Hp * Wp * ld + plane) * 2 < 0xffffffff and Nimg * (Hp - T + 1) * (Wp - T + 1) <= 0x7fffffff
 
 
 def _subpixel(xp, Nimg, Hi, Wi, Cs, Cp, k, Wsrc, s_ci, s_co, s_tap, bias, out, wkey=None):
@@ -182,7 +189,8 @@ def _subpixel(xp, Nimg, Hi, Wi, Cs, Cp, k, Wsrc, s_ci, s_co, s_tap, bias, out, w
         check(lib().genrl_subpixel_weight(_p(Wsrc), s_ci, s_co, s_tap, Cs, Cp, k, T, _p(wsub), _p(bias), _p(b4_), _stream()), 'subpixel_weight')
         return planes.split(wsub), b4_
     # (once per optimiser step when the caller names the parameter the weight comes from; weight and bias are stepped together)
-    wp, b4 = planes.derived(wkey, ('subpixel', bias is not None), build) if wkey is not None else build()
+    bkey = (id(bias), bias._version) if bias is not None else None      # (a bias edited or swapped without its weight rebuilds too)
+    wp, b4 = planes.derived(wkey, ('subpixel', bkey), build) if wkey is not None else build()
     _, Ho, Wo, _ = out.shape
     check(lib().genrl_gemm_h2_subpixel(xq.ptr(), xq.ld, xq.plane, xq.inv_ptr(), Nimg, Hp, Wp, Cs, T, wp.ptr(), wp.ld, wp.plane, wp.inv_ptr(),
                                        _p(out), Ho, Wo, Cp, _p(b4), _stream()), 'gemm_h2_subpixel')

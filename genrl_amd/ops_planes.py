@@ -104,15 +104,7 @@ class ActorTapePlanes(ops.ActorTape):
         A2, U = self.head_w.shape
         d = self.d_raw.reshape(M, A2)
         x_last = self.y[-1]
-        tgt = _grad_buf(self.head_w)
-        dWh = None if tgt is not None else torch.empty(A2, U, device=dev)
-        sgemm(d, 1, A2, x_last, 1, U, tgt if tgt is not None else dWh, U, None, A2, U, M, accumulate=tgt is not None)
-        tb = _grad_buf(self.head_b)
-        dbh = None
-        if tb is not None:
-            colsum(d, out=tb, accumulate=True)
-        else:
-            dbh = colsum(d)
+        dWh, dbh = self.head_param_grads(d, x_last)
         dy = torch.empty(M, U, device=dev)
         sgemm(d, A2, 1, self.head_w, 1, U, dy, U, None, M, U, A2)
         grads = [None] * len(self.layers)

@@ -81,7 +81,7 @@ class _Desc(ctypes.Structure):          # genrl_split_desc (include/genrl_hip.h)
                 ('transpose', ctypes.c_int)]
 
 
-_dcache = {}             # (id(W), tag) -> [epoch, object derived from W, W.data_ptr(), weakref(W), stream that built it]
+_dcache = {}             # (id(W), tag) -> [epoch, object derived from W, W.data_ptr(), weakref(W), stream that built it, W._version]
 
 
 def derived(W, tag, build):
@@ -93,10 +93,12 @@ def derived(W, tag, build):
         return build()
     key, st = (id(W), tag), _stream()
     ent = _dcache.get(key)
-    if ent is None or ent[0] != _epoch or ent[2] != W.data_ptr() or ent[3]() is not W or ent[4] != st:
+    # (W._version: an in-place edit made through torch -- p.data.copy_, nn.init, a broadcast of weights, an EMA copy -- is seen without an
+    # explicit invalidate; the optimiser's own kernels write through raw pointers and call invalidate)
+    if ent is None or ent[0] != _epoch or ent[2] != W.data_ptr() or ent[3]() is not W or ent[4] != st or ent[5] != W._version:
         if ent is None:
             weakref.finalize(W, _dcache.pop, key, None)
-        ent = _dcache[key] = [_epoch, build(), W.data_ptr(), weakref.ref(W), st]
+        ent = _dcache[key] = [_epoch, build(), W.data_ptr(), weakref.ref(W), st, W._version]
     return ent[1]
 
 

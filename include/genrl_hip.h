@@ -185,11 +185,6 @@ int genrl_actor_head_ln_linear_fwd(const float* y, long ldy, const float* stats,
 long genrl_convt_small_co_bwd_ws_floats(int Ci, int Co);
 int genrl_convt_small_co_bwd(const float* x, const float* Wp, const float* dy, float* dx, float* dWp, float* ws, int Nimg, int Hi, int Wi,
                              int Ci, int Co, int k, void* stream);
-/* A last line for a process that may die (bench.py's optional in-graph attempt under data parallelism): while set, SIGABRT / SIGSEGV write
- * `line` (+ newline) to stdout with write(2) and end the process with status 0 -- the result already measured in the safe mode is not lost to an
- * abort raised on a backend thread.  line == NULL: exit 0 silently (ranks other than 0).  genrl_clear_last_line restores the defaults. */
-int genrl_set_last_line(const char* line);
-int genrl_clear_last_line(void);
 /* ---- sequence-level entry points (csrc/seq.hip; SURVEY 8b rssm_observe_seq): the per-step launch loops of the RSSM scans
  * (EnsembleRSSM.observe, agent/dreamer_utils.py:362-371, 425-457; VideoSSM.update, agent/video_utils.py:150-187) run from ONE call --
  * the same launches in the same order as the per-step entry points above (bit-identical), without ~20 us of host work per launch.

@@ -5,7 +5,7 @@ import csv, sys, collections
 
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'gemm_planes_kernel<' in r['Kernel_Name'] or 'gemm_planes_hl_kernel<' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-log = [tuple(l.split()) for l in open(sys.argv[2]) if l.strip()]
+log = [tuple(l.split()[:4]) for l in open(sys.argv[2]) if l.strip() and l.startswith(('h2/', 'x3/'))]
 assert len(rows) == len(log), (len(rows), len(log))
 # one step = the shortest period of the logged sequence at its end
 P = next(p for p in range(50, len(log) // 2) if log[-p:] == log[-2 * p:-p])

@@ -178,3 +178,66 @@ def test_eager_iterations_do_not_retain_memory():
         assert seen[1] - seen[0] <= 8 << 20, (seen, 'bytes allocated after iterations 5 and 9')
         del ag, batch
         gc.collect()
+
+
+def _accumulate_grad_counter(ag):
+    """-> (counter dict, nodes to keep alive): counts, per parameter, the gradients that arrive at autograd's AccumulateGrad node"""
+    import collections
+    hits, keep = collections.Counter(), []
+    for n, p in ag.named_parameters():
+        rg = p.requires_grad
+        p.requires_grad_(True)
+        node = p.view_as(p).grad_fn.next_functions[0][0]
+        keep.append(node)
+
+        def pre(grads, n=n):
+            if grads[0] is not None:
+                hits[n] += 1
+        node.register_prehook(pre)
+        p.requires_grad_(rg)
+    return hits, keep
+
+
+@pytest.mark.parametrize('mode', ['eager', 'graphed', 'graphed_overlap', 'dreamer_graphed'])
+def test_no_gradient_reaches_autograds_accumulate_grad(mode):
+    """Every parameter gradient of the iteration is written by a kernel epilogue straight into the optimiser's flat gradient buffer; none
+    goes through autograd's AccumulateGrad node.  (Round 4's driver run printed "The AccumulateGrad node's stream does not match the stream
+    of the node that produced the incoming gradient": the policy's stacked output layer and the decoder's last bias still took that route,
+    and their nodes -- created in an eager warm-up on the default stream, kept alive by the previous iteration's outputs -- then received
+    gradients produced on the capture / side stream.)  The warning itself is an error here, on the default stream, under hipGraph capture and
+    with the connector's side stream."""
+    import warnings
+    from genrl_amd import config, noise
+    from genrl_amd.graph import GraphedStep
+    from bench import one_step, dreamer_step, synth_batch
+    B, T = 4, 16
+    dreamer = mode.startswith('dreamer')
+    if dreamer:
+        cfg = config.dreamer_cfg(B, T, device='cuda', **config.dreamer_tiny_overrides())
+        ag = config.make_dreamer_agent(cfg, act_dim=6)
+        step, A = dreamer_step, 6
+    else:
+        cfg = config.default_cfg(B, T, device='cuda', overlap_detached=(mode == 'graphed_overlap'), **config.tiny_overrides())
+        ag = config.make_agent(cfg); ag.wm.viclip_model = Clip()
+        step, A = one_step, 10
+    full = synth_batch(B, T, A=A, seed=1)
+    if dreamer:
+        full.pop('clip_video')
+    b = {k: torch.from_numpy(v).cuda() for k, v in full.items()}
+    hits, keep = _accumulate_grad_counter(ag)
+    with warnings.catch_warnings():
+        warnings.filterwarnings('error', message=".*AccumulateGrad node's stream.*")
+        with noise.static(seed=5):
+            m = step(ag, b)                                   # default stream; its outputs stay referenced across what follows
+            if mode != 'eager':
+                gs = GraphedStep(ag, b, step, warmup=1)
+                m2 = gs(b)
+            else:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):                 # the same iteration again on another stream
+                    m2 = step(ag, b)
+                torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+    assert all(torch.isfinite(torch.as_tensor(v)).all() for v in m2.values())
+    assert not hits, dict(hits)

@@ -45,7 +45,8 @@ def test_bench_two_ranks_on_one_gpu(graph):
 def test_bench_in_graph_attempt_cannot_lose_the_line(watchdog_s):
     """With RCCL the bench measures the cut mode first and THEN tries the collectives inside the graph, under a watchdog.  Forced here on
     the gloo rig (GENRL_BENCH_FORCE_INGRAPH=1), where an in-graph collective cannot work: either the attempt raises and the cut-mode line
-    is printed as usual, or gloo's worker thread ABORTS the process (what happens on this ROCm build) and the C-level last-line handler writes the
+    is printed as usual, or gloo's worker thread ABORTS the process (what happens on this ROCm build) and the bench-side last-line handler
+    (bench_support/last_line.c) writes the
     cut-mode line (watchdog 240 s); or the watchdog fires first (1 ms) and rank 0 prints the cut-mode line it holds; every rank exits 0."""
     if not torch.cuda.is_available():
         pytest.skip('needs MI355X')
@@ -53,5 +54,8 @@ def test_bench_in_graph_attempt_cannot_lose_the_line(watchdog_s):
                        GENRL_BENCH_FORCE_INGRAPH='1', GENRL_INGRAPH_WATCHDOG_S=watchdog_s)
     assert out['n_gpus'] == 2 and out['value'] > 0
     assert 'collectives cut' in out['config']['launch'], out['config']['launch']
+    # what became of the attempt is part of the parsed record (config.launch), not a side key
+    assert '[in-graph collectives:' in out['config']['launch'], out['config']['launch']
     if watchdog_s != '240':
-        assert 'in-graph' in out.get('note', ''), out.get('note')
+        assert 'timed out' in out['config']['launch'], out['config']['launch']
+    assert 'note' not in out
