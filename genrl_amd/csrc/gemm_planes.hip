@@ -104,7 +104,9 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // TM x TN 32x32 blocks per wave (2x2 waves per workgroup); BK = 64 (TM*TN == 1) or 32; NACC class accumulators;
 // FMT 0: x3 (three bf16 planes, six products), 1: h2 (two fp16 planes of the row-scaled value, three products); NS LDS stages
 template <int TM, int TN, int BK, int NACC, int FMT, int NS, bool FOLD = true, bool CONV = false, int PF = 0>
-__global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneSeg s1, float* __restrict__ C, long ldc,
+// (TM TN == 1 with a ring of TWO stages: 64.75 KiB of LDS and <= 256 registers -- two workgroups per CU, for launches of 257 .. 512
+// tiles, whose second round would otherwise wait for the first one's epilogues)
+__global__ __launch_bounds__(256, (TM * TN == 1 && NS == 2 && FMT == 1) ? 2 : 1) void gemm_planes_kernel(PlaneSeg s0, PlaneSeg s1, float* __restrict__ C, long ldc,
                                                          const float* __restrict__ bias, int M, int N, int accumulate,
                                                          int tiles_m, int tiles_n, int xcd_m, SampleEpi smp, ConvGather cg) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -130,6 +132,9 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
   // loads behind the last MFMA, where their latency was exposed once per workgroup
   constexpr int EPI = FMT == 1 ? 4 * (BM + 2 * BN) : 0, EPI_AT = NS * STAGE + (PF ? 1024 : 0);
   __shared__ __attribute__((aligned(1024))) unsigned char lds[EPI_AT + EPI];
+#if PLANES_ABL == 6       /* ablation 6 (scripts/intercept64.py): the launch alone -- same grid, LDS and register footprint, no work */
+  if (M > 0) { if (threadIdx.x == 1023) lds[0] = 0; return; }
+#endif
 
   // XCD-aware tile order (workgroup b runs on XCD b % 8; each XCD gets a compact sub-block of the tile grid)
   int bid = blockIdx.x, tile_m, tile_n;
@@ -436,9 +441,22 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
       self(self, std::integral_constant<int, p + 1>{}, guarded);
     }
   };
+#if PLANES_ABL < 7         /* ablations 7 .. 10: no K loop at all (7: no epilogue either; 9: epilogue without its stores; 10: non-temporal stores) */
   while (it + PERIOD <= nk) run(run, std::integral_constant<int, 0>{}, false);
   run(run, std::integral_constant<int, 0>{}, true);
-  wait_vm<0>();                       // no DMA may be in flight into this workgroup's LDS when it exits
+#else
+  asm volatile("" ::"v"(fr[0][0][0][0]), "v"(fr[0][KS - 1][NB_ - 1][NPL - 1]));
+#endif
+  // (the ring's last slots were issued as re-reads of the final stage into buffers nobody reads: they are drained at the very END of
+  // the kernel -- no DMA may be in flight into this workgroup's LDS when it exits -- so that their round trip runs under the epilogue;
+  // the epilogue's own LDS words sit outside the ring and were covered by the first barrier.  scripts/intercept64.py: -0.x us per launch)
+#if PLANES_ABL == 7
+  wait_vm<0>();
+  if (M > 0) return;
+#endif
+#ifdef PLANES_EARLY_DRAIN
+  wait_vm<0>();
+#endif
 
   // ---- epilogue: lane (l32, h32), register v of block (i, j) = C[m = l32][n = 8 (v/4) + 4 h32 + v%4]
   const float* ainv = ainv_l;
@@ -496,7 +514,14 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
             const float4 cv = *reinterpret_cast<const float4*>(c);
             o[0] += cv.x; o[1] += cv.y; o[2] += cv.z; o[3] += cv.w;
           }
+#if PLANES_ABL == 9
+          asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(c));
+#elif PLANES_ABL == 10 || defined(PLANES_NT_STORE)
+          __builtin_nontemporal_store(o[0], c); __builtin_nontemporal_store(o[1], c + 1);
+          __builtin_nontemporal_store(o[2], c + 2); __builtin_nontemporal_store(o[3], c + 3);
+#else
           *reinterpret_cast<float4*>(c) = make_float4(o[0], o[1], o[2], o[3]);
+#endif
           if constexpr (TM * TN == 1 && FMT == 1) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) lg[4 * gq + v] = o[v];
@@ -563,6 +588,7 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_kernel(PlaneSeg s0, PlaneS
       }
     }
   }
+  wait_vm<0>();                       // no DMA may be in flight into this workgroup's LDS when it exits
 }
 
 // ---- 128x128 tile, h2 operands, PLANE-ALTERNATING half stages -------------------------------------------------------------------------
@@ -796,9 +822,11 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_hl_kernel(PlaneSeg s0, flo
     half_iter(std::integral_constant<int, 0>{});
     half_iter(std::integral_constant<int, 1>{});
   }
+#ifdef PLANES_EARLY_DRAIN
   wait_vm<0>();
+#endif
 
-  // ---- epilogue (as above, TM = TN = 2, NACC = 2)
+  // ---- epilogue (as above, TM = TN = 2, NACC = 2); the ring's trailing re-read DMAs are drained behind it, at the kernel's end
   auto epi_f = [&](int idx) __attribute__((always_inline)) -> float {
     return *reinterpret_cast<const __attribute__((address_space(3))) float*>((uintptr_t)(lds0 + EPI_AT + 4 * idx));
   };
@@ -854,6 +882,7 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_hl_kernel(PlaneSeg s0, flo
         }
       }
   }
+  wait_vm<0>();                        // no DMA may be in flight into this workgroup's LDS when it exits
 }
 
 // ---- fp32 -> x3 planes (three bf16 terms, exact) -------------------------------------------------------------------------------------------
@@ -1273,7 +1302,16 @@ static int gemm_h2_impl(const uint16_t* a0, long a0_ld, long a0_plane, const flo
       default: L64(3, 0);
     }
 #else
-    L64(3, 0);
+    // 257 .. 512 tiles (3200-row products of the 512-wide Dreamer-v3 rollout: 400 tiles): two co-resident workgroups per CU on a
+    // two-stage ring instead of two rounds of one (GENRL_PLANES_2PER=0 / 1: never / always -- experiments)
+    static const char* two_env = getenv("GENRL_PLANES_2PER");
+    const long ntile = (long)tm * tn;
+    // measured (scripts/two_per_cu.py, profiles/r05_two_per_cu.txt): 400 tiles 14.0 -> 11.2 us (K 512), 26.9 -> 23.9 (K 1536); 800 tiles
+    // 25.8 -> 20.2; 1200 tiles K 1024 58 -> 53; but 256 tiles 11.2 -> 13.8 and 768 tiles at K 2048 62 -> 64 (the two-stage ring is too
+    // shallow for long K loops on its own): from 257 tiles up while K <= 1536
+    const bool two = two_env ? two_env[0] == '1' : (ntile > 256 && k0 + k1 <= 1536);
+    if (two && !smp.q) L64(2, 0);
+    else L64(3, 0);
 #endif
 #undef L64
   }
