@@ -452,8 +452,13 @@ class ActorCritic(Module):  # ref :323-462
         metrics = {}
         hor = self.cfg.imag_horizon
         self._target_critic.requires_grad_(False)
+        # the critic update beside the actor's backward, on its own stream: measured per config (profiles/r05_fork_ab.txt) -- it pays only
+        # where the connector updates are running on THEIR side stream at the same time (c2 23.5 -> 23.4 ms, c4 44.2 -> 43.9) and costs
+        # where nothing else runs beside (c3 38.9 -> 40.0 ms, 13.9 -> 15.2 at 8 sequences; c5 9.4 -> 10.1): forked only in the first
+        # case (GENRL_FORK_CRITIC=1 / 0: always / never)
+        fc = os.environ.get('GENRL_FORK_CRITIC', 'auto')
         overlap = (getattr(self.cfg, 'overlap_detached', False) and common.Optimizer.grad_reduce is None
-                   and os.environ.get('GENRL_FORK_CRITIC', '1') != '0')
+                   and fc != '0' and (fc == '1' or streams.pending('detached')))
         with common.RequiresGrad(self.actor):
             seq = world_model.imagine(self.actor, start, is_terminal, hor)
             self._rollout_actor_raw = getattr(world_model, '_last_actor_raw', None)

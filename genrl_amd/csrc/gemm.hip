@@ -1605,7 +1605,10 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
   // M <= 32: always.  33 .. 128 rows with N, K <= 1024 (the rollout's 1024 -> 1024 layers at 4 sequences per GPU): row groups
   // of 32 give 256 workgroups and one launch where the 64x64 tiles need a K split + reduce launch (7.8 vs 11.0 us measured;
   // longer K or wider N favour the tiles again: scripts/small_m.py)
-  const bool skinny_mid = M <= 128 && N <= 1024 && K <= 1024 && !getenv("GENRL_SKINNY_MAX_M");
+  // (round 5: up to 64 rows also the 1536-wide gate products of the 512-wide Dreamer-v3 scan, 64 x 1536 x 1024 forward 11.6 -> 7.9 us and
+  // 64 x 1024 x 1536 dgrad 12.8 -> 9.7 us against tiles + split-K + reduce launch: scripts/small_m_scan.py)
+  const bool skinny_mid = ((M <= 128 && N <= 1024 && K <= 1024) || (M <= 64 && N <= 1536 && K <= 1536 && (N <= 1024 || K <= 1024))) &&
+                          !getenv("GENRL_SKINNY_MAX_M");
   // precision 16 (mode 1: EVERY product rounds both operands to bf16, fp32 accumulation -- the arithmetic oracle/genrl_oracle.py
   // restates as `bf16_operands`): only sgemm_rr_kernel<BF = 1> implements it, so the weight-streaming and tall-stream kernels
   // (fp32 MFMAs fed straight from memory) are bypassed; a product that misses sgemm_rr's alignment preconditions runs on the fallback

@@ -38,3 +38,8 @@ def join(name=None):
         if key[1] == torch.cuda.current_device() and (name is None or key[0] == name):
             cur.wait_stream(_side[key])
             _dirty.discard(key)
+
+
+def pending(name):
+    """has work been forked onto side stream `name` (on the current device) that nobody has joined yet?"""
+    return (name, torch.cuda.current_device()) in _dirty

@@ -1,14 +1,16 @@
 """rocprofv3 kernel trace of a bench run -> per-STEP table: for every kernel name the launches per step, the microseconds per
 launch and the milliseconds per step, over the LAST n replayed steps of the trace (warm-up, capture and any other run-in are cut:
-steps are delimited by the adam_kernel launches, 5 per iteration).  python scripts/kernel_table.py <kernel_trace.csv> [steps]"""
+steps are delimited by the adam_kernel launches, 5 per iteration at c2 / c4, 3 for the DreamerAgent of c3, 2 at c5).
+python scripts/kernel_table.py <kernel_trace.csv> [steps [adam launches per iteration]]"""
 import csv, sys, collections, re
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+API = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows)
 adam = [i for i, e in enumerate(ev) if 'adam_kernel' in e[2]]
-assert len(adam) >= 5 * (nsteps + 1), len(adam)
-lo, hi = adam[-5 * nsteps - 1] + 1, adam[-1] + 1           # kernels of the last nsteps iterations (ordered by start time)
+assert len(adam) >= API * (nsteps + 1), len(adam)
+lo, hi = adam[-API * nsteps - 1] + 1, adam[-1] + 1           # kernels of the last nsteps iterations (ordered by start time)
 seg = ev[lo:hi]
 wall = (seg[-1][1] - ev[lo - 1][1]) / 1e6 / nsteps
 
