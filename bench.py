@@ -557,7 +557,7 @@ def main():
                'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
                'dtype': ('f32' if (ops.F32_MODE == 'f32' and not planes.ENABLED) else
                          'f32 (storage, accumulation, every non-GEMM kernel and the fp32-MFMA GEMMs; the forward / dgrad / weight-gradient '
-                         'products of the imagination rollout, of the Dense+LN+SiLU chains from 512 rows up and of the encoder / decoder '
+                         'products of the imagination rollout, of the Dense+LN+SiLU chains from 320 rows up and of the encoder / decoder '
                          'convolutions take fp32 operands pre-split into two fp16 planes of the scaled value (22 mantissa bits + fp32 '
                          'accumulation of 3 fp16-MFMA products), any remaining 128x128-tile GEMM splits each fp32 operand exactly into 3 bf16 '
                          'terms in registers (6 bf16-MFMA products).  Error vs float64: same order as the fp32 MFMAs\' -- measured 0.4-2x theirs for '

@@ -485,7 +485,12 @@ def linear(x, W, b=None, planes_of_x=None):
     return _LinearPlanes.apply(x, W, b, P, r0)
 
 
-MIN_ROWS_PLANES = 512       # below this the products are launch / latency bound either way
+# rows from which products run on plane operands.  Round 5 (profiles/r05_minrows_ab.txt, whole step, one box): at 384 / 400 rows the plane
+# rollout's 16 + 10 launches per step beat the fp32-operand rollout's 20 + 14 by 15 % / 7 % (17.0 -> 14.5 ms at 12 sequences of c2,
+# 13.9 -> 12.9 at the 8 x 50 per-rank batch of c3 under DP-8), at 256 rows by 8-12 % -- below the 15 % the exactness of the sampled
+# latents on the 256-row c5 case is worth (one near-tie of 8 192 falls on the other side with plane operands): 256 rows stay on
+# the fp32-operand kernels, everything from 320 rows up takes the planes (rounds 2-4: 512)
+MIN_ROWS_PLANES = 320
 
 
 def min_rows():
