@@ -55,7 +55,7 @@ __device__ __forceinline__ int group_argmax(float v, int idx) {
   return idx;
 }
 
-struct MaskedCopy { float* out2; const float* scale; int S; };            // forward: out2 = scale[g / S] * sample
+struct MaskedCopy { float* out2; const float* scale; int S; int* idx2; };  // forward: out2 = scale[g / S] * sample; idx2[g] = class (-1: scale 0)
 struct MaskedGrad { const float* g2; const float* scale; int S; };      // backward: upstream = gsample + scale[g / S] * g2
 
 // sample[g,k] = onehot(argmax_k pn/q) (q == nullptr: mode = argmax pn).  Also optionally writes pn.
@@ -82,7 +82,97 @@ __global__ __launch_bounds__(256) void onehot_fwd_kernel(const float* __restrict
     }
     if (probs) probs[gi * K + k] = c.pn;
     // second copy scaled per sequence row (the is_first reset of the NEXT scan step's previous latent, agent/dreamer_utils.py:433-434)
-    if (mc.out2) mc.out2[gi * K + k] = (k == best) ? (mc.scale ? mc.scale[gi / mc.S] : 1.0f) : 0.0f;
+    const float sc2 = (mc.out2 || mc.idx2) ? (mc.scale ? mc.scale[gi / mc.S] : 1.0f) : 1.0f;
+    if (mc.out2) mc.out2[gi * K + k] = (k == best) ? sc2 : 0.0f;
+    if (mc.idx2 && k == 0) mc.idx2[gi] = sc2 != 0.0f ? best : -1;
+  }
+}
+
+// ---- logits of ONE categorical latent per workgroup + its sample, for few rows (the posterior / prior head of a scan step at <= 64
+// sequences: o_t W^T + b -> OneHotDist.sample, agent/dreamer_utils.py:443-457, 475-490): the weight-streaming product of gemm.hip's
+// skinny_kernel on 32 output columns (two MFMA column blocks; 16 waves split the reduction, fixed-order sum through LDS) with the
+// softmax -> unimix -> exponential-race argmax of dist.hip's onehot_fwd_kernel as its epilogue: one launch instead of two in a chain
+// whose every launch costs ~4 us.  Writes the logits, the one-hot sample, the sample scaled per sequence row (the next step's is_first
+// reset) and the class index (-1 where the scale is 0) for the next step's gather (rowops.hip: onehot_gather_ln_kernel).
+template <int MB>
+__global__ __launch_bounds__(1024) void skinny_sample_kernel(const float* __restrict__ A, long a_ld, const float* __restrict__ B, long b_ld,
+                                                             const float* __restrict__ bias, float* __restrict__ C, long ldc,
+                                                             const float* __restrict__ q, float* __restrict__ sample,
+                                                             float* __restrict__ sample2, int* __restrict__ idx2,
+                                                             const float* __restrict__ scale2, int M, int Kred, int S, float a) {
+  constexpr int NW = 16;
+  __shared__ float red[NW][MB][2][4][64];
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, qd = l >> 4;
+  const int lat = blockIdx.x, n0 = lat * 32;
+  const int m_base = blockIdx.z * (16 * MB);
+  f32x4 acc[MB][2];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) { acc[mb][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mb][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const float* arow[MB];
+  bool rok[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int r = m_base + li + 16 * mb;
+    rok[mb] = r < M;
+    arow[mb] = A + (long)min(r, M - 1) * a_ld;
+  }
+  const float* b0r = B + (long)(n0 + li) * b_ld;
+  const float* b1r = B + (long)(n0 + 16 + li) * b_ld;
+  const int kchunks = Kred >> 4;                         // (host side: Kred % 16 == 0)
+  const int cpw = (kchunks + NW - 1) / NW;
+  const int c0 = w * cpw, c1 = min(c0 + cpw, kchunks);
+#pragma unroll 4
+  for (int c = c0; c < c1; ++c) {
+    const int k = (c << 4) + 4 * qd;
+    float4 av[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      av[mb] = *reinterpret_cast<const float4*>(arow[mb] + k);
+      if (!rok[mb]) av[mb] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float4 b0 = *reinterpret_cast<const float4*>(b0r + k), b1 = *reinterpret_cast<const float4*>(b1r + k);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb].x, b0.x, acc[mb][0], 0, 0, 0);
+      acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb].y, b0.y, acc[mb][0], 0, 0, 0);
+      acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb].z, b0.z, acc[mb][0], 0, 0, 0);
+      acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb].w, b0.w, acc[mb][0], 0, 0, 0);
+      acc[mb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb].x, b1.x, acc[mb][1], 0, 0, 0);
+      acc[mb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb].y, b1.y, acc[mb][1], 0, 0, 0);
+      acc[mb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb].z, b1.z, acc[mb][1], 0, 0, 0);
+      acc[mb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb].w, b1.w, acc[mb][1], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) red[w][mb][j][v][l] = acc[mb][j][v];
+  __syncthreads();
+  // thread t -> (row r = t / 32 of the group, class k = t % 32): the 32 lanes of a half wave hold one latent of one row
+  const int t = threadIdx.x;
+  const int r = t >> 5, k = t & 31;
+  const bool act = r < 16 * MB;
+  const int mb = act ? (r >> 4) : 0, rr = r & 15, jb = k >> 4, cj = k & 15;
+  const int lane = (rr >> 2) * 16 + cj, v = rr & 3;
+  float sum = 0.f;
+#pragma unroll
+  for (int ww = 0; ww < NW; ++ww) sum += red[ww][mb][jb][v][lane];
+  const int orow = m_base + r;
+  const bool valid = act && orow < M;
+  const float logit = sum + (bias ? bias[n0 + k] : 0.f);
+  Cat<32> cat;
+  cat.init(logit, valid, 32, a);
+  const long g = (long)min(orow, M - 1) * S + lat;                  // group index of (row, latent)
+  const float score = valid ? (q ? cat.pn / q[g * 32 + k] : cat.pn) : -INFINITY;
+  const int best = group_argmax<32>(score, k);
+  if (valid) {
+    C[(long)orow * ldc + n0 + k] = logit;
+    sample[g * 32 + k] = (k == best) ? 1.0f : 0.0f;
+    const float sc2 = (sample2 || idx2) ? (scale2 ? scale2[orow] : 1.0f) : 1.0f;
+    if (sample2) sample2[g * 32 + k] = (k == best) ? sc2 : 0.0f;
+    if (idx2 && k == 0) idx2[g] = sc2 != 0.0f ? best : -1;
   }
 }
 
@@ -535,10 +625,10 @@ int genrl_split_h2(const float* x, long ldx, int R, int Cn, uint16_t* out, long 
                    void* stream);
 
 static int onehot_fwd_impl(const float* logits, const float* q, float* sample, float* probs, long G, int K, float unimix,
-                     PlaneOut xo, int rowlen, void* stream, MaskedCopy mc = MaskedCopy{nullptr, nullptr, 1}) {
+                     PlaneOut xo, int rowlen, void* stream, MaskedCopy mc = MaskedCopy{nullptr, nullptr, 1, nullptr}) {
   GENRL_ENTER();
   if (G <= 0) return GENRL_OK;
-  if (mc.out2 && mc.S <= 0) return GENRL_EINVAL;
+  if ((mc.out2 || mc.idx2) && mc.S <= 0) return GENRL_EINVAL;
   if (xo.p && (rowlen <= 0 || xo.ld < rowlen || !xo.inv)) return GENRL_EINVAL;
   return dispatch_w(K, [&](auto w) {
     constexpr int W = decltype(w)::value;
@@ -593,10 +683,31 @@ int genrl_onehot_bwd_h2(const float* logits, const float* gsample, float* dlogit
 /* the scan forms (EnsembleRSSM.observe without single_obs_posterior, csrc/seq.hip): the sample plus a copy scaled per sequence row
  * (G = rows * S groups; sample2 = scale2[g / S] * sample: the next step's reset previous latent), and the straight-through backward of
  * upstream = gsample (may be NULL) + scale2[g / S] * g2 */
-int genrl_onehot_fwd_masked(const float* logits, const float* q, float* sample, float* sample2, const float* scale2, int S, long G,
-                            int K, float unimix, void* stream) {
+int genrl_onehot_fwd_masked(const float* logits, const float* q, float* sample, float* sample2, int* idx2, const float* scale2, int S,
+                            long G, int K, float unimix, void* stream) {
   return onehot_fwd_impl(logits, q, sample, nullptr, G, K, unimix, PlaneOut{nullptr, 0, 0, nullptr}, 1, stream,
-                         MaskedCopy{sample2, scale2, S});
+                         MaskedCopy{sample2, scale2, S, idx2});
+}
+/* logits C (M x S*32, row stride ldc) = A (M x Kred, rows a_ld apart) W^T + bias for a head of S categorical latents of 32 classes
+ * (W: S*32 x Kred, rows b_ld apart) AND their samples in one launch (few rows: M <= 64 is what it is meant for); outputs as
+ * genrl_onehot_fwd_masked's.  Kred % 16 == 0, a_ld / b_ld % 4 == 0, 16-byte aligned operands; returns 1 otherwise. */
+int genrl_linear_sample32(const float* A, long a_ld, const float* W, long b_ld, const float* bias, float* C, long ldc, const float* q,
+                          float* sample, float* sample2, int* idx2, const float* scale2, int M, int S, int Kred, float unimix,
+                          void* stream) {
+  GENRL_ENTER();
+  if (M <= 0 || S <= 0) return GENRL_OK;
+  if (Kred <= 0 || (Kred & 15) || (a_ld & 3) || (b_ld & 3) || ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) ||
+      !C || !sample)
+    return GENRL_EINVAL;
+  dim3 grid(S, 1, M <= 16 ? 1 : cdiv(M, 32)), block(1024);
+  if (M <= 16)
+    hipLaunchKernelGGL((skinny_sample_kernel<1>), grid, block, 0, (hipStream_t)stream, A, a_ld, W, b_ld, bias, C, ldc, q, sample, sample2, idx2,
+                       scale2, M, Kred, S, unimix);
+  else
+    hipLaunchKernelGGL((skinny_sample_kernel<2>), grid, block, 0, (hipStream_t)stream, A, a_ld, W, b_ld, bias, C, ldc, q, sample, sample2, idx2,
+                       scale2, M, Kred, S, unimix);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
 }
 int genrl_onehot_bwd_masked(const float* logits, const float* gsample, const float* g2, const float* scale2, int S, float* dlogits,
                             long G, int K, float unimix, int accumulate, void* stream) {

@@ -913,6 +913,81 @@ __global__ __launch_bounds__(256) void ln_act_fwd_wave_kernel(const float* __res
   }
 }
 
+// x_t = SiLU(LayerNorm(xpre_t)) with xpre_t += onehot(idx) W^T done as a GATHER: the previous latent of a scan step is one-hot (S classes
+// picked), so its product with the latent block of _img_in (agent/dreamer_utils.py:461-463) is the sum of S rows of the TRANSPOSED weight
+// wT [S K][N] -- no matrix product, and the LayerNorm that follows needs no second launch (one wave per sequence row; a scan step's
+// launches cost ~4 us each whatever they do).  idx [M][S]: class per latent, -1 = contributes nothing (is_first reset).  xpre holds the
+// batched half (action columns + bias) on entry and the full pre-activation on return (the backward's LayerNorm input).
+template <int NV>
+__global__ __launch_bounds__(64) void onehot_gather_ln_kernel(const int* __restrict__ idx, int S, int K, const float* __restrict__ wT,
+                                                              long ldw, float* __restrict__ xpre, long ldx,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ y, long ldy, float* __restrict__ mean_out,
+                                                              float* __restrict__ rstd_out, int N, float eps) {
+  const int nv = N >> 2, lane = threadIdx.x;
+  const long row = blockIdx.x;
+  const int my = lane < S ? idx[row * S + lane] : -1;
+  float4* xr = reinterpret_cast<float4*>(xpre + row * ldx);
+  float4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = lane + 64 * i;
+    v[i] = j < nv ? xr[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int s0 = 0; s0 < S; s0 += 8) {                 // eight weight rows in flight per trip; summed in latent order (deterministic)
+    float4 wv[8][NV];
+    bool on[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = s0 + u;
+      const int cls = __shfl(my, s < S ? s : 0, 64);
+      on[u] = s < S && cls >= 0;
+      const float4* wr = reinterpret_cast<const float4*>(wT + ((long)(s < S ? s : 0) * K + (cls >= 0 ? cls : 0)) * ldw);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int j = lane + 64 * i;
+        wv[u][i] = (on[u] && j < nv) ? wr[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) { v[i].x += wv[u][i].x; v[i].y += wv[u][i].y; v[i].z += wv[u][i].z; v[i].w += wv[u][i].w; }
+  }
+  float sm = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = lane + 64 * i;
+    if (j < nv) { xr[j] = v[i]; sm += v[i].x + v[i].y + v[i].z + v[i].w; }
+  }
+  const float mean = wave_sum(sm) / N;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = lane + 64 * i;
+    if (j < nv) {
+      const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += a * a + bb * bb + c * c + d * d;
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / N + eps);
+  float4* yr = reinterpret_cast<float4*>(y + row * ldy);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = lane + 64 * i;
+    if (j < nv) {
+      const float4 g = reinterpret_cast<const float4*>(gamma)[j], b = reinterpret_cast<const float4*>(beta)[j];
+      float4 o;
+      o.x = siluf_((v[i].x - mean) * rstd * g.x + b.x);
+      o.y = siluf_((v[i].y - mean) * rstd * g.y + b.y);
+      o.z = siluf_((v[i].z - mean) * rstd * g.z + b.z);
+      o.w = siluf_((v[i].w - mean) * rstd * g.w + b.w);
+      yr[j] = o;
+    }
+  }
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
 // backward: dx (may alias dy) + per-workgroup partials part[blockIdx.x][np][N] (np = 2: dgamma, dbeta; 3: + column
 // sums of dx), same contract as ln_act_bwd_blk_kernel
 template <int NV>
@@ -1410,6 +1485,24 @@ int genrl_ln_act_fwd_h2u(const float* x, long ldx, const float* gamma, const flo
                          void* stream) {
   if (!yp || !inv) return GENRL_EINVAL;
   return ln_act_fwd_impl(x, ldx, gamma, beta, y, ldy, mean, rstd, M, N, eps, act, PlaneOut{yp, ldp, plane, inv}, stream, true);
+}
+
+/* x = SiLU(LayerNorm(xpre)), xpre (M x N, rows ldx apart) += sum over the S latents of wT[(s K + idx[m][s])][:] first (idx -1: nothing):
+ * the latent half of _img_in for a one-hot previous latent as a gather (see onehot_gather_ln_kernel).  wT: [S K][N] fp32, rows ldw apart.
+ * N % 4 == 0, N <= 1024, S <= 64, ld* % 4 == 0, 16-byte aligned; returns 1 otherwise. */
+int genrl_onehot_gather_ln_fwd(const int* idx, int S, int K, const float* wT, long ldw, float* xpre, long ldx, const float* gamma,
+                               const float* beta, float* y, long ldy, float* mean, float* rstd, int M, int N, float eps, void* stream) {
+  GENRL_ENTER();
+  if (M <= 0) return GENRL_OK;
+  if (!idx || S <= 0 || S > 64 || K <= 0 || (N & 3) || N > 1024 || N <= 0 || (ldw & 3) || (ldx & 3) || (ldy & 3) || !aligned16(wT) ||
+      !aligned16(xpre) || !aligned16(y) || !aligned16(gamma) || !aligned16(beta))
+    return GENRL_EINVAL;
+  const int nv = cdiv(N, 256);
+#define GO(NV) hipLaunchKernelGGL((onehot_gather_ln_kernel<NV>), dim3(M), dim3(64), 0, (hipStream_t)stream, idx, S, K, wT, ldw, xpre, ldx, gamma, beta, y, ldy, mean, rstd, N, eps)
+  if (nv == 1) GO(1); else if (nv == 2) GO(2); else if (nv == 3) GO(3); else GO(4);
+#undef GO
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
 }
 
 static inline int blk_grid_for(int M) { return M < BLK_GRID ? M : BLK_GRID; }

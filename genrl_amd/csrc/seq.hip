@@ -247,7 +247,9 @@ int genrl_imagine_seq_f32_bwd(const genrl_rollout_f32* r, void* st) {
 // ---- EnsembleRSSM.observe WITHOUT single_obs_posterior (conf/defaults/dreamer_v3.yaml:5; agent/dreamer_utils.py:362-371, 425-457): the posterior
 // reads [deter_t, embed_t], so the sampled latent sits inside the recurrence.  What does not feed the recurrence is batched over T by the
 // caller (genrl_amd/ops.py::_ObserveSeq): the action half of _img_in (+ bias) is already in xpre, the embed half of _obs_out (+ bias) already
-// in opre, the prior head runs on all deter afterwards.  Per step, eight dependent launches:
+// in opre, the prior head runs on all deter afterwards.  Per step, eight dependent launches (six with the fused forms: from step 1 on the
+// previous latent is a one-hot sample, so its product is a gather fused with the LayerNorm -- r->idx / r->w_in_sT -- and the head product
+// takes the sample as its epilogue -- r->fuse_sample):
 //   xpre_t += sm_t W_s^T -> LN + SiLU -> x_t (left half of xh_t) -> gpre_t = [x_t | hm_t] W_g^T -> LN + gates -> deter_t (and hm_{t+1} =
 //   mask_{t+1} deter_t into the right half of xh_{t+1}) -> opre_t += deter_t W_od^T -> LN + SiLU -> o_t -> plog_t = o_t W_d^T + b -> sample
 //   -> pst_t (and sm_{t+1} = mask_{t+1} pst_t).
@@ -265,8 +267,13 @@ int genrl_observe_seq_fwd(const genrl_observe* r, void* st) {
   for (int t = 0; t < T; ++t) {
     const long b0 = (long)t * B;
     const bool nxt = t + 1 < T;
-    RC(osg(r, r->sm + b0 * SK, SK, 1, r->w_in_s, r->ld_in_s, 1, r->xpre + b0 * U, U, nullptr, B, U, SK, 1, st));
-    RC(genrl_ln_act_fwd(r->xpre + b0 * U, U, r->in_g, r->in_be, r->xh + b0 * X, X, r->xm + b0, r->xr + b0, B, U, r->in_eps, 1, st));
+    if (r->idx && r->w_in_sT && t > 0) {       // the previous latent is a one-hot sample: gather + LayerNorm in one launch
+      RC(genrl_onehot_gather_ln_fwd(r->idx + b0 * r->S, r->S, r->K, r->w_in_sT, U, r->xpre + b0 * U, U, r->in_g, r->in_be, r->xh + b0 * X, X,
+                                    r->xm + b0, r->xr + b0, B, U, r->in_eps, st));
+    } else {
+      RC(osg(r, r->sm + b0 * SK, SK, 1, r->w_in_s, r->ld_in_s, 1, r->xpre + b0 * U, U, nullptr, B, U, SK, 1, st));
+      RC(genrl_ln_act_fwd(r->xpre + b0 * U, U, r->in_g, r->in_be, r->xh + b0 * X, X, r->xm + b0, r->xr + b0, B, U, r->in_eps, 1, st));
+    }
     RC(osg(r, r->xh + b0 * X, X, 1, r->w_g, r->ld_g, 1, r->gpre + b0 * 3 * D, 3 * D, nullptr, B, 3 * D, X, 0, st));
     RC(genrl_gru_gates_fwd_ld2(r->gpre + b0 * 3 * D, r->xh + b0 * X + U, X, r->gru_g, r->gru_be, r->deter + b0 * D, D,
                                nxt ? r->xh + (b0 + B) * X + U : nullptr, X, (nxt && r->mask) ? r->mask + b0 + B : nullptr, r->gm + b0,
@@ -274,9 +281,16 @@ int genrl_observe_seq_fwd(const genrl_observe* r, void* st) {
     RC(osg(r, r->deter + b0 * D, D, 1, r->w_o, r->ld_o, 1, r->opre + b0 * U, U, r->opre_acc ? nullptr : r->out_b, B, U, D,
            r->opre_acc ? 1 : 0, st));
     RC(genrl_ln_act_fwd(r->opre + b0 * U, U, r->out_g, r->out_be, r->o + b0 * U, U, r->om + b0, r->orr + b0, B, U, r->out_eps, 1, st));
-    RC(osg(r, r->o + b0 * U, U, 1, r->w_d, U, 1, r->plog + b0 * SK, SK, r->dist_b, B, SK, U, 0, st));
-    RC(genrl_onehot_fwd_masked(r->plog + b0 * SK, r->q ? r->q + b0 * SK : nullptr, r->pst + b0 * SK, nxt ? r->sm + (b0 + B) * SK : nullptr,
-                               (nxt && r->mask) ? r->mask + b0 + B : nullptr, r->S, (long)B * r->S, r->K, r->unimix, st));
+    int* idx_next = (nxt && r->idx) ? r->idx + (b0 + B) * r->S : nullptr;
+    if (r->fuse_sample && r->K == 32) {         // head product + sample in one launch
+      RC(genrl_linear_sample32(r->o + b0 * U, U, r->w_d, U, r->dist_b, r->plog + b0 * SK, SK, r->q ? r->q + b0 * SK : nullptr, r->pst + b0 * SK,
+                               nxt ? r->sm + (b0 + B) * SK : nullptr, idx_next, (nxt && r->mask) ? r->mask + b0 + B : nullptr, B, r->S, U,
+                               r->unimix, st));
+    } else {
+      RC(osg(r, r->o + b0 * U, U, 1, r->w_d, U, 1, r->plog + b0 * SK, SK, r->dist_b, B, SK, U, 0, st));
+      RC(genrl_onehot_fwd_masked(r->plog + b0 * SK, r->q ? r->q + b0 * SK : nullptr, r->pst + b0 * SK, nxt ? r->sm + (b0 + B) * SK : nullptr,
+                                 idx_next, (nxt && r->mask) ? r->mask + b0 + B : nullptr, r->S, (long)B * r->S, r->K, r->unimix, st));
+    }
   }
   return GENRL_OK;
 }

@@ -2002,7 +2002,7 @@ class _ObserveArgs(ctypes.Structure):          # genrl_observe (include/genrl_hi
                 + [('w_in_s', _FP), ('ld_in_s', ctypes.c_long), ('w_g', _FP), ('ld_g', ctypes.c_long), ('w_o', _FP),
                    ('ld_o', ctypes.c_long), ('w_d', _FP)]
                 + [(n, _FP) for n in ('in_g', 'in_be', 'gru_g', 'gru_be', 'out_g', 'out_be', 'dist_b', 'mask', 'q')]
-                + [('out_b', _FP), ('opre_acc', _CI)]
+                + [('out_b', _FP), ('opre_acc', _CI), ('idx', _FP), ('w_in_sT', _FP), ('fuse_sample', _CI)]
                 + [(n, _FP) for n in ('sm', 'xpre', 'xh', 'gpre', 'deter', 'opre', 'o', 'plog', 'pst',
                                       'xm', 'xr', 'gm', 'gr', 'om', 'orr', 'ws')]
                 + [('ws_floats', ctypes.c_long)]
@@ -2030,9 +2030,13 @@ def _observe_fwd_py(a):
     for t in range(T):
         b0 = t * B
         nxt = t + 1 < T
-        _sgemm_ptr(a.sm + f * b0 * SK, SK, 1, a.w_in_s, a.ld_in_s, 1, a.xpre + f * b0 * U, U, None, B, U, SK, 1, a.ws, a.ws_floats)
-        check(L.genrl_ln_act_fwd(a.xpre + f * b0 * U, U, a.in_g, a.in_be, a.xh + f * b0 * X, X, a.xm + f * b0, a.xr + f * b0, B, U,
-                                 a.in_eps, 1, st), 'ln_act_fwd')
+        if a.idx and a.w_in_sT and t > 0:
+            check(L.genrl_onehot_gather_ln_fwd(a.idx + f * b0 * S, S, K, a.w_in_sT, U, a.xpre + f * b0 * U, U, a.in_g, a.in_be,
+                                               a.xh + f * b0 * X, X, a.xm + f * b0, a.xr + f * b0, B, U, a.in_eps, st), 'onehot_gather_ln')
+        else:
+            _sgemm_ptr(a.sm + f * b0 * SK, SK, 1, a.w_in_s, a.ld_in_s, 1, a.xpre + f * b0 * U, U, None, B, U, SK, 1, a.ws, a.ws_floats)
+            check(L.genrl_ln_act_fwd(a.xpre + f * b0 * U, U, a.in_g, a.in_be, a.xh + f * b0 * X, X, a.xm + f * b0, a.xr + f * b0, B, U,
+                                     a.in_eps, 1, st), 'ln_act_fwd')
         _sgemm_ptr(a.xh + f * b0 * X, X, 1, a.w_g, a.ld_g, 1, a.gpre + f * b0 * 3 * D, 3 * D, None, B, 3 * D, X, 0, a.ws, a.ws_floats)
         check(L.genrl_gru_gates_fwd_ld2(a.gpre + f * b0 * 3 * D, a.xh + f * (b0 * X + U), X, a.gru_g, a.gru_be, a.deter + f * b0 * D, D,
                                         (a.xh + f * ((b0 + B) * X + U)) if nxt else None, X,
@@ -2042,10 +2046,17 @@ def _observe_fwd_py(a):
                    1 if a.opre_acc else 0, a.ws, a.ws_floats)
         check(L.genrl_ln_act_fwd(a.opre + f * b0 * U, U, a.out_g, a.out_be, a.o + f * b0 * U, U, a.om + f * b0, a.orr + f * b0, B, U,
                                  a.out_eps, 1, st), 'ln_act_fwd')
-        _sgemm_ptr(a.o + f * b0 * U, U, 1, a.w_d, U, 1, a.plog + f * b0 * SK, SK, a.dist_b, B, SK, U, 0, a.ws, a.ws_floats)
-        check(L.genrl_onehot_fwd_masked(a.plog + f * b0 * SK, (a.q + f * b0 * SK) if a.q else None, a.pst + f * b0 * SK,
-                                        (a.sm + f * (b0 + B) * SK) if nxt else None, (a.mask + f * (b0 + B)) if (nxt and a.mask) else None,
-                                        S, B * S, K, a.unimix, st), 'onehot_fwd')
+        idx_next = (a.idx + f * (b0 + B) * S) if (nxt and a.idx) else None
+        m_next = (a.mask + f * (b0 + B)) if (nxt and a.mask) else None
+        if a.fuse_sample and K == 32:
+            check(L.genrl_linear_sample32(a.o + f * b0 * U, U, a.w_d, U, a.dist_b, a.plog + f * b0 * SK, SK, (a.q + f * b0 * SK) if a.q else None,
+                                          a.pst + f * b0 * SK, (a.sm + f * (b0 + B) * SK) if nxt else None, idx_next, m_next, B, S, U,
+                                          a.unimix, st), 'linear_sample32')
+        else:
+            _sgemm_ptr(a.o + f * b0 * U, U, 1, a.w_d, U, 1, a.plog + f * b0 * SK, SK, a.dist_b, B, SK, U, 0, a.ws, a.ws_floats)
+            check(L.genrl_onehot_fwd_masked(a.plog + f * b0 * SK, (a.q + f * b0 * SK) if a.q else None, a.pst + f * b0 * SK,
+                                            (a.sm + f * (b0 + B) * SK) if nxt else None, idx_next, m_next, S, B * S, K, a.unimix, st),
+                  'onehot_fwd')
 
 
 def _observe_bwd_py(a):
@@ -2158,10 +2169,12 @@ class _ObserveSeq(Function):
         nws = max(lib().genrl_sgemm_ws_floats(*s_) for s_ in _observe_shapes(B, SK, U, D))
         ws = torch.empty(max(nws, 1), device=dev)
         a.ws, a.ws_floats = ws.data_ptr(), nws
+        keep = _scan_fuse(a, w_s, T, B, S, K, U, dev)
         if SEQ_C and gemm_profile is None:
             check(lib().genrl_observe_seq_fwd(ctypes.byref(a), _stream()), 'observe_seq_fwd')
         else:
             _observe_fwd_py(a)
+        del keep
         ctx.save_for_backward(emb, am, mask, q, W_in, w_s, b_in, g_in, be_in, W_g, g_g, be_g, W_o, b_o, g_o, be_o, W_d, b_d,
                               sm, xpre, xh, gpre, deter, opre, o, plog, stats)
         ctx.dims = (T, B, S, K, D, U, A, E)
@@ -2249,6 +2262,32 @@ class _ObserveSeq(Function):
                 None, None)
 
 
+OBSERVE_FUSE = os.environ.get('GENRL_OBSERVE_FUSE', '1') != '0'     # the scans' fused forward launches (gather + LayerNorm, head product + sample)
+
+
+def _scan_fuse(a, w_s, T, B, S, K, U, dev):
+    """fill the fused-forward fields of an _ObserveArgs (csrc/seq.hip: six instead of eight launches per step); -> tensors to keep alive"""
+    if not OBSERVE_FUSE or gemm_precision_is_p16():
+        return ()
+    keep = []
+    if U % 4 == 0 and U <= 1024 and S <= 64 and T > 1:
+        if w_s.shape[1] != S * K:               # (the caller's latent block is a column range of the wider weight: compact it first)
+            w_c = torch.empty(U, S * K, device=dev)
+            copy2d(w_s, w_s.shape[1], w_c, S * K, U, S * K)
+            w_s = w_c
+        w_sT = transpose_last2_raw(w_s.reshape(1, U, S * K)).reshape(S * K, U)        # [S K][U]: a latent class = one row
+        idx = torch.empty(T, B, S, dtype=torch.int32, device=dev)
+        a.idx, a.w_in_sT = idx.data_ptr(), w_sT.data_ptr()
+        keep += [w_sT, idx]
+    if K == 32 and U % 16 == 0:
+        a.fuse_sample = 1
+    return tuple(keep)
+
+
+def gemm_precision_is_p16():
+    return lib().genrl_gemm_precision() == 1
+
+
 def _observe_shapes(B, SK, U, D):
     X = U + D
     return [(B, U, SK), (B, 3 * D, X), (B, U, D), (B, SK, U), (B, D, U), (B, X, 3 * D)]
@@ -2309,8 +2348,10 @@ def rssm_imagine_seq(act, stoch0, deter0, q, S, K, W_in, b_in, g_in, be_in, W_g,
     nws = max(lib().genrl_sgemm_ws_floats(*s_) for s_ in _observe_shapes(B, SK, U, D))
     ws = torch.empty(max(nws, 1), device=dev)
     a.ws, a.ws_floats = ws.data_ptr(), nws
+    keep = _scan_fuse(a, w_s, T, B, S, K, U, dev)
     if SEQ_C and gemm_profile is None:
         check(lib().genrl_observe_seq_fwd(ctypes.byref(a), _stream()), 'observe_seq_fwd')
     else:
         _observe_fwd_py(a)
+    del keep
     return deter, plog, pst

@@ -287,6 +287,10 @@ typedef struct {
   const float* in_g; const float* in_be; const float* gru_g; const float* gru_be; const float* out_g; const float* out_be;
   const float* dist_b; const float* mask; const float* q;
   const float* out_b; int opre_acc;   /* opre_acc 1: opre holds the batched half on entry (observe); 0: opre_t = deter_t w_o^T + out_b (imagine) */
+  /* fused forward launches (both NULL / 0: the eight-launch form): idx (T, B, S) int32 scratch + w_in_sT = the latent block of _img_in
+   * TRANSPOSED ([S K][U], rows U apart): from step 1 on the latent half of _img_in is a gather fused with its LayerNorm
+   * (genrl_onehot_gather_ln_fwd); fuse_sample 1 (K == 32): head product + sample in one launch (genrl_linear_sample32): 6 launches per step */
+  int* idx; const float* w_in_sT; int fuse_sample;
   float* sm; float* xpre; float* xh; float* gpre; float* deter; float* opre; float* o; float* plog; float* pst;
   float* xm; float* xr; float* gm; float* gr; float* om; float* orr;
   float* ws; long ws_floats;
@@ -448,8 +452,21 @@ int genrl_onehot_bwd(const float* logits, const float* gsample, float* dlogits, 
 /* the scan forms (EnsembleRSSM.observe without single_obs_posterior, genrl_observe_seq_*): G = rows * S groups; the forward also writes
  * sample2 = scale2[g / S] * sample (the next step's is_first-reset previous latent, agent/dreamer_utils.py:433-434; sample2 may be NULL);
  * the backward's upstream is gsample (may be NULL) + scale2[g / S] * g2 (g2 may be NULL; scale2 NULL = 1) */
-int genrl_onehot_fwd_masked(const float* logits, const float* q, float* sample, float* sample2, const float* scale2, int S, long G,
-                            int K, float unimix, void* stream);
+int genrl_onehot_fwd_masked(const float* logits, const float* q, float* sample, float* sample2, int* idx2, const float* scale2, int S,
+                            long G, int K, float unimix, void* stream);
+/* (idx2, int32 [G], may be NULL: the sampled class of every group, -1 where scale2 is 0 -- what genrl_onehot_gather_ln_fwd reads)
+ * The head product AND the sample in one launch, for few rows (M <= 64 is what it is meant for) and 32-class latents: logits C (M x S*32,
+ * rows ldc apart) = A (M x Kred, rows a_ld apart) W^T + bias (W: S*32 x Kred, rows b_ld apart; agent/dreamer_utils.py:443-457, 475-490),
+ * outputs as genrl_onehot_fwd_masked's.  Kred % 16 == 0, a_ld / b_ld % 4 == 0, 16-byte aligned operands; returns 1 otherwise. */
+int genrl_linear_sample32(const float* A, long a_ld, const float* W, long b_ld, const float* bias, float* C, long ldc, const float* q,
+                          float* sample, float* sample2, int* idx2, const float* scale2, int M, int S, int Kred, float unimix,
+                          void* stream);
+/* x = SiLU(LayerNorm(xpre)) after xpre (M x N, rows ldx apart) += sum over the S latents of wT[(s K + idx[m][s])][:] (idx -1: nothing):
+ * the latent block of _img_in applied to a ONE-HOT previous latent as a gather of rows of the transposed weight wT [S K][N] (rows ldw
+ * apart) -- no product -- with the LayerNorm + SiLU that follows (agent/dreamer_utils.py:461-463) in the same launch.  xpre holds the
+ * batched half (action columns + bias) on entry and the full pre-activation on return.  N % 4 == 0, N <= 1024, S <= 64. */
+int genrl_onehot_gather_ln_fwd(const int* idx, int S, int K, const float* wT, long ldw, float* xpre, long ldx, const float* gamma,
+                               const float* beta, float* y, long ldy, float* mean, float* rstd, int M, int N, float eps, void* stream);
 int genrl_onehot_bwd_masked(const float* logits, const float* gsample, const float* g2, const float* scale2, int S, float* dlogits,
                             long G, int K, float unimix, int accumulate, void* stream);
 /* KL(Independent(OneHotDist(lp)) || Independent(OneHotDist(lq))) per row + entropies

@@ -27,7 +27,7 @@ def _rssm(S, K, D, U, E, A, seed):
     return r
 
 
-def _run(case, mode, seed=0, with_state=True):
+def _run(case, mode, seed=0, with_state=True, fuse=True):
     from genrl_amd import noise as gnoise
     T, B, S, K, D, U, E, A = case
     r = _rssm(S, K, D, U, E, A, seed)
@@ -52,8 +52,9 @@ def _run(case, mode, seed=0, with_state=True):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     from genrl_amd import ops
-    seq_c = ops.SEQ_C
+    seq_c, fuse_was = ops.SEQ_C, ops.OBSERVE_FUSE
     ops.SEQ_C = mode != 'python'
+    ops.OBSERVE_FUSE = fuse
     try:
         with gnoise.inject(sites):
             post, prior = r.observe(embed, action, is_first, state)
@@ -61,7 +62,7 @@ def _run(case, mode, seed=0, with_state=True):
                 + (prior['stoch'] * w['qs']).sum() + (prior['logit'] * w['ql']).sum())
         loss.backward()
     finally:
-        ops.SEQ_C = seq_c
+        ops.SEQ_C, ops.OBSERVE_FUSE = seq_c, fuse_was
         for k, v in old.items():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
     torch.cuda.synchronize()
@@ -77,9 +78,12 @@ def _run(case, mode, seed=0, with_state=True):
 
 @pytest.mark.parametrize('case', CASES)
 @pytest.mark.parametrize('with_state', [False, True])
-def test_observe_scan_matches_the_stepwise_form(case, with_state):
+@pytest.mark.parametrize('fuse', [False, True])
+def test_observe_scan_matches_the_stepwise_form(case, with_state, fuse):
+    """fuse: the six-launch forward (the one-hot latent's product as a gather fused with its LayerNorm, the head product with the sample
+    as its epilogue: genrl_onehot_gather_ln_fwd, genrl_linear_sample32) against the same stepwise reference"""
     ref = _run(case, 'stepwise', seed=sum(case), with_state=with_state)
-    got = _run(case, 'scan', seed=sum(case), with_state=with_state)
+    got = _run(case, 'scan', seed=sum(case), with_state=with_state, fuse=fuse)
     assert set(ref) == set(got), set(ref) ^ set(got)
     for k in ('post.stoch', 'prior.stoch'):
         assert torch.equal(got[k], ref[k]), k                    # sampled latents: exact
