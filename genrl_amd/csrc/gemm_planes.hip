@@ -618,11 +618,23 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_hl_kernel(PlaneSeg s0, flo
     int bid = blockIdx.x;
     const int ntiles = tiles_m * tiles_n;
     const int x = bid % 8, i = bid / 8;
+    const int order = xcd_m >> 8;          // experiments (GENRL_HL_ORDER): how an XCD walks its sub-block
+    xcd_m &= 255;
     if (xcd_m > 0) {
       const int sub_m = tiles_m / xcd_m, sub_n = tiles_n / (8 / xcd_m);
       const int xm = x / (8 / xcd_m), xn = x % (8 / xcd_m);
-      tile_m = xm * sub_m + i / sub_n;
-      tile_n = xn * sub_n + i % sub_n;
+      int im = i / sub_n, in = i % sub_n;
+      if (order == 1 && sub_m % 8 == 0 && sub_n % 4 == 0) {
+        // rounds of 8 row panels x 4 column panels (32 resident tiles), consecutive rounds sharing one operand: column halves
+        // inside a row block in snake order, so that every round keeps either its A panels or its B panels from the round before
+        const int nb_n = sub_n / 4, blk = i / 32, j = i % 32;
+        const int rb = blk / nb_n, cbq = blk % nb_n, cb = (rb & 1) ? nb_n - 1 - cbq : cbq;
+        im = rb * 8 + j / 4; in = cb * 4 + j % 4;
+      } else if (order == 2) {              // column-major inside the sub-block
+        im = i % sub_m; in = i / sub_m;
+      }
+      tile_m = xm * sub_m + im;
+      tile_n = xn * sub_n + in;
     } else {
       const int q = ntiles / 8, r = ntiles % 8;
       bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
@@ -1106,6 +1118,11 @@ __global__ __launch_bounds__(256) void split_h2_t_batch_kernel(SplitBatch b) {
 static inline void log_launch(const char* family, long M, long N, long K, double bytes) { genrl_log_launch(family, M, N, K, bytes); }
 static inline double kk_bytes(long M, long N, long K) { return 4.0 * ((double)M * K + (double)N * K + (double)M * N); }
 // the 128x128 products on the plane-alternating kernel (gemm_planes_hl_kernel); GENRL_PLANES_HL=0: the two-whole-stages kernel
+// how an XCD walks its sub-block of 128 x 128 tiles (gemm_planes_hl_kernel).  1 (default since round 5): rounds of 8 row panels x 4 column
+// panels in snake order -- 16384 x 1024 x 1024 122.2 -> 116.8 us, 16384 x 1536 x 1024 180.2 -> 164.8, K = 2048 202.3 -> 197.0 against 0 =
+// row-major over the sub-block (rounds of 4 x 8); the L2-miss bytes do NOT change (201.8 MB per launch either way = the compulsory 6 MB per
+// round of 32 resident tiles: no operand survives from one round to the next in a 4 MiB L2), profiles/r05_hl_order.txt
+static int hl_order() { static const int o = getenv("GENRL_HL_ORDER") ? atoi(getenv("GENRL_HL_ORDER")) : 1; return o; }
 static bool hl_on() { static const bool on = !getenv("GENRL_PLANES_HL") || getenv("GENRL_PLANES_HL")[0] != '0'; return on; }
 int g_planes_nosplit = 0;        // experiments: 1 = no row split against wave quantisation (GENRL_PLANES_NOSPLIT)
 int g_planes_variant = 0;        // experiments (scripts/cold_bench.py): ring depth / prefetch distance variants
@@ -1136,6 +1153,8 @@ int genrl_split_x3(const float* x, long ldx, int R, int Cn, uint16_t* out, long 
 }
 
 static int xcd_split(int tm, int tn) {   // xm XCDs along m (1, 2, 4, 8) such that the grid divides, squarest sub-block
+  static const char* force = getenv("GENRL_XCD_M");          // experiments: force the split (if it divides the grid)
+  if (force) { const int xm = atoi(force); if (xm > 0 && 8 % xm == 0 && tm % xm == 0 && tn % (8 / xm) == 0) return xm; }
   int best = 0; double bs = 1e30;
   for (int xm = 1; xm <= 8; xm *= 2) {
     const int xn = 8 / xm;
@@ -1279,7 +1298,7 @@ static int gemm_h2_impl(const uint16_t* a0, long a0_ld, long a0_plane, const flo
                                                                                            xcd_split(tm, tn), SampleEpi{}, ConvGather{});
 #endif
       else if (hl_on())
-        gemm_planes_hl_kernel<false><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, C, ldc, bs, M, N, acc, tm, tn, xcd_split(tm, tn), ConvGather{});
+        gemm_planes_hl_kernel<false><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, C, ldc, bs, M, N, acc, tm, tn, xcd_split(tm, tn) | (hl_order() << 8), ConvGather{});
       else
         gemm_planes_kernel<2, 2, 64, 2, 1, 2, false><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
                                                                                            xcd_split(tm, tn), SampleEpi{}, ConvGather{});
