@@ -136,8 +136,8 @@ WORKLOADS = {
 
 
 # kernel family (the label the library's launch log uses, csrc/common.h: genrl_log_launch) of a rocprofv3 kernel name
-_FAMILIES = (('h2/64', ('gemm_planes_kernel<1, 1, 64',)), ('h2/128', ('gemm_planes_hl_kernel<false>', 'gemm_planes_kernel<2, 2')),
-             ('h2/gather128', ('gemm_planes_hl_kernel<true>',)), ('h2tn', ('gemm_planes_tn_kernel<false>',)),
+_FAMILIES = (('h2/64', ('gemm_planes_kernel<1, 1, 64',)), ('h2/128', ('gemm_planes_hl_kernel<false>', 'gemm_planes_kernel<2, 2', 'gemm_planes_hlw_kernel<false')),
+             ('h2/gather128', ('gemm_planes_hl_kernel<true>', 'gemm_planes_hlw_kernel<true')), ('h2tn', ('gemm_planes_tn_kernel<false>',)),
              ('h2tn/conv', ('gemm_planes_tn_kernel<true>',)), ('f32/tile64', ('sgemm_rr_kernel<2', 'sgemm_kernel<64')),
              ('f32/tile128', ('sgemm_rr_kernel<4', 'sgemm_kernel<128')), ('f32/tall', ('sgemm_tall_kernel',)),
              ('f32/skinny', ('skinny_kernel',)))

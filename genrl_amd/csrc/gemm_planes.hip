@@ -897,6 +897,299 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_hl_kernel(PlaneSeg s0, flo
   wait_vm<0>();                        // no DMA may be in flight into this workgroup's LDS when it exits
 }
 
+// ---- 128 x 192 tile (round 5): the half-stage kernel above with THREE 32 x 32 blocks per wave along n ------------------------------------
+// The sub-pixel products have N = 4 C_out = 192 columns (agent/dreamer_utils.py:686-706 in gather form): 1.5 of two 128-wide column tiles,
+// a quarter of the MFMA work on zero padding.  Same structure as gemm_planes_hl_kernel -- half stages (h planes, then l planes of a 64-k
+// block), fragments of a half stage in registers (two h sets, one l set), one barrier per half-iteration, side operations between the
+// MFMAs -- with BN = 64 TJ: a half stage is (128 + 192) x 128 B = 40 KiB, so the ring holds THREE of them (a DMA has two half-iterations
+// to land, each 1.5 x as long as a 128-wide one); its 40 one-KiB pieces (16 of A, 24 of B) are dealt ten per wave in order, so a wave
+// may carry pieces of both operands (two running source pointers, selected per piece by a wave-uniform flag).  432 registers.
+template <bool CONV, int TJ, int WGM = 2>
+__global__ __launch_bounds__(256, 1) void gemm_planes_hlw_kernel(PlaneSeg s0, float* __restrict__ C, long ldc, const float* __restrict__ bias,
+                                                                 int M, int N, int accumulate, int tiles_m, int tiles_n, int xcd_m,
+                                                                 ConvGather cg) {
+  // WGM waves along m (2: 2 x 2 waves, 128 x 64 TJ tile; 4: 4 x 1 waves, 256 x 32 TJ tile), every wave 2 x TJ blocks of 32 x 32
+  constexpr int WGN = 4 / WGM, BM = 64 * WGM, BN = 32 * TJ * WGN, ROWB = 128, HALF = (BM + BN) * ROWB, NS = 3, KS = 4, NB = 2 + TJ;
+  constexpr int APIECES = BM / 8, NPT = (BM + BN) / 8, NP = NPT / 4;
+  static_assert(NPT % 4 == 0, "pieces deal evenly over four waves");
+  constexpr int EPI = 4 * (BM + 2 * BN), EPI_AT = NS * HALF;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[EPI_AT + EPI];
+  int tile_m, tile_n;
+  {
+    int bid = blockIdx.x;
+    const int ntiles = tiles_m * tiles_n;
+    const int x = bid % 8, i = bid / 8;
+    if (xcd_m > 0) {
+      const int sub_m = tiles_m / xcd_m, sub_n = tiles_n / (8 / xcd_m);
+      const int xm = x / (8 / xcd_m), xn = x % (8 / xcd_m);
+      tile_m = xm * sub_m + i / sub_n;
+      tile_n = xn * sub_n + i % sub_n;
+    } else {
+      const int q = ntiles / 8, r = ntiles % 8;
+      bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+      tile_m = bid / tiles_n;
+      tile_n = bid % tiles_n;
+    }
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = WGM == 2 ? (wave >> 1) : wave, wn = WGM == 2 ? (wave & 1) : 0;
+  const unsigned lds0 = (unsigned)(uintptr_t)lds;
+  // ---- DMA side: piece p = wave * NP + i of a half stage; p < APIECES: rows 8 p .. of A's tile, else rows 8 (p - APIECES) .. of B's
+  const int r_in = lane >> 3, slot = lane & 7;
+  const char* gA = reinterpret_cast<const char*>(s0.a);
+  const char* gB = reinterpret_cast<const char*>(s0.b);
+  const long pbA = s0.a_plane * 2, pbB = s0.b_plane * 2;
+  unsigned voff[NP];
+  unsigned koff[2] = {0u, 0u};
+  int kch[2] = {0, 0}, kkw[2] = {0, 0}, kkk[2] = {0, 0};
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int p = wave * NP + i;
+    if (p < APIECES) {
+      const int row = p * 8 + r_in;
+      if constexpr (CONV) {
+        const int m = min(m0 + row, M - 1);
+        const int n_img = m / (cg.Ho * cg.Wo), rem = m - n_img * (cg.Ho * cg.Wo);
+        const int oy = rem / cg.Wo, ox = rem - oy * cg.Wo;
+        voff[i] = (unsigned)((((long)(n_img * cg.H + cg.s * oy) * cg.W + cg.s * ox) * s0.a_ld) * 2);
+      } else {
+        voff[i] = (unsigned)(((long)min(m0 + row, M - 1) * s0.a_ld) * 2 + ((slot ^ ((row >> 1) & 7)) << 4));
+      }
+    } else {
+      const int row = (p - APIECES) * 8 + r_in;
+      voff[i] = (unsigned)(((long)min(n0 + row, N - 1) * s0.b_ld) * 2 + ((slot ^ ((row >> 1) & 7)) << 4));
+    }
+  }
+  if constexpr (CONV) {
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {          // (row >> 1) & 7 = 4 (piece & 1) + (r_in >> 1): one chunk state per piece parity
+      const int f = (4 * par + (r_in >> 1)) & 7;
+      const int kk = 8 * (slot ^ f);
+      const int tap = kk / cg.C, ch = kk - tap * cg.C, kh = tap / cg.k, kw = tap - kh * cg.k;
+      kkk[par] = kk; kch[par] = ch; kkw[par] = kw;
+      koff[par] = (unsigned)((((long)kh * cg.W + kw) * s0.a_ld + ch) * 2);
+    }
+  }
+  const unsigned piece0 = lds0 + wave * NP * 1024;
+  // ---- fragment side
+  const int l32 = lane & 31, h32 = lane >> 5;
+  const int f_rd = (l32 >> 1) & 7;
+  unsigned a_s[KS], b_s[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const unsigned xo = (unsigned)(((2 * s + h32) ^ f_rd) << 4);
+    a_s[s] = lds0 + (wm * 64 + l32) * ROWB + xo;
+    b_s[s] = lds0 + BM * ROWB + (wn * 32 * TJ + l32) * ROWB + xo;
+  }
+  f32x16 acc[2][2][TJ];                // [0: low class (h*l + l*h, x 2^11) | 1: h*h][i][j]
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.f;
+  u32x4 Hf[2][KS][NB], Lf[KS][NB];     // [k-step][block: 0, 1 = A rows, 2 .. = B rows]
+  auto ldfrag = [&](unsigned addr) __attribute__((always_inline)) -> u32x4 {
+    return *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((uintptr_t)addr);
+  };
+  auto read_one = [&](u32x4 (&dst)[KS][NB], int r, int buf) __attribute__((always_inline)) {
+    const int s = r / NB, blk = r % NB;
+    dst[s][blk] = blk < 2 ? ldfrag(a_s[s] + blk * 32 * ROWB + buf * HALF) : ldfrag(b_s[s] + (blk - 2) * 32 * ROWB + buf * HALF);
+  };
+  auto mma = [&](f32x16& c, const u32x4& bfr, const u32x4& afr) __attribute__((always_inline)) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, bfr), __builtin_bit_cast(f16x8_t, afr), c, 0, 0, 0);
+  };
+  {   // epilogue factors ahead of everything else
+    const float* src = wave == 0 ? s0.a_inv : (wave == 1 ? s0.b_inv : (wave == 2 ? bias : nullptr));
+    const int base = wave == 0 ? m0 : n0, lim = (wave == 0 ? M : N) - 1;
+    const unsigned dst = lds0 + EPI_AT + (wave == 0 ? 0 : (wave == 1 ? 4 * BM : 4 * (BM + BN)));
+    if (src) {
+#pragma unroll
+      for (int j = 0; j < ((BM > BN ? BM : BN) + 63) / 64; ++j)
+        if (64 * j + lane < (wave == 0 ? BM : BN))          // (BN = 96: the second load's upper lanes would land on the bias words)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + min(base + 64 * j + lane, lim)),
+                                           (__attribute__((address_space(3))) void*)(uintptr_t)(dst + 256 * j), 4, 0, 0);
+    }
+  }
+  const int nu = 2 * (s0.k / 64);
+  int issued = 0;
+  auto next_half = [&]() __attribute__((always_inline)) {
+    if (issued > 0 && issued < nu) {
+      if (issued & 1) { gA += pbA; gB += pbB; }
+      else {
+        gB += 128 - pbB;
+        if constexpr (CONV) {
+          gA -= pbA;                                           // (the gather moves by its own chunk states)
+          const unsigned ld2 = (unsigned)(s0.a_ld * 2);
+#pragma unroll
+          for (int par = 0; par < 2; ++par) {
+            if (kkk[par] + 64 + 8 <= cg.K) {
+              kkk[par] += 64;
+              int ch = kch[par] + 64, kw = kkw[par];
+              unsigned off = koff[par] + 128u;
+#pragma unroll
+              for (int rep = 0; rep < 2; ++rep)
+                if (ch >= cg.C) {
+                  ch -= cg.C; off -= (unsigned)(cg.C * 2);
+                  ++kw; off += ld2;
+                  if (kw == cg.k) { kw = 0; off += (unsigned)(cg.W - cg.k) * ld2; }
+                }
+              kch[par] = ch; kkw[par] = kw; koff[par] = off;
+            }
+          }
+        } else {
+          gA += 128 - pbA;
+        }
+      }
+    }
+    ++issued;
+  };
+  auto issue_one = [&](int buf, int i) __attribute__((always_inline)) {
+    const int p = wave * NP + i;                               // (wave-uniform)
+    const unsigned dst = piece0 + buf * HALF + i * 1024;
+    if (p < APIECES) {
+      if constexpr (CONV) glds16(gA + (size_t)(voff[i] + koff[p & 1]), dst);
+      else glds16(gA + (size_t)voff[i], dst);
+    } else {
+      glds16(gB + (size_t)voff[i], dst);
+    }
+  };
+#pragma unroll
+  for (int st = 0; st < NS; ++st) {
+    next_half();
+#pragma unroll
+    for (int i = 0; i < NP; ++i) issue_one(st, i);
+  }
+  next_half();                         // books half stage NS (issued by half-iteration 0)
+  wait_vm<(NS - 1) * NP>();
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int r = 0; r < KS * NB; ++r) read_one(Hf[0], r, 0);
+
+  int u = 0;
+  // half-iteration u: buffer BUF = u % 3; LPH = u & 1 (its l planes: h*l and l*h products; else h*h); HS = (u >> 1) & 1 = the h set
+  auto half_iter = [&](auto BC, auto LC, auto HC) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(BC)::value, HS = decltype(HC)::value;
+    constexpr bool LPH = decltype(LC)::value != 0;
+    constexpr int NM = LPH ? 4 * KS * TJ : 2 * KS * TJ, KB = 2, NSIDE = KS * NB + NP;
+    constexpr int PER = (NSIDE + (NM - KB) - 1) / (NM - KB);
+    static_assert((NSIDE + PER - 1) / PER <= NM - KB, "not enough MFMAs to carry the side operations");
+    // side operations in the order read, read, DMA, read, read, DMA, ... while both kinds last (NPAIR triples), then the rest of one kind
+    constexpr int NR = KS * NB, NPAIR = NP < NR / 2 ? NP : NR / 2;
+    auto mfma_one = [&](int m) __attribute__((always_inline)) {
+      if constexpr (!LPH) {                         // m = s * 2 TJ + i * TJ + j
+        const int s = m / (2 * TJ), i = (m / TJ) % 2, j = m % TJ;
+        mma(acc[1][i][j], Hf[HS][s][2 + j], Hf[HS][s][i]);
+      } else {                                      // m = s * 4 TJ + t * 2 TJ + i * TJ + j; t 0: l(A) * h(B), 1: h(A) * l(B)
+        const int s = m / (4 * TJ), t = (m / (2 * TJ)) % 2, i = (m / TJ) % 2, j = m % TJ;
+        if (t == 0) mma(acc[0][i][j], Hf[HS][s][2 + j], Lf[s][i]);
+        else mma(acc[0][i][j], Lf[s][2 + j], Hf[HS][s][i]);
+      }
+    };
+#pragma unroll
+    for (int m = 0; m < KB; ++m) mfma_one(m);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_vm<(NS - 2) * NP>();                       // half stage u + 1 landed (own DMAs)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = KB; m < NM; ++m) {
+      mfma_one(m);
+#pragma unroll
+      for (int o = (m - KB) * PER; o < (m - KB + 1) * PER; ++o) {
+        if (o >= NSIDE) continue;
+        const bool tri = o < 3 * NPAIR;
+        const bool dma = tri ? (o % 3 == 2) : (NR == 2 * NPAIR);
+        if (dma) {
+          issue_one(BUF, tri ? o / 3 : NPAIR + (o - 3 * NPAIR));
+        } else {
+          const int r = tri ? o - o / 3 : 2 * NPAIR + (o - 3 * NPAIR);
+          if constexpr (LPH) read_one(Hf[1 - HS], r, (BUF + 1) % NS);      // h planes of the next block
+          else read_one(Lf, r, (BUF + 1) % NS);                              // l planes of this block
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    next_half();
+    ++u;
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+  // (buffer, plane half, h set) of half-iteration u = (u % 3, u & 1, (u >> 1) & 1): period 12
+#define HLW_PAIR(B0, B1, H) half_iter(B0{}, I0{}, H{}); half_iter(B1{}, I1{}, H{})
+  while (u + 12 <= nu) {
+    HLW_PAIR(I0, I1, I0); HLW_PAIR(I2, I0, I1); HLW_PAIR(I1, I2, I0); HLW_PAIR(I0, I1, I1); HLW_PAIR(I2, I0, I0); HLW_PAIR(I1, I2, I1);
+  }
+  if (u + 2 <= nu) { HLW_PAIR(I0, I1, I0); }      // (nu is even: up to five more blocks, each at its fixed phase of the period)
+  if (u + 2 <= nu) { HLW_PAIR(I2, I0, I1); }
+  if (u + 2 <= nu) { HLW_PAIR(I1, I2, I0); }
+  if (u + 2 <= nu) { HLW_PAIR(I0, I1, I1); }
+  if (u + 2 <= nu) { HLW_PAIR(I2, I0, I0); }
+#undef HLW_PAIR
+
+  // ---- epilogue (as gemm_planes_hl_kernel's, TJ column blocks per wave); the ring's trailing re-read DMAs are drained behind it
+  auto epi_f = [&](int idx) __attribute__((always_inline)) -> float {
+    return *reinterpret_cast<const __attribute__((address_space(3))) float*>((uintptr_t)(lds0 + EPI_AT + 4 * idx));
+  };
+  auto epi_f4 = [&](int idx) __attribute__((always_inline)) -> float4 {
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    const f32x4_ t = *reinterpret_cast<const __attribute__((address_space(3))) f32x4_*>((uintptr_t)(lds0 + EPI_AT + 4 * idx));
+    return make_float4(t[0], t[1], t[2], t[3]);
+  };
+  const bool vec_c = ((ldc & 3) == 0) && (((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0);
+  const bool shuffle = CONV && cg.sCo > 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = m0 + (wm * 2 + i) * 32 + l32;
+    if (row >= M) continue;
+    const float ra = s0.a_inv ? epi_f((wm * 2 + i) * 32 + l32) : 1.f;
+    int s_py = 0, s_px = 0; long s_img = 0;
+    if (shuffle) {
+      const int per = cg.Ho * cg.Wo, n_img = row / per, rem = row - n_img * per;
+      s_py = rem / cg.Wo; s_px = rem - s_py * cg.Wo;
+      s_img = (long)n_img * cg.sHo;
+    }
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int ci = (wn * TJ + j) * 32 + 8 * gq + 4 * h32, col = n0 + ci;
+        if (col >= N) continue;
+        float cbv[4] = {1.f, 1.f, 1.f, 1.f}, bsv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (s0.b_inv) { const float4 t = epi_f4(BM + ci); cbv[0] = t.x; cbv[1] = t.y; cbv[2] = t.z; cbv[3] = t.w; }
+        if (bias) { const float4 t = epi_f4(BM + BN + ci); bsv[0] = t.x; bsv[1] = t.y; bsv[2] = t.z; bsv[3] = t.w; }
+        float o[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          o[v] = (acc[0][i][j][4 * gq + v] * (1.f / 2048.f) + acc[1][i][j][4 * gq + v]) * ra * cbv[v] + bsv[v];
+        if (shuffle) {
+          const int cls = col / cg.sCo, co = col - cls * cg.sCo;
+          const int oy = 2 * s_py + (cls >> 1), ox = 2 * s_px + (cls & 1);
+          if (oy < cg.sHo && ox < cg.sWo)
+            *reinterpret_cast<float4*>(C + ((s_img + oy) * cg.sWo + ox) * cg.sCo + co) = make_float4(o[0], o[1], o[2], o[3]);
+          continue;
+        }
+        float* c = C + (long)row * ldc + col;
+        if (vec_c && col + 3 < N) {
+          if (accumulate) {
+            const float4 cv = *reinterpret_cast<const float4*>(c);
+            o[0] += cv.x; o[1] += cv.y; o[2] += cv.z; o[3] += cv.w;
+          }
+          *reinterpret_cast<float4*>(c) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            if (col + v < N) c[v] = accumulate ? c[v] + o[v] : o[v];
+        }
+      }
+  }
+  wait_vm<0>();                        // no DMA may be in flight into this workgroup's LDS when it exits
+}
+
 // ---- fp32 -> x3 planes (three bf16 terms, exact) -------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned bf16_rne(float x) {      // bits of the nearest-even bf16 (finite inputs)
   const unsigned u = __builtin_bit_cast(unsigned, x);
@@ -1123,6 +1416,21 @@ static inline double kk_bytes(long M, long N, long K) { return 4.0 * ((double)M 
 // row-major over the sub-block (rounds of 4 x 8); the L2-miss bytes do NOT change (201.8 MB per launch either way = the compulsory 6 MB per
 // round of 32 resident tiles: no operand survives from one round to the next in a 4 MiB L2), profiles/r05_hl_order.txt
 static int hl_order() { static const int o = getenv("GENRL_HL_ORDER") ? atoi(getenv("GENRL_HL_ORDER")) : 1; return o; }
+// 128 x 192 tiles (gemm_planes_hlw_kernel) where they pad fewer columns than 128-wide ones (N = 192: the sub-pixel products' 4 x 48
+// columns); GENRL_HL_WIDE=0: never, 2: also where both tilings pad the same (N = 384, 768, 1536: fewer, larger tiles -- experiments)
+static bool use_wide(int N) {
+  static const int mode = getenv("GENRL_HL_WIDE") ? atoi(getenv("GENRL_HL_WIDE")) : 1;
+  if (mode == 0) return false;
+  const int c128 = cdiv(N, 128) * 128, c192 = cdiv(N, 192) * 192;
+  return c192 < c128 || (mode == 2 && c192 == c128);
+}
+// 256 x 96 tiles (gemm_planes_hlw_kernel<.., 3, 4>: four waves along m) for the convolution products with N <= 96 output channels instead of
+// 128 x 128 tiles with a quarter of the columns padding: 173056 x 96 x 1728 281 -> 259 us, but 200704 x 96 x 768 189 -> 196 (twelve half
+// stages behind a longer prologue): from K = 1024 up (GENRL_HL_TALL=0: never, 2: always), profiles/r05_wide_ab.txt
+static bool use_tall96(int N, int K) {
+  static const int mode = getenv("GENRL_HL_TALL") ? atoi(getenv("GENRL_HL_TALL")) : 1;
+  return mode != 0 && N <= 96 && (mode == 2 || K >= 1024);
+}
 static bool hl_on() { static const bool on = !getenv("GENRL_PLANES_HL") || getenv("GENRL_PLANES_HL")[0] != '0'; return on; }
 int g_planes_nosplit = 0;        // experiments: 1 = no row split against wave quantisation (GENRL_PLANES_NOSPLIT)
 int g_planes_variant = 0;        // experiments (scripts/cold_bench.py): ring depth / prefetch distance variants
@@ -1297,7 +1605,10 @@ static int gemm_h2_impl(const uint16_t* a0, long a0_ld, long a0_plane, const flo
         gemm_planes_kernel<2, 2, 64, 2, 1, 2, false, false, 4><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
                                                                                            xcd_split(tm, tn), SampleEpi{}, ConvGather{});
 #endif
-      else if (hl_on())
+      else if (hl_on() && use_wide(N)) {
+        const int tw = cdiv(N, 192);
+        gemm_planes_hlw_kernel<false, 3><<<tm * tw, 256, 0, (hipStream_t)stream>>>(sg, C, ldc, bs, M, N, acc, tm, tw, xcd_split(tm, tw), ConvGather{});
+      } else if (hl_on())
         gemm_planes_hl_kernel<false><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, C, ldc, bs, M, N, acc, tm, tn, xcd_split(tm, tn) | (hl_order() << 8), ConvGather{});
       else
         gemm_planes_kernel<2, 2, 64, 2, 1, 2, false><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
@@ -1355,9 +1666,17 @@ int genrl_gemm_h2_conv(const uint16_t* img, long ld_img, long plane_img, const f
   const int M = (int)Ml;
   PlaneSeg s0{img, ld_img, plane_img, b, b_ld, b_plane, (int)b_ld, img_inv, b_inv};
   const PlaneSeg none{nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, nullptr};
-  const int tm = cdiv(M, 128), tn = cdiv(N, 128);
+  const bool wide = hl_on() && use_wide(N);
+  const bool tall = hl_on() && use_tall96(N, K);      // N <= 96 (the 48 -> 96 channel layer): 256 x 96 tiles instead of 128 x 128 with a quarter padding
+  const int tm = cdiv(M, tall ? 256 : 128), tn = tall ? 1 : cdiv(N, wide ? 192 : 128);
   log_launch("h2/conv128", M, N, (int)b_ld, 4.0 * ((double)Nimg * H * W * Cc + (double)N * b_ld + (double)M * N));
-  if (hl_on())
+  if (tall)
+    gemm_planes_hlw_kernel<true, 3, 4><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, C, ldc, bias, M, N, accumulate, tm, tn, xcd_split(tm, tn),
+                                                                                ConvGather{H, W, Cc, k, Ho, Wo, K, 2, 0, 0, 0});
+  else if (wide)
+    gemm_planes_hlw_kernel<true, 3><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, C, ldc, bias, M, N, accumulate, tm, tn, xcd_split(tm, tn),
+                                                                             ConvGather{H, W, Cc, k, Ho, Wo, K, 2, 0, 0, 0});
+  else if (hl_on())
     gemm_planes_hl_kernel<true><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, C, ldc, bias, M, N, accumulate, tm, tn, xcd_split(tm, tn),
                                                                           ConvGather{H, W, Cc, k, Ho, Wo, K, 2, 0, 0, 0});
   else
@@ -1390,10 +1709,15 @@ int genrl_gemm_h2_subpixel(const uint16_t* img, long ld_img, long plane_img, con
   if (!hl_on()) return GENRL_EINVAL;                                                              // (the epilogue lives in the half-stage kernel)
   const int M = (int)Ml;
   PlaneSeg s0{img, ld_img, plane_img, b, b_ld, b_plane, (int)b_ld, img_inv, b_inv};
-  const int tm = cdiv(M, 128), tn = cdiv(N, 128);
+  const bool wide = use_wide(N);
+  const int tm = cdiv(M, 128), tn = cdiv(N, wide ? 192 : 128);
   log_launch("h2/subpixel128", M, N, (int)b_ld, 4.0 * ((double)Nimg * Hp * Wp * Cc + (double)N * b_ld + (double)Nimg * Ho * Wo * Co));
-  gemm_planes_hl_kernel<true><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, out, 4, bias, M, N, 0, tm, tn, xcd_split(tm, tn),
-                                                                        ConvGather{Hp, Wp, Cc, T, Hq, Wq, K, 1, Ho, Wo, Co});
+  if (wide)
+    gemm_planes_hlw_kernel<true, 3><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, out, 4, bias, M, N, 0, tm, tn, xcd_split(tm, tn),
+                                                                             ConvGather{Hp, Wp, Cc, T, Hq, Wq, K, 1, Ho, Wo, Co});
+  else
+    gemm_planes_hl_kernel<true><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, out, 4, bias, M, N, 0, tm, tn, xcd_split(tm, tn),
+                                                                          ConvGather{Hp, Wp, Cc, T, Hq, Wq, K, 1, Ho, Wo, Co});
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }

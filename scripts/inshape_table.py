@@ -3,7 +3,7 @@ the library's own launch log of the same process (GENRL_GEMM_LOG: tile, M, N, K 
 n-th logged launch IS the n-th gemm_planes_kernel dispatch).  python scripts/inshape_table.py <kernel_trace.csv> <gemm.log>"""
 import csv, sys, collections
 
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'gemm_planes_kernel<' in r['Kernel_Name'] or 'gemm_planes_hl_kernel<' in r['Kernel_Name']]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'gemm_planes_kernel<' in r['Kernel_Name'] or 'gemm_planes_hl_kernel<' in r['Kernel_Name'] or 'gemm_planes_hlw_kernel<' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 log = [tuple(l.split()[:4]) for l in open(sys.argv[2]) if l.strip() and l.startswith(('h2/', 'x3/'))]
 assert len(rows) == len(log), (len(rows), len(log))
