@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256) void ln_act_fwd_blk_kernel(const float* __rest
         if (act) {
           o.x = siluf_(o.x); o.y = siluf_(o.y); o.z = siluf_(o.z); o.w = siluf_(o.w);
         }
-        yr[j] = o;
+        if (y) yr[j] = o;            // (y == NULL: planes only -- a caller whose every consumer reads the planes)
         v[i] = o;
       }
     }
@@ -890,7 +890,7 @@ __global__ __launch_bounds__(256) void ln_act_fwd_wave_kernel(const float* __res
         if (act) {
           o.x = siluf_(o.x); o.y = siluf_(o.y); o.z = siluf_(o.z); o.w = siluf_(o.w);
         }
-        yr[j] = o;
+        if (y) yr[j] = o;            // (y == NULL: planes only)
         v[i] = o;
       }
     }
@@ -1435,6 +1435,7 @@ static int ln_act_fwd_impl(const float* x, long ldx, const float* gamma, const f
                     aligned16(y) && aligned16(gamma) && aligned16(beta);
   const bool narrow = N <= 256 && (N & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && aligned16(x) && aligned16(y) &&
                       aligned16(gamma) && aligned16(beta) && M >= 64 && NARROW_LN;
+  if (!y && !(fast && xo.p && !uniform)) return GENRL_EINVAL;     // (planes only: the wave- / block-per-row kernels, which write planes themselves)
   if (narrow) {
     const int gl = N <= 64 ? 16 : (N <= 128 ? 32 : 64);
     const int grid = (int)std::min<long>(cdiv(M, 4 * (64 / gl)), 2048);
