@@ -267,7 +267,9 @@ class _RolloutPlanes(Function):
         dd = d_deter.clone() if d_deter is not None else z(H + 1, N, D)
         dl_in = d_logit.reshape(H + 1, N, SK).contiguous() if d_logit is not None else None
         da_in = d_action.contiguous() if d_action is not None else None
-        dlg, do, do_pre, dg_pre, dx, dx_pre = f(N, SK), f(N, U), f(N, U), f(N, 3 * D), f(N, U), f(N, U)
+        # (d o_pre is consumed as planes only: the LayerNorm backward writes no fp32 copy of it where its kernel can do without)
+        no_dx = 256 < U <= 4096 and U % 4 == 0
+        dlg, do, do_pre, dg_pre, dx, dx_pre = f(N, SK), f(N, U), (None if no_dx else f(N, U)), f(N, 3 * D), f(N, U), f(N, U)
         dlg_p, dop_p, dg_p, dxp_p = planes.Planes(N, SK, dev), planes.Planes(N, U, dev), planes.Planes(N, 3 * D, dev), planes.Planes(N, U, dev)
         dha, dhb = f(N, D), f(N, D)
         cur, nxt = dha, None                              # ping-pong: recurrent gradient into deter_h from step h's GRU
