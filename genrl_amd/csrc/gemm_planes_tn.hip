@@ -250,6 +250,9 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_tn_kernel(TnArgs g) {
     --left; --fleft;
   };
   auto issue_one = [&](int buf, int i) __attribute__((always_inline)) {
+#if defined(TN_ABL_DMA)      /* ablations (scripts/tn_abl.sh): 1 no tile DMAs in the loop, 2 none of B's, 3 none of A's (wrong results) */
+    if (!first && left < nk - 2 && (TN_ABL_DMA == 1 || (TN_ABL_DMA == 2 && isB) || (TN_ABL_DMA == 3 && !isB))) return;
+#endif
     if (i < NPD) {
       if constexpr (CONVB) {
         if (isB) { tn_glds16(gbase + (size_t)(ro[buf][i] + tapoff), piece0 + buf * STAGE + i * 1024); return; }
@@ -335,7 +338,9 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_tn_kernel(TnArgs g) {
     mfma_one(set, 0);
     mfma_one(set, 1);
     __builtin_amdgcn_sched_barrier(0);
+#ifndef TN_ABL_NOWAIT      /* ablation (scripts/tn_conv_probe.py): do not wait for the stage's DMAs -- wrong results, the MFMA / LDS rate alone */
     tn_wait_vm<0>();
+#endif
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // (CONVB: this iteration issues stage t+2 with the row offsets of set t % 2, loaded during iteration t-1; the ones of stage
@@ -453,13 +458,29 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 }
 
 int tn_splits(int NI, int NJ, int M) {
+  // One workgroup per CU (65 KiB stages): tiles x splits workgroups run in ceil(tiles splits / 256) ROUNDS of ceil(stages / splits) stages each.
+  // Rounds 1-4 rounded tiles x splits to the NEAREST multiple -- 6 tiles x 43 = 258, 24 x 11 = 264, 38 x 7 = 266, 72 x 4 = 288 workgroups:
+  // a second round for 2 .. 32 stragglers, i.e. twice the time (round 5, scripts/tn_conv_probe.py: the convolution weight gradients with
+  // few output tiles ran at 122-145 TF/s where the 252- and 228-workgroup shapes ran at 240-330).  Now: the split count that minimises
+  // rounds x (stages per split + a fixed cost per round) (ties: fewer splits = fewer partial tiles to reduce); GENRL_TN_SPLIT_NEAREST=1
+  // restores the old rule.
   const int tiles = cdiv(NI, 128) * cdiv(NJ, 128), stages = M / 64;
-  int s = tiles >= 192 ? 1 : (256 + tiles / 2) / tiles;     // ~one workgroup per CU
-  const int smax = stages / 8 > 0 ? stages / 8 : 1;         // >= 8 stages per workgroup
-  if (s > smax) s = smax;
-  if (s > 64) s = 64;                                       // (the workspace holds 64 cref slots)
-  if (s < 1) s = 1;
-  return s;
+  int smax = stages / 8 > 0 ? stages / 8 : 1;               // >= 8 stages per workgroup
+  if (smax > 64) smax = 64;                                 // (the workspace holds 64 cref slots)
+  static const bool nearest = getenv("GENRL_TN_SPLIT_NEAREST") != nullptr;
+  if (nearest) {
+    int s = tiles >= 192 ? 1 : (256 + tiles / 2) / tiles;
+    if (s > smax) s = smax;
+    return s < 1 ? 1 : s;
+  }
+  // cost in stage times: every round pays its stages plus ~8 stage times of prologue / epilogue / partial-tile traffic (without that
+  // term 114 tiles x 400 stages went to 50 splits = 23 rounds of 8 stages: 287 -> 373 us)
+  int best = 1; long bc = -1;
+  for (int s = 1; s <= smax; ++s) {
+    const long cost = (long)cdiv((long)tiles * s, 256) * (cdiv(stages, s) + 8);
+    if (bc < 0 || cost < bc) { bc = cost; best = s; }
+  }
+  return best;
 }
 // layout of the workspace: [factors: splits x fac_stride fp16][cref: 64 floats][split-K partial tiles]
 struct TnPlan { int nsplit, sps; long fac_stride, fac_bytes; };
