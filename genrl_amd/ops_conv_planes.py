@@ -146,7 +146,10 @@ def _gemm_tn_conv(Ap, img_p, Nimg, H, W, C, k, out, ldc, NI, M):
 
 # ---- gather ("sub-pixel") form of the scatter side: ConvTranspose2d forward / Conv2d input gradient without cols + col2im ---------
 SUBPIXEL = os.environ.get('GENRL_SUBPIXEL', '1') != '0'
-SUBPIXEL_ODD = os.environ.get('GENRL_SUBPIXEL_ODD', '0') != '0'     # odd kernels (k = 5 treated as 6 with a zero tap: 1.4x the taps)
+# odd kernels (k = 5 treated as 6 with a zero tap: 1.4 x the taps).  Round 4 measured it neutral on c2's 5^2 -> 13^2 layer and left it off; with the
+# 128 x 192 tile and at c4's sizes (the 29^2 -> 61^2 layer: a 1.66 GB cols matrix otherwise) it pays: c4 40.3 -> 39.5 ms, c3 37.0 -> 36.75, c2 22.0 -> 22.0
+# (round 5, scripts/r05_odd_ab.sh): on by default, GENRL_SUBPIXEL_ODD=0 restores GEMM -> col2im for odd kernels
+SUBPIXEL_ODD = os.environ.get('GENRL_SUBPIXEL_ODD', '1') != '0'
 
 
 def _hl_on():
