@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void ln_act_fwd_grp_kernel(const float* __rest
     float4 z = make_float4(d.x * rstd * g4.x + b4.x, d.y * rstd * g4.y + b4.y, d.z * rstd * g4.z + b4.z,
                            d.w * rstd * g4.w + b4.w);
     if (act) z = make_float4(siluf_(z.x), siluf_(z.y), siluf_(z.z), siluf_(z.w));
-    if (cok) *reinterpret_cast<float4*>(y + r * ldy + c) = z;
+    if (cok && y) *reinterpret_cast<float4*>(y + r * ldy + c) = z;            // (y == NULL: planes only)
     if (xo.p && c < xo.ld) h2_store4(xo, r, c, cok ? z : make_float4(0.f, 0.f, 0.f, 0.f), u_sc);     // (padding columns: zeros)
     if (gl == 0) {
       mean_out[r] = mean;
@@ -287,7 +287,7 @@ __global__ void reduce_chunks2_kernel(const float* __restrict__ part, float* __r
   *o = accumulate ? *o + s : s;
 }
 #ifndef REDUCE2M_MAX
-#define REDUCE2M_MAX 512   /* partial rows summed by ONE launch of reduce_chunks2m (512 = every block-per-row backward) */
+#define REDUCE2M_MAX 1024  /* partial rows summed by ONE launch of reduce_chunks2m (512 = every block-per-row backward, 1024 = the channel LayerNorm's) */
 #endif
 // one-launch version for a moderate number of partial rows (17..REDUCE2M_MAX): 64 columns x 4 interleaved row
 // subsets per block, summed through LDS (fixed order)
@@ -1435,7 +1435,8 @@ static int ln_act_fwd_impl(const float* x, long ldx, const float* gamma, const f
                     aligned16(y) && aligned16(gamma) && aligned16(beta);
   const bool narrow = N <= 256 && (N & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && aligned16(x) && aligned16(y) &&
                       aligned16(gamma) && aligned16(beta) && M >= 64 && NARROW_LN;
-  if (!y && !(fast && xo.p && !uniform)) return GENRL_EINVAL;     // (planes only: the wave- / block-per-row kernels, which write planes themselves)
+  // (planes only: the kernels that write planes themselves -- wave- / block-per-row, and the channel kernel's uniform planes)
+  if (!y && !(xo.p && (uniform ? narrow : fast))) return GENRL_EINVAL;
   if (narrow) {
     const int gl = N <= 64 ? 16 : (N <= 128 ? 32 : 64);
     const int grid = (int)std::min<long>(cdiv(M, 4 * (64 / gl)), 2048);
@@ -1507,10 +1508,17 @@ int genrl_onehot_gather_ln_fwd(const int* idx, int S, int K, const float* wT, lo
 }
 
 static inline int blk_grid_for(int M) { return M < BLK_GRID ? M : BLK_GRID; }
+// workgroups of the channel-LayerNorm backward (rows of <= 256 floats, one lane group per row; two 16-byte loads in flight per lane and
+// iteration): 1024 = 4 per CU measured 1.5 % of the c4 step faster than 512 and than 2048 (scripts/r05_lngrid_ab.sh; GENRL_LN_NARROW_GRID)
+static inline int narrow_grid_cap() {
+  static const int cap = [] { const char* e = getenv("GENRL_LN_NARROW_GRID"); const int v = e ? atoi(e) : 1024; return v < 64 ? 64 : (v > REDUCE2M_MAX ? REDUCE2M_MAX : v); }();
+  return cap;
+}
+static inline int narrow_grid_for(int M, int gl) { return (int)std::min<long>(cdiv(M, 4 * (64 / gl)), narrow_grid_cap()); }
 
 // workspace: >= genrl_ln_ws_floats(M, N) floats
 long genrl_ln_ws_floats(int M, int N) {
-  const int a = chunks_for(M), b = blk_grid_for(M);
+  const int a = chunks_for(M), b = N <= 256 ? std::max(blk_grid_for(M), narrow_grid_for(M, 64)) : blk_grid_for(M);
   return (long)((a > b ? a : b) + 16) * 3 * N;
 }
 
@@ -1521,7 +1529,7 @@ int genrl_ln_bwd_parts(int M, int N) {
   if (N <= 256) {
     if (!(M >= 64 && NARROW_LN)) return 0;
     const int gl = N <= 64 ? 16 : (N <= 128 ? 32 : 64);
-    return (int)std::min<long>(cdiv(M, 4 * (64 / gl)), blk_grid_for(M));
+    return narrow_grid_for(M, gl);
   }
   if (N > 4096) return 0;
   if (N <= 1024 && WAVE_LN) return blk_grid_for(cdiv(M, 4));
@@ -1575,7 +1583,7 @@ static int ln_act_bwd_impl(const float* dy, long lddy, const float* x, long ldx,
   if (defer && (!dgamma || !(fast || narrow))) return GENRL_EINVAL;
   if (narrow) {
     const int gl = N <= 64 ? 16 : (N <= 128 ? 32 : 64);
-    const int grid = (int)std::min<long>(cdiv(M, 4 * (64 / gl)), blk_grid_for(M));
+    const int grid = narrow_grid_for(M, gl);
     float* part = dgamma ? ws : nullptr;
     const int np = dcolsum ? 3 : 2;
 #define GO(GLV) hipLaunchKernelGGL((ln_act_bwd_grp_kernel<GLV>), dim3(grid), dim3(256), 0, s, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, part, M, N, act, np, amax_ws)

@@ -1451,7 +1451,7 @@ class _PermuteWeight(Function):
         return transpose_last2_raw(g.contiguous()).reshape(W.shape)
 
 
-def conv2d_s2(x, W, b, ln=None):
+def conv2d_s2(x, W, b, ln=None, fp32_out=True, planes_out=True):
     """W (Co,Ci,k,k) in the reference layout; permuted per call to (Co, kh*kw*Ci) (gradient flows back
     through the permute).  ln = (gamma, beta, eps): channel-LayerNorm + SiLU fused into the same node."""
     Co, Ci, k, _ = W.shape
@@ -1572,7 +1572,7 @@ class _ConvT2dS2(Function):
         return dx, dW, db, None, dg, dbe, None, None
 
 
-def convT2d_s2(x, W, b, ln=None, out_nchw=False):
+def convT2d_s2(x, W, b, ln=None, out_nchw=False, fp32_out=True, planes_out=True):
     """W (Ci,Co,k,k) in the reference layout; permuted per call to (Ci, kh*kw*Co).  out_nchw: (N,Co,Ho,Wo) output
     (written that way by the overlap-add kernel; no LayerNorm fusion then)."""
     Ci, Co, k, _ = W.shape

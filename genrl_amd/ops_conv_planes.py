@@ -66,15 +66,22 @@ def _uniform_split(x2d):
     return P
 
 
-def _ln_fwd(pre2d, gamma, beta, eps, want_planes):
-    """channel-LayerNorm + SiLU of the rows; -> (y, mean, rstd, uniform planes of y or None)"""
+LAZY_FP32 = os.environ.get('GENRL_CONV_LAZY_FP32', '1') != '0'
+
+
+def _ln_fwd(pre2d, gamma, beta, eps, want_planes, want_fp32=True):
+    """channel-LayerNorm + SiLU of the rows; -> (y, mean, rstd, uniform planes of y or None, lazy).  want_fp32 False (an inner layer whose
+    consumer gathers from the planes): y is allocated but NOT written when the kernel makes the planes itself -- lazy is then a cell
+    [True] and a consumer that does read fp32 values after all fills y from the planes first (_need_fp32)"""
     M, N = pre2d.shape
     y = torch.empty_like(pre2d)
     mean = torch.empty(M, device=pre2d.device); rstd = torch.empty(M, device=pre2d.device)
-    P = None
+    P = lazy = None
     if want_planes and N <= 256 and N % 4 == 0 and M >= 64:
         P = planes.Planes(M, N, pre2d.device, zero=False)
-        check(lib().genrl_ln_act_fwd_h2u(_p(pre2d), N, _p(gamma), _p(beta), _p(y), N, _p(mean), _p(rstd), M, N, eps, 1,
+        if not want_fp32 and LAZY_FP32:
+            lazy = [True]
+        check(lib().genrl_ln_act_fwd_h2u(_p(pre2d), N, _p(gamma), _p(beta), None if lazy else _p(y), N, _p(mean), _p(rstd), M, N, eps, 1,
                                          P.ptr(), P.ld, P.plane, P.inv_ptr(), _stream()), 'ln_act_fwd_h2u')
         P.uniform = True
     else:
@@ -82,7 +89,14 @@ def _ln_fwd(pre2d, gamma, beta, eps, want_planes):
               'ln_act_fwd')
         if want_planes and N % 4 == 0:
             P = _uniform_split(y)
-    return y, mean, rstd, P
+    return y, mean, rstd, P, lazy
+
+
+def _need_fp32(x, cell, xp):
+    """x's fp32 values are about to be read: fill them from the planes if the producer skipped them (see _ln_fwd)"""
+    if cell is not None and cell[0]:
+        x.data.view(xp.rows, xp.cols).copy_(xp.float())      # (.data: the values autograd saw were never defined -- no version bump)
+        cell[0] = False
 
 
 def _ln_bwd(dy2d, pre2d, gamma, beta, mean, rstd, bias, want_planes):
@@ -221,8 +235,9 @@ class _Conv2dS2P(Function):
     """ops._Conv2dS2 with plane products.  x: f32 NHWC (N,H,W,C) [xp: its uniform planes or None] or u8 NCHW frames;
     Wp (Co, k*k*Ci) = weight permuted to (co, kh, kw, ci); channel-LayerNorm + SiLU fused; returns NHWC with ._planes set."""
     @staticmethod
-    def forward(ctx, x, Wp, b, k, gamma, beta, eps, xp, holder, wsrc=(None,)):
+    def forward(ctx, x, Wp, b, k, gamma, beta, eps, xp, holder, wsrc=(None,), opts=(None, True, True)):
         ctx.wsrc = wsrc[0]
+        ctx.xlazy, fp32_out, planes_out = opts      # (cell of a planes-only input; does anything read this layer's fp32 output / planes?)
         u8 = x.dtype == torch.uint8
         x = x.contiguous()
         if u8:
@@ -236,13 +251,15 @@ class _Conv2dS2P(Function):
         on_planes = (not u8) and xp is not None and _gather_ok(M, C)
         if on_planes:
             _gemm_conv(xp, Nimg, Hi, Wi, C, k, _wplanes(ctx.wsrc, Wp, False), y, Co, b, Co)
-        elif ops._implicit_conv(x, C):
-            sgemm_conv(x, K, 1, Wp, K, 1, y, Co, b, M, Co, K, 1, (Hi, Wi, C, k))
         else:
-            cols = ops._im2col(x, Nimg, Hi, Wi, C, k, 2 if u8 else 0)
-            sgemm(cols, K, 1, Wp, K, 1, y, Co, b, M, Co, K)
-        out, mean, rstd, outp = _ln_fwd(y, gamma, beta, eps, want_planes=M >= min_rows())
-        holder.append(outp)
+            _need_fp32(x, ctx.xlazy, xp)
+            if ops._implicit_conv(x, C):
+                sgemm_conv(x, K, 1, Wp, K, 1, y, Co, b, M, Co, K, 1, (Hi, Wi, C, k))
+            else:
+                cols = ops._im2col(x, Nimg, Hi, Wi, C, k, 2 if u8 else 0)
+                sgemm(cols, K, 1, Wp, K, 1, y, Co, b, M, Co, K)
+        out, mean, rstd, outp, lazy = _ln_fwd(y, gamma, beta, eps, want_planes=planes_out and M >= min_rows(), want_fp32=fp32_out)
+        holder.append(outp); holder.append(lazy)
         ctx.dims = (Nimg, Hi, Wi, C, k, u8)
         ctx.bias = b
         ctx.xp = xp if on_planes else None
@@ -267,6 +284,8 @@ class _Conv2dS2P(Function):
         dx = dW = None
         if ctx.needs_input_grad[1]:
             dW = torch.empty(Co, K, device=dy.device)
+            if not (tn and dyp is not None):
+                _need_fp32(x, ctx.xlazy, xp)
             if tn and dyp is not None:
                 _gemm_tn_conv(dyp, xp, Nimg, Hi, Wi, C, k, dW, K, Co, M)
             elif ops._implicit_conv(x, C) and Co % 4 == 0:
@@ -288,15 +307,18 @@ class _Conv2dS2P(Function):
             else:
                 sgemm(dy2, Co, 1, Wp, 1, K, dcols, K, None, M, K, Co)
             dx = ops._col2im(dcols, None, Nimg, Ho, Wo, C, k, Hi, Wi)
-        return dx, dW, db, None, dg, dbe, None, None, None, None
+        return dx, dW, db, None, dg, dbe, None, None, None, None, None
 
 
 class _ConvT2dS2P(Function):
     """ops._ConvT2dS2 (with the fused channel-LayerNorm + SiLU) with plane products.  x NHWC (N,Hi,Wi,Ci), xp: planes of its rows
     (uniform or per-row scales) or None; Wp (Ci, k*k*Co) = weight permuted to (ci, kh, kw, co)."""
     @staticmethod
-    def forward(ctx, x, Wp, b, k, gamma, beta, eps, xp, holder, wsrc=(None,)):
+    def forward(ctx, x, Wp, b, k, gamma, beta, eps, xp, holder, wsrc=(None,), opts=(None, True, True)):
         ctx.wsrc = wsrc[0]
+        ctx.xlazy, fp32_out, planes_out = opts
+        if ctx.xlazy is not None and not (x.dtype == torch.float32 and x.is_contiguous()):
+            _need_fp32(x, ctx.xlazy, xp)
         x = _f32(x).contiguous()
         Nimg, Hi, Wi, Ci = x.shape
         Nw = Wp.shape[1]
@@ -314,12 +336,14 @@ class _ConvT2dS2P(Function):
             if on_planes and Ci >= KR_MIN_K:
                 planes.gemm(xp, _wplanes(ctx.wsrc, Wp, True), cols, Nw, None, M, Nw)      # cols = x W
             else:
+                _need_fp32(x, ctx.xlazy, xp)
                 sgemm(x, Ci, 1, Wp, 1, Nw, cols, Nw, None, M, Nw, Ci)
             y = ops._col2im(cols, b, Nimg, Hi, Wi, Co, k)
             del cols
         Ho, Wo = y.shape[1], y.shape[2]
-        out, mean, rstd, outp = _ln_fwd(y.reshape(-1, Co), gamma, beta, eps, want_planes=Nimg * Ho * Wo >= min_rows())
-        holder.append(outp)
+        out, mean, rstd, outp, lazy = _ln_fwd(y.reshape(-1, Co), gamma, beta, eps, want_planes=planes_out and Nimg * Ho * Wo >= min_rows(),
+                                              want_fp32=fp32_out)
+        holder.append(outp); holder.append(lazy)
         ctx.dims = (Nimg, Hi, Wi, Ci, Co, k)
         ctx.bias = b
         ctx.xp = xp if on_planes else None
@@ -354,6 +378,8 @@ class _ConvT2dS2P(Function):
             dx = dx.reshape(Nimg, Hi, Wi, Ci)
         if ctx.needs_input_grad[1]:
             dW = torch.empty(Ci, Nw, device=dy.device)
+            if not (tn and dyp is not None):
+                _need_fp32(x, ctx.xlazy, xp)
             if tn and dyp is not None:
                 _gemm_tn_conv(xp, dyp, Nimg, Ho, Wo, Co, k, dW, Nw, Ci, M)                              # dW = x^T patches(dy)
             elif implicit:
@@ -362,24 +388,27 @@ class _ConvT2dS2P(Function):
                 if dcols is None:
                     dcols = ops._im2col(dyv, Nimg, Ho, Wo, Co, k, 0)
                 sgemm(x, 1, Ci, dcols, 1, Nw, dW, Nw, None, Ci, Nw, M)
-        return dx, dW, db, None, dg, dbe, None, None, None, None
+        return dx, dW, db, None, dg, dbe, None, None, None, None, None
 
 
-def conv2d_s2(x, W, b, ln):
+def conv2d_s2(x, W, b, ln, fp32_out=True, planes_out=True):
     """ops.conv2d_s2 with the fused channel-LayerNorm; the output carries ._planes (uniform planes of its pixel rows) for the
-    next layer when it was worth making them"""
+    next layer when it was worth making them.  fp32_out False: the caller passes the output to another layer of this module only,
+    which reads the planes (the fp32 values are then filled on demand: ._lazy); planes_out False: nothing reads the planes"""
     Co, Ci, k, _ = W.shape
     Wp = ops._PermuteWeight.apply(W).reshape(Co, k * k * Ci)
     holder = []
-    y = _Conv2dS2P.apply(x, Wp, b, k, ln[0], ln[1], float(ln[2]), getattr(x, '_planes', None), holder, (W,))
-    y._planes = holder[0] if holder else None
+    y = _Conv2dS2P.apply(x, Wp, b, k, ln[0], ln[1], float(ln[2]), getattr(x, '_planes', None), holder, (W,),
+                         (getattr(x, '_lazy', None), fp32_out, planes_out))
+    y._planes, y._lazy = holder if holder else (None, None)
     return y
 
 
-def convT2d_s2(x, W, b, ln):
+def convT2d_s2(x, W, b, ln, fp32_out=True, planes_out=True):
     Ci, Co, k, _ = W.shape
     Wp = ops._PermuteWeight.apply(W).reshape(Ci, k * k * Co)
     holder = []
-    y = _ConvT2dS2P.apply(x, Wp, b, k, ln[0], ln[1], float(ln[2]), getattr(x, '_planes', None), holder, (W,))
-    y._planes = holder[0] if holder else None
+    y = _ConvT2dS2P.apply(x, Wp, b, k, ln[0], ln[1], float(ln[2]), getattr(x, '_planes', None), holder, (W,),
+                          (getattr(x, '_lazy', None), fp32_out, planes_out))
+    y._planes, y._lazy = holder if holder else (None, None)
     return y

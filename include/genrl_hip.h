@@ -97,7 +97,8 @@ int genrl_gemm_h2_sample(const uint16_t* a0, long a0_ld, long a0_plane, const fl
  * products need -- a patch row gathers from several pixel rows, a weight gradient sums over them (csrc/gemm_planes*.hip).
  * genrl_split_h2u: from an fp32 matrix, exact tensor maximum (two launches; ws >= 1024 floats).  genrl_ln_act_fwd_h2u: the channel
  * LayerNorm (+SiLU, rows of <= 256 floats, agent/dreamer_utils.py:1031-1040) emits them itself with the scale its parameters
- * guarantee (|gamma x^ + beta| <= max|gamma| sqrt(N) + max|beta|).  genrl_ln_act_bwd_h2u: its backward leaves one partial maximum
+ * guarantee (|gamma x^ + beta| <= max|gamma| sqrt(N) + max|beta|); y == NULL: planes only (an inner layer's fp32 activation has no reader
+ * when the next convolution gathers from the planes forward and backward).  genrl_ln_act_bwd_h2u: its backward leaves one partial maximum
  * of dx per workgroup in amax_ws (>= 2048 floats), a second launch splits dx with the tensor's scale. */
 int genrl_split_h2u(const float* x, long ldx, int R, int Cn, uint16_t* out, long ld_out, long plane, float* inv, float* ws,
                     void* stream);

@@ -33,9 +33,12 @@ def _ln_silu(y, ga, be):
 
 
 @pytest.mark.parametrize('N,Hi,C0,C1,C2', [(8, 31, 48, 96, 192), (64, 14, 96, 192, 384), (3, 31, 48, 96, 192), (16, 31, 56, 48, 64)])
-def test_encoder_chain_on_planes(N, Hi, C0, C1, C2):
+@pytest.mark.parametrize('inner_fp32', [True, False])
+def test_encoder_chain_on_planes(N, Hi, C0, C1, C2, inner_fp32):
     """two stride-2 k4 convolutions + channel-LN + SiLU: the second layer gathers its patches from the uniform planes the first
-    layer's LayerNorm wrote; N = 3: pixel counts that are no multiple of 64 (weight gradients fall back to the fp32 kernels)"""
+    layer's LayerNorm wrote; N = 3: pixel counts that are no multiple of 64 (weight gradients fall back to the fp32 kernels).
+    inner_fp32 False: the first layer's LayerNorm writes the planes only, as inside Encoder._cnn (the N = 3 weight gradient then
+    fills the fp32 values from the planes before it reads them: ops_conv_planes._need_fp32)"""
     from genrl_amd import ops, ops_conv_planes as cp, planes
     x = torch.randn(N, Hi, Hi, C0, generator=g(1))
     W1 = torch.randn(C1, C0, 4, 4, generator=g(2)) / (C0 * 16) ** .5; b1 = 0.1 * torch.randn(C1, generator=g(3))
@@ -50,15 +53,21 @@ def test_encoder_chain_on_planes(N, Hi, C0, C1, C2):
     def hip(x, W1, b1, g1, e1, W2, b2, g2, e2):
         xin = x * 1.0
         xin._planes = cp._uniform_split(xin.detach().reshape(-1, C0))            # (as a previous layer would have left them)
-        y = cp.conv2d_s2(xin, W1, b1, (g1, e1, 1e-3))
-        assert y._planes is not None
-        return cp.conv2d_s2(y, W2, b2, (g2, e2, 1e-3))
+        y = cp.conv2d_s2(xin, W1, b1, (g1, e1, 1e-3), fp32_out=inner_fp32)
+        assert y._planes is not None and (y._lazy is None) == inner_fp32
+        out = cp.conv2d_s2(y, W2, b2, (g2, e2, 1e-3))
+        hip.cell = y._lazy
+        return out
     _check(hip, ref, [x, W1, b1, g1, e1, W2, b2, g2, e2], rtol=3e-4, atol=3e-4)
+    if not inner_fp32:               # filled exactly when a product had to read it: the fp32 weight gradient of the ragged pixel count
+        H2 = (((Hi - 4) // 2 + 1) - 4) // 2 + 1
+        assert hip.cell[0] == ((N * H2 * H2) % 64 == 0), hip.cell
 
 
 @pytest.mark.parametrize('N,Hi,C0,C1,C2,k1,k2', [(64, 1, 1536, 192, 96, 5, 5), (64, 5, 192, 96, 48, 5, 6), (5, 5, 192, 96, 48, 5, 6),
                                                  (128, 5, 64, 48, 56, 5, 6)])
-def test_decoder_chain_on_planes(N, Hi, C0, C1, C2, k1, k2):
+@pytest.mark.parametrize('inner_fp32', [True, False])
+def test_decoder_chain_on_planes(N, Hi, C0, C1, C2, k1, k2, inner_fp32):
     """two stride-2 transposed convolutions + channel-LN + SiLU: forward on planes of the input rows, the input gradient gathers
     patches of dY from uniform planes, the weight gradient sums x^T patches(dY) over the input pixels"""
     from genrl_amd import ops_conv_planes as cp
@@ -73,7 +82,7 @@ def test_decoder_chain_on_planes(N, Hi, C0, C1, C2, k1, k2):
         return _ln_silu(F.conv_transpose2d(y.permute(0, 3, 1, 2), W2, b2, stride=2).permute(0, 2, 3, 1), g2, e2)
 
     def hip(x, W1, b1, g1, e1, W2, b2, g2, e2):
-        y = cp.convT2d_s2(x * 1.0, W1, b1, (g1, e1, 1e-3))
+        y = cp.convT2d_s2(x * 1.0, W1, b1, (g1, e1, 1e-3), fp32_out=inner_fp32)
         return cp.convT2d_s2(y, W2, b2, (g2, e2, 1e-3))
     _check(hip, ref, [x, W1, b1, g1, e1, W2, b2, g2, e2], rtol=3e-4, atol=3e-4)
 
@@ -84,7 +93,12 @@ def test_uniform_planes_of_the_channel_layernorm():
     from genrl_amd import ops_conv_planes as cp, planes
     pre = torch.randn(5000, 96, generator=g(1)).cuda() * 3
     ga = (1 + 0.2 * torch.randn(96, generator=g(2))).cuda(); be = (0.3 * torch.randn(96, generator=g(3))).cuda()
-    y, mean, rstd, P = cp._ln_fwd(pre, ga, be, 1e-3, True)
+    y, mean, rstd, P, lazy = cp._ln_fwd(pre, ga, be, 1e-3, True)
+    assert lazy is None
+    y2, mean2, rstd2, P2, lazy2 = cp._ln_fwd(pre, ga, be, 1e-3, True, want_fp32=False)     # planes only: the same planes, y filled on demand
+    assert lazy2 == [True] and torch.equal(P2.t, P.t) and torch.equal(P2.inv, P.inv) and torch.equal(mean2, mean) and torch.equal(rstd2, rstd)
+    cp._need_fp32(y2, lazy2, P2)
+    assert lazy2 == [False] and torch.equal(y2, P.float())
     ref = F.silu(F.layer_norm(pre, (96,), ga, be, 1e-3))
     assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5)
     assert (P.inv == P.inv[0]).all() and P.ld == 128 and (P.t[:, :, 96:] == 0).all()
