@@ -355,7 +355,7 @@ extern "C" int genrl_subpixel_weight(const float* W, long s_ci, long s_co, long 
 // the block's 2 x Co x 32 (NCHW) outputs leave through a per-wave LDS transpose as 16-byte stores.  Exact fp32 arithmetic.
 namespace {
 template <int T, int J>      // k = 2T taps per dimension pair; Ci = 16 J
-__global__ __launch_bounds__(256) void convt_small_co_fwd_kernel(const float* __restrict__ x, const float* __restrict__ Wp,
+__global__ __launch_bounds__(256, 3) void convt_small_co_fwd_kernel(const float* __restrict__ x, const float* __restrict__ Wp,
                                                                  const float* __restrict__ bias, float* __restrict__ out, int Nimg,
                                                                  int Hi, int Wi, int Co, int out_nchw) {
   constexpr int Ci = 16 * J, NS = T * T * J * 4, k = 2 * T;
@@ -380,34 +380,46 @@ __global__ __launch_bounds__(256) void convt_small_co_fwd_kernel(const float* __
           bf[((u * T + v) * J + j) * 4 + e] = (n < 4 * Co) ? Wp[(long)ci * (k * k * Co) + (kh * k + kw) * Co + c_n] : 0.f;
         }
   const float bias_n = (bias && n < 4 * Co) ? bias[c_n] : 0.f;
-  for (long blk = (long)blockIdx.x * 4 + wave; blk < nblk; blk += (long)gridDim.x * 4) {
-    const int bx = (int)(blk % bpr);
-    const long t = blk / bpr;
-    const int py = (int)(t % Hq);
-    const int img = (int)(t / Hq);
-    const int px = bx * 16 + r;                           // this lane's patch column (A row r)
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};     // (one chain: per-channel-group accumulators measured no faster, 229 vs 190 us)
-    // taps in flight: the loads of tap t + 1 are issued before the 4 J MFMAs of tap t (two register sets)
-    auto load_tap = [&](int tap, float4 (&av)[J]) __attribute__((always_inline)) {
-      const int u = tap / T, v = tap - u * T;
-      const int iy = py + u - (T - 1), ix = px + v - (T - 1);
-      const bool ok = iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
-      const float* p = x + ((long)(img * Hi + (ok ? iy : 0)) * Wi + (ok ? ix : 0)) * Ci + 4 * kq;
+  // taps in flight: the loads of tap t + 1 are issued before the 4 J MFMAs of tap t (two register sets), and the loads of the NEXT block's
+  // first tap before the last tap's MFMAs and this block's epilogue (they were exposed once per block: 9 taps of ~400 MFMA cycles each
+  // against ~2 000 cycles of load latency).  Nine taps are odd, so consecutive blocks start on alternating register sets: PAR.
+  auto load_tap = [&](int bx, int py, int img, int tap, float4 (&av)[J]) __attribute__((always_inline)) {
+    const int px = bx * 16 + r;
+    const int u = tap / T, v = tap - u * T;
+    const int iy = py + u - (T - 1), ix = px + v - (T - 1);
+    const bool ok = iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
+    const float* p = x + ((long)(img * Hi + (ok ? iy : 0)) * Wi + (ok ? ix : 0)) * Ci + 4 * kq;
 #pragma unroll
-      for (int j = 0; j < J; ++j) {
-        av[j] = *reinterpret_cast<const float4*>(p + 16 * j);
-        if (!ok) av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    };
-    float4 av[2][J];
-    load_tap(0, av[0]);
+    for (int j = 0; j < J; ++j) {
+      av[j] = *reinterpret_cast<const float4*>(p + 16 * j);
+      if (!ok) av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  const long step = (long)gridDim.x * 4;
+  float4 av[2][J];
+  long blk = (long)blockIdx.x * 4 + wave;
+  int nbx = 0, npy = 0, nimg = 0;                       // the block after `blk`, decoded one block ahead
+  auto decode = [&](long b) __attribute__((always_inline)) {
+    nbx = (int)(b % bpr);
+    const long t = b / bpr;
+    npy = (int)(t % Hq);
+    nimg = (int)(t / Hq);
+  };
+  if (blk < nblk) { decode(blk); load_tap(nbx, npy, nimg, 0, av[0]); }
+  auto block = [&](auto PARC) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(PARC)::value;
+    const int bx = nbx, py = npy, img = nimg;
+    const bool more = blk + step < nblk;
+    if (more) decode(blk + step);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};     // (one chain: per-channel-group accumulators measured no faster, 229 vs 190 us)
 #pragma unroll
     for (int tap = 0; tap < T * T; ++tap) {
-      if (tap + 1 < T * T) load_tap(tap + 1, av[(tap + 1) & 1]);
+      if (tap + 1 < T * T) load_tap(bx, py, img, tap + 1, av[(tap + 1 + PAR) & 1]);
+      else if (more) load_tap(nbx, npy, nimg, 0, av[(tap + 1 + PAR) & 1]);
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         const int s = (tap * J + j) * 4;
-        const float4 a4 = av[tap & 1][j];
+        const float4 a4 = av[(tap + PAR) & 1][j];
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bf[s + 0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bf[s + 1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bf[s + 2], acc, 0, 0, 0);
@@ -444,6 +456,14 @@ __global__ __launch_bounds__(256) void convt_small_co_fwd_kernel(const float* __
       }
     }
     __builtin_amdgcn_wave_barrier();
+  };
+  static_assert((T * T) % 2 == 1, "alternating register sets assume an odd tap count");
+  while (blk < nblk) {
+    block(std::integral_constant<int, 0>{});
+    blk += step;
+    if (blk >= nblk) break;
+    block(std::integral_constant<int, 1>{});
+    blk += step;
   }
 }
 }  // namespace

@@ -52,17 +52,34 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   const float coef = gscale * (clip > 0.f ? fminf(clip / (norm[0] + 1e-6f), 1.0f) : 1.0f);
   const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i0 >= n) return;
+  auto upd = [&](float& pi, float& gq, float& mq, float& vq) __attribute__((always_inline)) {
+    const float gi = gq * coef;
+    const float mi = b1 * mq + (1.0f - b1) * gi;
+    const float vi = b2 * vq + (1.0f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+    pi = (1.0f - wd) * pi - (lr / bc1) * (mi / denom);
+    mq = mi;
+    vq = vi;
+    if (zero_grad) gq = 0.f;             // Optimizer's zero_grad() in the same pass (the gradient is read exactly here)
+  };
+  // 16-byte accesses (the four streams are 28 bytes per parameter: this kernel is HBM traffic and nothing else; the scalar form ran at 2.1 TB/s)
+  if (i0 + 3 < n && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
+    float4 p4 = *reinterpret_cast<float4*>(p + i0), g4 = *reinterpret_cast<float4*>(g + i0);
+    float4 m4 = *reinterpret_cast<float4*>(m + i0), v4 = *reinterpret_cast<float4*>(v + i0);
+    upd(p4.x, g4.x, m4.x, v4.x); upd(p4.y, g4.y, m4.y, v4.y); upd(p4.z, g4.z, m4.z, v4.z); upd(p4.w, g4.w, m4.w, v4.w);
+    *reinterpret_cast<float4*>(p + i0) = p4;
+    *reinterpret_cast<float4*>(m + i0) = m4;
+    *reinterpret_cast<float4*>(v + i0) = v4;
+    if (zero_grad) *reinterpret_cast<float4*>(g + i0) = g4;
+    return;
+  }
   const int cnt = (int)min(4L, n - i0);
   for (int j = 0; j < cnt; ++j) {
     const long i = i0 + j;
-    const float gi = g[i] * coef;
-    const float mi = b1 * m[i] + (1.0f - b1) * gi;
-    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-    const float denom = sqrtf(vi) / sqrt_bc2 + eps;
-    p[i] = (1.0f - wd) * p[i] - (lr / bc1) * (mi / denom);
-    m[i] = mi;
-    v[i] = vi;
-    if (zero_grad) g[i] = 0.f;           // Optimizer's zero_grad() in the same pass (the gradient is read exactly here)
+    float pi = p[i], gi = g[i], mi = m[i], vi = v[i];
+    upd(pi, gi, mi, vi);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (zero_grad) g[i] = gi;
   }
 }
 

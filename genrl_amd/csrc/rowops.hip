@@ -1349,7 +1349,8 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_blk_kernel(
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-constexpr int BLK_GRID = 512;   // workgroups of the block-per-row kernels (2 per CU); rows are grid-strided
+constexpr int BLK_GRID = 512;   // workgroups of the block-per-row FORWARD kernels (x 4); rows are grid-strided
+// the backward kernels (one partial row of parameter gradients per workgroup): GENRL_BLK_GRID, see blk_grid_for
 
 // row chunks of the column-reduction kernels: enough workgroups (up to 2048) to cover HBM latency on
 // the tall-skinny conv activations (M ~ 10^6 rows x 48..384 channels); partials are then reduced in
@@ -1507,7 +1508,11 @@ int genrl_onehot_gather_ln_fwd(const int* idx, int S, int K, const float* wT, lo
   return GENRL_OK;
 }
 
-static inline int blk_grid_for(int M) { return M < BLK_GRID ? M : BLK_GRID; }
+static inline int blk_grid_cap() {
+  static const int cap = [] { const char* e = getenv("GENRL_BLK_GRID"); const int v = e ? atoi(e) : BLK_GRID; return v < 64 ? 64 : (v > REDUCE2M_MAX ? REDUCE2M_MAX : v); }();
+  return cap;
+}
+static inline int blk_grid_for(int M) { return M < blk_grid_cap() ? M : blk_grid_cap(); }
 // workgroups of the channel-LayerNorm backward (rows of <= 256 floats, one lane group per row; two 16-byte loads in flight per lane and
 // iteration): 1024 = 4 per CU measured 1.5 % of the c4 step faster than 512 and than 2048 (scripts/r05_lngrid_ab.sh; GENRL_LN_NARROW_GRID)
 static inline int narrow_grid_cap() {

@@ -21,6 +21,12 @@ echo "c3 GENRL_OBSERVE_SEQ=0 (stepwise observe):  $(GENRL_OBSERVE_SEQ=0 $B --con
 echo "c3 GENRL_OBSERVE_FUSE=0 (8 launches/step):  $(GENRL_OBSERVE_FUSE=0 $B --config c3 --steps 20 --warmup 5 2>/dev/null | ms)"
 echo "c3 GENRL_PLANES_2PER=0:                    $(GENRL_PLANES_2PER=0 $B --config c3 --steps 20 --warmup 5 2>/dev/null | ms)"
 echo "c3 GENRL_FORK_CRITIC=1:                    $(GENRL_FORK_CRITIC=1 $B --config c3 --steps 20 --warmup 5 2>/dev/null | ms)"
+echo "c4 default:                                $($B --config c4 --steps 20 --warmup 5 2>/dev/null | ms)"
+echo "c4 GENRL_TN_SPLIT_NEAREST=1 (round-4 split): $(GENRL_TN_SPLIT_NEAREST=1 $B --config c4 --steps 20 --warmup 5 2>/dev/null | ms)"
+echo "c4 GENRL_SUBPIXEL_ODD=0:                   $(GENRL_SUBPIXEL_ODD=0 $B --config c4 --steps 20 --warmup 5 2>/dev/null | ms)"
+echo "c4 GENRL_CONV_LAZY_FP32=0:                 $(GENRL_CONV_LAZY_FP32=0 $B --config c4 --steps 20 --warmup 5 2>/dev/null | ms)"
+echo "c4 GENRL_LN_NARROW_GRID=512:               $(GENRL_LN_NARROW_GRID=512 $B --config c4 --steps 20 --warmup 5 2>/dev/null | ms)"
+echo "c4 default again:                          $($B --config c4 --steps 20 --warmup 5 2>/dev/null | ms)"
 echo "c5 default:                                $($B --config c5 --steps 30 --warmup 5 2>/dev/null | ms)"
 echo "c5 GENRL_OBSERVE_SEQ=0 (stepwise imagine):  $(GENRL_OBSERVE_SEQ=0 $B --config c5 --steps 30 --warmup 5 2>/dev/null | ms)"
 echo "c5 GENRL_FORK_CRITIC=1:                    $(GENRL_FORK_CRITIC=1 $B --config c5 --steps 30 --warmup 5 2>/dev/null | ms)"
@@ -54,5 +60,7 @@ timeout 300 bash scripts/inshape.sh > $O/inshape.txt 2>&1
 timeout 600 bash scripts/pmc.sh > $O/pmc.txt 2>&1; cp gpurun_out/pmc/pmc_summary.json $O/pmc.json 2>/dev/null
 rm -rf /tmp/k3; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/k3 -o p -- $B --config c3 --steps 6 --warmup 3 > /dev/null 2>&1
 python scripts/kernel_table.py /tmp/k3/p_kernel_trace.csv 4 3 > $O/kernel_table_c3.txt 2>&1
+rm -rf /tmp/k4; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/k4 -o p -- $B --config c4 --steps 6 --warmup 3 > /dev/null 2>&1
+python scripts/kernel_table.py /tmp/k4/p_kernel_trace.csv 4 > $O/kernel_table_c4.txt 2>&1
 timeout 900 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err
 tail -3 $O/feature_ab.txt; python -c "import json; d=json.load(open('$O/bench_c2.json')); print(d['ms_per_step'], d['config']['eager_ms_per_step'])"

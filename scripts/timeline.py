@@ -37,3 +37,11 @@ for g, at, n in sorted(gaps, reverse=True)[:8]: print(f'   {g / 1e3:7.1f} us at 
 print(f'idle total {sum(g for g, _, _ in gaps) / 1e6:.2f} ms in {len(gaps)} gaps')
 print('time running alone, by kernel:')
 for n, t in alone.most_common(int(sys.argv[2]) if len(sys.argv) > 2 else 14): print(f'   {t / 1e6:7.2f} ms  {n}')
+if len(sys.argv) > 3:          # argv[3] = ms: the kernel sequence of the step's first ms (start, duration, gap before, queue)
+    lim = float(sys.argv[3]) * 1e6
+    prev_end = t0
+    print(f'first {sys.argv[3]} ms of the step:')
+    for s, e, n, q in seg:
+        if s - t0 > lim: break
+        print(f'  +{(s - t0) / 1e3:8.1f} us  {(e - s) / 1e3:7.1f} us  gap {(s - prev_end) / 1e3:6.1f}  q{q}  {short(n)}')
+        prev_end = max(prev_end, e)
