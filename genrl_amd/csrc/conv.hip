@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, 3) void convt_small_co_fwd_kernel(const float*
                                                                  int Hi, int Wi, int Co, int out_nchw) {
   constexpr int Ci = 16 * J, NS = T * T * J * 4, k = 2 * T;
   __shared__ float tr[4][2][4][32];                       // [wave][a][c][2 i + b]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, kq = lane >> 4;
   const int Hq = Hi + T - 1, Wq = Wi + T - 1, Ho = 2 * Hq - (k & 1), Wo = 2 * Wq - (k & 1);     // (k even: Ho = 2 Hq)
   const int bpr = (Wq + 15) / 16;                         // blocks per patch row
@@ -398,19 +398,22 @@ __global__ __launch_bounds__(256, 3) void convt_small_co_fwd_kernel(const float*
   const long step = (long)gridDim.x * 4;
   float4 av[2][J];
   long blk = (long)blockIdx.x * 4 + wave;
-  int nbx = 0, npy = 0, nimg = 0;                       // the block after `blk`, decoded one block ahead
-  auto decode = [&](long b) __attribute__((always_inline)) {
-    nbx = (int)(b % bpr);
-    const long t = b / bpr;
-    npy = (int)(t % Hq);
-    nimg = (int)(t / Hq);
+  // (bx, py, img) of a block walk along incrementally, one block ahead (the integer divisions of a per-block decode are paid once, for the
+  // first block and for the stride: four 64-bit divisions per block cost a wave more issue cycles than a tap's MFMAs)
+  int nbx = (int)(blk % bpr), npy, nimg;
+  { const long t = blk / bpr; npy = (int)(t % Hq); nimg = (int)(t / Hq); }
+  const int sbx = (int)(step % bpr), simg = (int)((step / bpr) / Hq), spy = (int)((step / bpr) % Hq);
+  auto advance = [&]() __attribute__((always_inline)) {
+    nbx += sbx; npy += spy; nimg += simg;
+    if (nbx >= bpr) { nbx -= bpr; ++npy; }
+    if (npy >= Hq) { npy -= Hq; ++nimg; }
   };
-  if (blk < nblk) { decode(blk); load_tap(nbx, npy, nimg, 0, av[0]); }
+  if (blk < nblk) load_tap(nbx, npy, nimg, 0, av[0]);
   auto block = [&](auto PARC) __attribute__((always_inline)) {
     constexpr int PAR = decltype(PARC)::value;
     const int bx = nbx, py = npy, img = nimg;
     const bool more = blk + step < nblk;
-    if (more) decode(blk + step);
+    advance();
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};     // (one chain: per-channel-group accumulators measured no faster, 229 vs 190 us)
 #pragma unroll
     for (int tap = 0; tap < T * T; ++tap) {
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(256, 3) void convt_small_co_fwd_kernel(const float*
     if (out_nchw) {
       // 2 x Co segments of 32 floats: lane -> (a, c, 16-byte piece q4)
       for (int idx = lane; idx < 2 * Co * 8; idx += 64) {
-        const int q4 = idx & 7, ac = idx >> 3, a = ac / Co, c = ac - a * Co;
+        const int q4 = idx & 7, ac = idx >> 3, a = ac >= Co ? 1 : 0, c = ac - a * Co;
         const int oy = 2 * py + a, ox = ox0 + 4 * q4;
         if (oy < Ho && ox < Wo) {
           float* o = out + (((long)img * Co + c) * Ho + oy) * Wo + ox;
@@ -501,7 +504,7 @@ template <int CB, int NR>      // NR rounds of 4 groups >= 18 Co groups
 __global__ __launch_bounds__(256) void convt_small_co_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ Wp,
                                                                    float* __restrict__ dx, int Nimg, int Hi, int Wi, int Co) {
   constexpr int Ci = 16 * CB, k = 6;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, kq = lane >> 4;
   const int Ho = 2 * (Hi - 1) + k, Wo = 2 * (Wi - 1) + k, K = k * k * Co, NG = 3 * k * Co;
   const int bpr = (Wi + 15) / 16;
   const long nblk = (long)Nimg * Hi * bpr;
@@ -519,9 +522,13 @@ __global__ __launch_bounds__(256) void convt_small_co_dgrad_kernel(const float* 
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) bf[t][e][cb] = gv ? Wp[(long)(16 * cb + r) * K + (kh * k + 2 * p + e) * Co + c] : 0.f;
   }
-  for (int blk = blockIdx.x * 4 + wave; blk < (int)nblk; blk += gridDim.x * 4) {        // (nblk < 2^31: checked by the host)
-    const int bx = blk % bpr, t0 = blk / bpr;
-    const int iy = t0 % Hi, img = t0 / Hi;
+  // (bx, iy, img) walk along incrementally: the divisions of a per-block decode are paid for the first block and the stride only
+  const int blk0 = blockIdx.x * 4 + wave, bstep = gridDim.x * 4;
+  int bx = blk0 % bpr, iy = (blk0 / bpr) % Hi, img = (blk0 / bpr) / Hi;
+  const int sbx = bstep % bpr, siy = (bstep / bpr) % Hi, simg = (bstep / bpr) / Hi;
+  for (int blk = blk0; blk < (int)nblk; blk += bstep, bx += sbx, iy += siy, img += simg) {        // (nblk < 2^31: checked by the host)
+    if (bx >= bpr) { bx -= bpr; ++iy; }
+    if (iy >= Hi) { iy -= Hi; ++img; }
     const int ix = bx * 16 + r;
     const bool pv = ix < Wi;
     const float* base = dy + (long)img * Co * Ho * Wo + (long)(2 * iy) * Wo + 2 * (pv ? ix : 0);
