@@ -212,6 +212,7 @@ class WorldModel(Module):  # ref :120-321
 
     def update(self, data, state=None):  # ref :166-187
         streams.join()
+        planes.prefetch()       # (weight planes / permuted conv weights made stale by the last optimiser steps: rebuilt beside the first layer)
         self.train()
         with common.RequiresGrad(self):
             assert not (getattr(self.cfg, 'freeze_decoder', False) or getattr(self.cfg, 'freeze_post', False)
@@ -223,6 +224,7 @@ class WorldModel(Module):  # ref :120-321
             metrics.update(self.model_opt(model_loss, self.parameters(), defer=len(self.detached_update_fns) > 0))
         if len(self.detached_update_fns) > 0:
             detached_loss, metrics = self.update_additional_detached_modules(data, outputs, metrics)
+        streams.join('wprep')   # (planes.prefetch's stream: its work was waited for build by build long ago; no fork outlives the update)
         self.model_opt.flush()
         self.eval()
         return state, outputs, metrics

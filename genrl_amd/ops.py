@@ -1429,6 +1429,13 @@ class _Conv2dS2(Function):
         return dx, dW, db, None, dg, dbe, None
 
 
+def permuted(W):
+    """the (A, k*k, B) permutation of the conv weight W (A, B, k, k), cached per optimiser step (planes.derived)"""
+    from . import planes
+    A, B, k, _ = W.shape
+    return planes.derived(W, 'perm', lambda: transpose_last2_raw(W.detach().reshape(A, B, k * k)))
+
+
 class _PermuteWeight(Function):
     """(A, B, k, k) conv weight -> (A, k*k, B) for the NHWC products; the gradient is permuted back straight INTO the
     parameter's flat gradient buffer when it has one (no tensor for autograd's AccumulateGrad to add)."""
@@ -1437,8 +1444,7 @@ class _PermuteWeight(Function):
         A, B, k, _ = W.shape
         ctx.W = W
         # (cached per optimiser step: the encoder / decoder weights are permuted once, not once per call -- planes.derived)
-        from . import planes
-        return planes.derived(W, 'perm', lambda: transpose_last2_raw(W.detach().reshape(A, B, k * k))).detach()
+        return permuted(W).detach()
 
     @staticmethod
     def backward(ctx, g):

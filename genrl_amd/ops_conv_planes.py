@@ -201,9 +201,12 @@ def _subpixel(xp, Nimg, Hi, Wi, Cs, Cp, k, Wsrc, s_ci, s_co, s_tap, bias, out, w
     K = T * T * Cs
 
     def build():
+        # (from the parameter alone when the caller names it -- planes.prefetch may run this again at the next iteration's start: Wsrc is
+        # then this iteration's permuted copy, ops.permuted(wkey) the current one, same layout)
+        src = ops.permuted(wkey) if isinstance(wkey, torch.nn.Parameter) else Wsrc
         wsub = torch.empty(4 * Cp, K, device=dev)
         b4_ = torch.empty(4 * Cp, device=dev) if bias is not None else None
-        check(lib().genrl_subpixel_weight(_p(Wsrc), s_ci, s_co, s_tap, Cs, Cp, k, T, _p(wsub), _p(bias), _p(b4_), _stream()), 'subpixel_weight')
+        check(lib().genrl_subpixel_weight(_p(src), s_ci, s_co, s_tap, Cs, Cp, k, T, _p(wsub), _p(bias), _p(b4_), _stream()), 'subpixel_weight')
         return planes.split(wsub), b4_
     # (once per optimiser step when the caller names the parameter the weight comes from; weight and bias are stepped together)
     bkey = (id(bias), bias._version) if bias is not None else None      # (a bias edited or swapped without its weight rebuilds too)
@@ -220,7 +223,9 @@ def _wplanes(wsrc, Wp, transpose):
     """planes of the permuted weight matrix Wp (or of its transpose): once per optimiser step when the parameter it comes from is known"""
     if wsrc is None:
         return planes.split(Wp.detach(), transpose=transpose)
-    return planes.derived(wsrc, ('perm_planes', transpose), lambda: planes.split(Wp.detach(), transpose=transpose))
+    shape = tuple(Wp.shape)          # (the builder depends on the parameter alone: planes.prefetch may call it again, see _subpixel)
+    src = (lambda: ops.permuted(wsrc).reshape(shape)) if isinstance(wsrc, torch.nn.Parameter) else (lambda: Wp.detach())
+    return planes.derived(wsrc, ('perm_planes', transpose), lambda: planes.split(src(), transpose=transpose))
 
 
 KR_MIN_K = int(os.environ.get('GENRL_PLANES_KR_MIN_K', '512'))      # GEMM -> col2im products: with few input channels (K = C) a 128 x 128 tile is two K stages of prologue and a
