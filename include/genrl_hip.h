@@ -336,6 +336,11 @@ int genrl_split_x3(const float* x, long ldx, int R, int Cn, uint16_t* out, long 
 int genrl_gemm_x3(const uint16_t* a0, long a0_ld, long a0_plane, const uint16_t* b0, long b0_ld, long b0_plane, int k0,
                   const uint16_t* a1, long a1_ld, long a1_plane, const uint16_t* b1, long b1_ld, long b1_plane, int k1,
                   float* C, long ldc, const float* bias, int M, int N, int accumulate, void* stream);
+/* split-K products of the fp32-operand tile kernel (genrl_sgemm*: few tiles, long K -- the 256-row data-free block): 1
+ * (GENRL_SPLITK_INKERNEL=1 in the environment) = the last split to finish a tile adds the partial tiles itself, in split order, and no
+ * reduce launch follows; 0 (default: the in-kernel form measured slower) = partial tiles + reduce launch.  Same arithmetic bit
+ * for bit.  Returns the previous setting. */
+int genrl_splitk_inkernel(int on);
 int genrl_planes_force_tile(int t);      /* experiments: 0 auto, 1 64x64 tiles, 2 128x128 tiles (both formats) */
 int genrl_planes_variant(int v);         /* experiments: ring depth / L2 prefetch distance of the plane kernels (scripts/cold_bench.py) */
 
