@@ -353,6 +353,9 @@ extern "C" int genrl_subpixel_weight(const float* W, long s_ci, long s_co, long 
 // both operands use it), the weight fragments of all T T Ci / 4 steps live in registers for the whole kernel (108 VGPRs), so the
 // loop is: 3 predicated 16-byte loads + 12 MFMAs per tap, no LDS, no barrier.  Output NCHW (the reference's frame layout) or NHWC:
 // the block's 2 x Co x 32 (NCHW) outputs leave through a per-wave LDS transpose as 16-byte stores.  Exact fp32 arithmetic.
+#ifndef CONVT_ABL
+#define CONVT_ABL 0
+#endif
 namespace {
 template <int T, int J>      // k = 2T taps per dimension pair; Ci = 16 J
 __global__ __launch_bounds__(256, 3) void convt_small_co_fwd_kernel(const float* __restrict__ x, const float* __restrict__ Wp,
@@ -417,18 +420,28 @@ __global__ __launch_bounds__(256, 3) void convt_small_co_fwd_kernel(const float*
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};     // (one chain: per-channel-group accumulators measured no faster, 229 vs 190 us)
 #pragma unroll
     for (int tap = 0; tap < T * T; ++tap) {
+#if CONVT_ABL != 2       /* ablation 2 (scripts/convt_abl.sh): no operand loads in the tap loop */
       if (tap + 1 < T * T) load_tap(bx, py, img, tap + 1, av[(tap + 1 + PAR) & 1]);
       else if (more) load_tap(nbx, npy, nimg, 0, av[(tap + 1 + PAR) & 1]);
+#endif
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         const int s = (tap * J + j) * 4;
         const float4 a4 = av[(tap + PAR) & 1][j];
+#if CONVT_ABL == 1       /* ablation 1: no MFMAs (operands kept live) */
+        asm volatile("" ::"v"(a4.x), "v"(a4.y), "v"(a4.z), "v"(a4.w), "v"(bf[s]), "v"(bf[s + 3]));
+#else
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bf[s + 0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bf[s + 1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bf[s + 2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bf[s + 3], acc, 0, 0, 0);
+#endif
       }
     }
+#if CONVT_ABL == 3       /* ablation 3: no epilogue (LDS transpose + stores) */
+    asm volatile("" ::"v"(acc[0]), "v"(acc[3]));
+    return;
+#endif
     // D[i = 4 kq + vv][n = r]: patch position px0 + i, column (a, b, c) -> output pixel (2 py + a, 2 (px0 + i) + b), channel c
     if (n < 4 * Co) {
 #pragma unroll

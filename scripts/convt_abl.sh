@@ -1,0 +1,10 @@
+# the 3-channel transposed-convolution forward kernel taken apart (ablation builds; results of 1-3 are wrong by construction)
+cd ${GRAFT_REPO_ROOT:-.}
+B="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-c++20-extensions -Wno-unused-value -shared -fPIC -I include -I genrl_amd/csrc"
+for a in 1 2 3; do $B -DCONVT_ABL=$a -o gpurun_ablc$a.so genrl_amd/csrc/*.hip 2>/dev/null & done; wait
+for n in 800 4096; do
+echo "== N=$n shipped";            python scripts/convt_direct_time.py $n 1 2>&1 | grep direct
+echo "== N=$n no MFMAs";           GENRL_HIP_SO=$PWD/gpurun_ablc1.so python scripts/convt_direct_time.py $n 1 2>&1 | grep direct
+echo "== N=$n no loads in the loop"; GENRL_HIP_SO=$PWD/gpurun_ablc2.so python scripts/convt_direct_time.py $n 1 2>&1 | grep direct
+echo "== N=$n no epilogue";        GENRL_HIP_SO=$PWD/gpurun_ablc3.so python scripts/convt_direct_time.py $n 1 2>&1 | grep direct
+done
