@@ -550,13 +550,25 @@ __global__ __launch_bounds__(256) void convt_small_co_dgrad_kernel(const float* 
     for (int cb = 0; cb < CB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NR; ++t) {
+#if CONVT_ABL == 12      /* ablations 11-13 (scripts/convt_abl.sh): dgrad without MFMAs / without its dy loads / without its stores */
+      float2 a = make_float2((float)blk, 1.f);
+#else
       float2 a = *reinterpret_cast<const float2*>(base + (aoff[t] >= 0 ? aoff[t] : 0));
       if (!pv || aoff[t] < 0) a = make_float2(0.f, 0.f);
+#endif
+#if CONVT_ABL == 11
+      asm volatile("" ::"v"(a.x), "v"(a.y), "v"(bf[t][0][0]), "v"(bf[t][1][CB - 1]));
+#else
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bf[t][0][cb], acc[cb], 0, 0, 0);
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bf[t][1][cb], acc[cb], 0, 0, 0);
+#endif
     }
+#if CONVT_ABL == 13
+    asm volatile("" ::"v"(acc[0][0]), "v"(acc[CB - 1][3]));
+    continue;
+#endif
     // D[i = 4 kq + v][j = r]: pixel bx 16 + i, channel 16 cb + r
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -613,24 +625,44 @@ __global__ __launch_bounds__(256) void convt_small_co_wgrad_kernel(const float* 
     const float* xp = x + (((long)img * Hi + iy) * Wi + (pv ? ix : 0)) * Ci + r;
     const float* dp = dy + (long)img * Co * Ho * Wo + (long)(2 * iy) * Wo + 2 * (pv ? ix : 0);
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) { a[rb] = xp[16 * rb]; if (!pv) a[rb] = 0.f; }
+    for (int rb = 0; rb < RB; ++rb) {
+#if CONVT_ABL == 23
+      a[rb] = (float)(ix + rb);
+#else
+      a[rb] = xp[16 * rb]; if (!pv) a[rb] = 0.f;
+#endif
+    }
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) { b[cb] = dp[boff[cb] >= 0 ? boff[cb] : 0]; if (!pv || boff[cb] < 0) b[cb] = 0.f; }
+    for (int cb = 0; cb < NCB; ++cb) {
+#if CONVT_ABL == 22
+      b[cb] = (float)(ix + cb);
+#else
+      b[cb] = dp[boff[cb] >= 0 ? boff[cb] : 0]; if (!pv || boff[cb] < 0) b[cb] = 0.f;
+#endif
+    }
   };
   float a0[RB], b0[NCB], a1[RB], b1[NCB];
   if (g0 < g1) load(g0, a0, b0);
   for (int g = g0; g < g1; g += 2) {
     if (g + 1 < g1) load(g + 1, a1, b1);
+#if CONVT_ABL == 21      /* ablations 21 / 22: wgrad without MFMAs / without the dy-patch loads / 23: without the x loads */
+    asm volatile("" ::"v"(a0[0]), "v"(a0[RB - 1]), "v"(b0[0]), "v"(b0[NCB - 1]));
+#else
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[rb], b0[cb], acc[rb][cb], 0, 0, 0);
+#endif
     if (g + 1 < g1) {
       if (g + 2 < g1) load(g + 2, a0, b0);
+#if CONVT_ABL == 21
+      asm volatile("" ::"v"(a1[0]), "v"(a1[RB - 1]), "v"(b1[0]), "v"(b1[NCB - 1]));
+#else
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rb], b1[cb], acc[rb][cb], 0, 0, 0);
+#endif
     }
   }
   float* out = part + (long)blockIdx.x * Ci * (16 * NCB);
