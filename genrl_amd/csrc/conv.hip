@@ -512,16 +512,22 @@ namespace {
 // dgrad: a wave owns 16 consecutive input pixels of one image row (MFMA rows), the Ci = 16 CB channels are CB column blocks.  K = 36 Co is
 // walked in GROUPS g = (c, kh, kw pair p): lane (r, kq) of round t takes group 4 t + kq and loads the float2 dy[c][2 iy + kh][2 ix + 2 p ..]
 // -- 8-byte loads that are CONTIGUOUS across the 16 pixels of the block (the first version's 4-byte loads at an 8-byte lane stride ran the
-// kernel at a fifth of the matrix rate) -- and the two floats are the A operands of two MFMA steps (kw = 2 p, 2 p + 1); weights in registers.
+// kernel at a fifth of the matrix rate) -- and the two floats are the A operands of two MFMA steps (kw = 2 p, 2 p + 1).
+// Round 5 (ablations: scripts/convt_abl.sh -- 704 us shipped at 4 096 images, 545 without the MFMAs, 395 without the dy loads, 420 without the
+// stores): the 84 weight words per lane moved from registers into LDS (16-byte reads, conflict-free: the same for all four waves), which
+// leaves room for the NEXT block's 14 loads to be in flight under this block's MFMAs and for more waves per SIMD, and the 16 x Ci output
+// block leaves through a per-wave LDS transpose as 16-byte stores of whole pixel rows instead of 4-byte stores in 64-byte segments.
 template <int CB, int NR>      // NR rounds of 4 groups >= 18 Co groups
 __global__ __launch_bounds__(256) void convt_small_co_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ Wp,
                                                                    float* __restrict__ dx, int Nimg, int Hi, int Wi, int Co) {
-  constexpr int Ci = 16 * CB, k = 6;
+  constexpr int Ci = 16 * CB, k = 6, NW = NR * 2 * CB, LDT = Ci + 4;
+  static_assert(NW % 4 == 0 && Ci % 4 == 0, "weight words in 16-byte reads");
+  __shared__ float4 wl[NW / 4][64];                      // word idx = (t 2 + e) CB + cb of lane l: wl[idx / 4][l][idx % 4]
+  __shared__ __attribute__((aligned(16))) float tr[4][16][LDT];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, kq = lane >> 4;
   const int Ho = 2 * (Hi - 1) + k, Wo = 2 * (Wi - 1) + k, K = k * k * Co, NG = 3 * k * Co;
   const int bpr = (Wi + 15) / 16;
   const long nblk = (long)Nimg * Hi * bpr;
-  float bf[NR][2][CB];
   int aoff[NR];
 #pragma unroll
   for (int t = 0; t < NR; ++t) {
@@ -530,55 +536,71 @@ __global__ __launch_bounds__(256) void convt_small_co_dgrad_kernel(const float* 
     const int gc = gv ? g : 0;
     const int c = gc / (3 * k), rem = gc - c * (3 * k), kh = rem / 3, p = rem - kh * 3;
     aoff[t] = gv ? (c * Ho + kh) * Wo + 2 * p : -1;
+    if (t % 4 == wave) {                                 // (the four waves share the table: each fills a quarter of the rounds)
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
+      for (int e = 0; e < 2; ++e)
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) bf[t][e][cb] = gv ? Wp[(long)(16 * cb + r) * K + (kh * k + 2 * p + e) * Co + c] : 0.f;
+        for (int cb = 0; cb < CB; ++cb) {
+          const int idx = (t * 2 + e) * CB + cb;
+          reinterpret_cast<float*>(&wl[idx / 4][lane])[idx % 4] = gv ? Wp[(long)(16 * cb + r) * K + (kh * k + 2 * p + e) * Co + c] : 0.f;
+        }
+    }
   }
+  __syncthreads();
   // (bx, iy, img) walk along incrementally: the divisions of a per-block decode are paid for the first block and the stride only
   const int blk0 = blockIdx.x * 4 + wave, bstep = gridDim.x * 4;
   int bx = blk0 % bpr, iy = (blk0 / bpr) % Hi, img = (blk0 / bpr) / Hi;
   const int sbx = bstep % bpr, siy = (bstep / bpr) % Hi, simg = (bstep / bpr) / Hi;
-  for (int blk = blk0; blk < (int)nblk; blk += bstep, bx += sbx, iy += siy, img += simg) {        // (nblk < 2^31: checked by the host)
-    if (bx >= bpr) { bx -= bpr; ++iy; }
-    if (iy >= Hi) { iy -= Hi; ++img; }
-    const int ix = bx * 16 + r;
+  auto load_blk = [&](int bx_, int iy_, int img_, float2 (&a)[NR]) __attribute__((always_inline)) {
+    const int ix = bx_ * 16 + r;
     const bool pv = ix < Wi;
-    const float* base = dy + (long)img * Co * Ho * Wo + (long)(2 * iy) * Wo + 2 * (pv ? ix : 0);
+    const float* base = dy + (long)img_ * Co * Ho * Wo + (long)(2 * iy_) * Wo + 2 * (pv ? ix : 0);
+#pragma unroll
+    for (int t = 0; t < NR; ++t) {
+      a[t] = *reinterpret_cast<const float2*>(base + (aoff[t] >= 0 ? aoff[t] : 0));
+      if (!pv || aoff[t] < 0) a[t] = make_float2(0.f, 0.f);
+    }
+  };
+  float2 cur[NR], nxt[NR];
+  if (blk0 < (int)nblk) load_blk(bx, iy, img, cur);
+  for (int blk = blk0; blk < (int)nblk; blk += bstep) {        // (nblk < 2^31: checked by the host)
+    int nbx = bx + sbx, niy = iy + siy, nimg = img + simg;
+    if (nbx >= bpr) { nbx -= bpr; ++niy; }
+    if (niy >= Hi) { niy -= Hi; ++nimg; }
+    const bool more = blk + bstep < (int)nblk;
+    if (more) load_blk(nbx, niy, nimg, nxt);
     f32x4 acc[CB];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 wq = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int t = 0; t < NR; ++t) {
-#if CONVT_ABL == 12      /* ablations 11-13 (scripts/convt_abl.sh): dgrad without MFMAs / without its dy loads / without its stores */
-      float2 a = make_float2((float)blk, 1.f);
-#else
-      float2 a = *reinterpret_cast<const float2*>(base + (aoff[t] >= 0 ? aoff[t] : 0));
-      if (!pv || aoff[t] < 0) a = make_float2(0.f, 0.f);
-#endif
-#if CONVT_ABL == 11
-      asm volatile("" ::"v"(a.x), "v"(a.y), "v"(bf[t][0][0]), "v"(bf[t][1][CB - 1]));
-#else
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bf[t][0][cb], acc[cb], 0, 0, 0);
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bf[t][1][cb], acc[cb], 0, 0, 0);
-#endif
+    for (int idx = 0; idx < NW; ++idx) {
+      if (idx % 4 == 0) wq = wl[idx / 4][lane];
+      const int t = idx / (2 * CB), e = (idx / CB) % 2, cb = idx % CB;
+      const float av = e ? cur[t].y : cur[t].x;
+      const float wv = idx % 4 == 0 ? wq.x : (idx % 4 == 1 ? wq.y : (idx % 4 == 2 ? wq.z : wq.w));
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wv, acc[cb], 0, 0, 0);
     }
-#if CONVT_ABL == 13
-    asm volatile("" ::"v"(acc[0][0]), "v"(acc[CB - 1][3]));
-    continue;
-#endif
-    // D[i = 4 kq + v][j = r]: pixel bx 16 + i, channel 16 cb + r
+    // D[i = 4 kq + v][j = r]: pixel bx 16 + i, channel 16 cb + r -> the wave's slab, then whole pixel rows out in 16-byte pieces
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int ox = bx * 16 + 4 * kq + v;
-      if (ox < Wi) {
-        float* o = dx + (((long)img * Hi + iy) * Wi + ox) * Ci + r;
+    for (int v = 0; v < 4; ++v)
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) o[16 * cb] = acc[cb][v];
-      }
+      for (int cb = 0; cb < CB; ++cb) tr[wave][4 * kq + v][16 * cb + r] = acc[cb][v];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (wave-private slab: no workgroup barrier)
+    __builtin_amdgcn_wave_barrier();
+    float* orow = dx + (((long)img * Hi + iy) * Wi + bx * 16) * Ci;
+#pragma unroll
+    for (int q = lane; q < 16 * (Ci / 4); q += 64) {
+      const int px = q / (Ci / 4), c4 = q - px * (Ci / 4);
+      if (bx * 16 + px < Wi)
+        *reinterpret_cast<float4*>(orow + px * Ci + 4 * c4) = *reinterpret_cast<const float4*>(&tr[wave][px][4 * c4]);
     }
+    __builtin_amdgcn_wave_barrier();
+    if (more) {
+#pragma unroll
+      for (int t = 0; t < NR; ++t) cur[t] = nxt[t];
+    }
+    bx = nbx; iy = niy; img = nimg;
   }
 }
 
@@ -717,7 +739,8 @@ extern "C" int genrl_convt_small_co_bwd(const float* x, const float* Wp, const f
   hipStream_t s = (hipStream_t)stream;
   if (dx) {
     const long nblk = (long)Nimg * Hi * ((Wi + 15) / 16);
-    const int blocks = (int)(cdiv(nblk, 4) < 768 ? cdiv(nblk, 4) : 768);
+    static const int dg_cap = getenv("GENRL_CONVT_DGRAD_WGS") ? atoi(getenv("GENRL_CONVT_DGRAD_WGS")) : 768;      // 3 per CU measured best (768: 456 us, 1024: 468, 2048: 457 at 4 096 images)
+    const int blocks = (int)(cdiv(nblk, 4) < dg_cap ? cdiv(nblk, 4) : dg_cap);
     hipLaunchKernelGGL((convt_small_co_dgrad_kernel<3, 14>), dim3(blocks), dim3(256), 0, s, dy, Wp, dx, Nimg, Hi, Wi, Co);
     GENRL_CHECK_LAUNCH();
   }

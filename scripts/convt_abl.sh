@@ -8,12 +8,9 @@ echo "== N=$n no MFMAs";           GENRL_HIP_SO=$PWD/gpurun_ablc1.so python scri
 echo "== N=$n no loads in the loop"; GENRL_HIP_SO=$PWD/gpurun_ablc2.so python scripts/convt_direct_time.py $n 1 2>&1 | grep direct
 echo "== N=$n no epilogue";        GENRL_HIP_SO=$PWD/gpurun_ablc3.so python scripts/convt_direct_time.py $n 1 2>&1 | grep direct
 done
-# the two backward kernels
-for a in 11 12 13 21 22 23; do $B -DCONVT_ABL=$a -o gpurun_ablc$a.so genrl_amd/csrc/*.hip 2>/dev/null & done; wait
+# the backward kernels (the input-gradient kernel's ablations 11-13 belong to its round-4 form: profiles/r05_convt_abl.txt)
+for a in 21 22 23; do $B -DCONVT_ABL=$a -o gpurun_ablc$a.so genrl_amd/csrc/*.hip 2>/dev/null & done; wait
 echo "== backward, shipped";                        python scripts/convt_bwd_time.py 4096 2>&1 | grep images
-echo "== dgrad without MFMAs";                      GENRL_HIP_SO=$PWD/gpurun_ablc11.so python scripts/convt_bwd_time.py 4096 2>&1 | grep images
-echo "== dgrad without its dy loads";               GENRL_HIP_SO=$PWD/gpurun_ablc12.so python scripts/convt_bwd_time.py 4096 2>&1 | grep images
-echo "== dgrad without its stores";                 GENRL_HIP_SO=$PWD/gpurun_ablc13.so python scripts/convt_bwd_time.py 4096 2>&1 | grep images
 echo "== wgrad without MFMAs";                      GENRL_HIP_SO=$PWD/gpurun_ablc21.so python scripts/convt_bwd_time.py 4096 2>&1 | grep images
 echo "== wgrad without the dy-patch loads";         GENRL_HIP_SO=$PWD/gpurun_ablc22.so python scripts/convt_bwd_time.py 4096 2>&1 | grep images
 echo "== wgrad without the x loads";                GENRL_HIP_SO=$PWD/gpurun_ablc23.so python scripts/convt_bwd_time.py 4096 2>&1 | grep images
