@@ -709,6 +709,121 @@ __global__ __launch_bounds__(256) void convt_small_co_wgrad_kernel(const float* 
   }
 }
 
+// wgrad, round 5 (Wo % 4 == 0: the 64 x 64 and 128 x 128 decoders): the same products with the operands STAGED through LDS.  The kernel
+// above requests every MFMA operand as a 4-byte global load one group (21 MFMAs, 0.3 us) ahead of its use: ablations (scripts/convt_abl.sh)
+// give 724 us at 4 096 images, 337 without the MFMAs, 269 for the MFMAs alone -- the two never overlap.  Here a wave owns CHUNKS of 16
+// consecutive pixels of one image row: their x rows (16 x Ci floats, contiguous) and the 3 x 6 dy row segments their patches come from
+// (36 floats each) arrive as 16-byte global loads -- six per lane and chunk, requested a whole chunk (84 MFMAs, 1.1 us) ahead into registers,
+// written to the wave's own LDS slab after the current chunk's MFMAs -- and the MFMA operands are 4-byte LDS reads.  Same accumulation order
+// per wave as above (pixels in row-major order, four per MFMA step); the per-wave share of the pixel sequence differs, so the sums differ
+// from the kernel above in the last bits (deterministic).
+template <int RB, int NCB>
+__global__ __launch_bounds__(256, 2) void convt_small_co_wgrad_lds_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                       float* __restrict__ part, int Nimg, int Hi, int Wi, int Co) {
+  constexpr int Ci = 16 * RB, k = 6, LDX = Ci + 4, LDD = 40, NROW = 18, XS = 16 * LDX, DS = NROW * LDD, SLAB = XS + DS;
+  constexpr int XV = 16 * Ci / 4, DV = NROW * 9;         // float4 pieces of a chunk: x rows, dy row segments (36 floats = 9 pieces each)
+  constexpr int NXV = (XV + 63) / 64, NDV = (DV + 63) / 64;
+  constexpr int RED = 4 * NCB * 4 * 64;
+  __shared__ __attribute__((aligned(16))) float lds[RED > 4 * SLAB ? RED : 4 * SLAB];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, kq = lane >> 4;
+  const int Ho = 2 * (Hi - 1) + k, Wo = 2 * (Wi - 1) + k, K = k * k * Co;
+  const int bpr = (Wi + 15) / 16;
+  const long nchunk = (long)Nimg * Hi * bpr;
+  float* const xs = lds + wave * SLAB;
+  float* const dsl = xs + XS;
+  // internal column order j = (c, kh, kw), kw fastest (see above); LDS offset of column j for the chunk's pixel 0: row (c 6 + kh), word kw
+  int boff[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int j = 16 * cb + r;
+    boff[cb] = j < K ? (j / k) * LDD + (j % k) : -1;
+  }
+  f32x4 acc[RB][NCB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nw = gridDim.x * 4, wid = blockIdx.x * 4 + wave;
+  const int per = (int)((nchunk + nw - 1) / nw), g0 = wid * per, g1 = (int)min(nchunk, (long)g0 + per);
+  int bx = g0 % bpr, iy = (g0 / bpr) % Hi, img = (g0 / bpr) / Hi;      // the chunk the NEXT load_chunk fetches
+  float4 xg[NXV], dg[NDV];
+  auto load_chunk = [&]() __attribute__((always_inline)) {
+    const int ix0 = 16 * bx;
+    const float* xp = x + (((long)img * Hi + iy) * Wi + ix0) * Ci;
+    const float* dp = dy + (long)img * Co * Ho * Wo + (long)(2 * iy) * Wo + 2 * ix0;
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+      const int q = lane + 64 * i, px = q / (Ci / 4);
+      const bool ok = q < XV && ix0 + px < Wi;
+      xg[i] = ok ? *reinterpret_cast<const float4*>(xp + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NDV; ++i) {
+      const int q = lane + 64 * i, row = q / 9, f = q - row * 9;           // row = c 6 + kh
+      const int c = row / k, kh = row - c * k;
+      const bool ok = q < DV && 2 * ix0 + 4 * f < Wo;                      // (Wo % 4 == 0: a piece is inside or outside as a whole)
+      dg[i] = ok ? *reinterpret_cast<const float4*>(dp + ((long)c * Ho + kh) * Wo + 4 * f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (++bx == bpr) { bx = 0; if (++iy == Hi) { iy = 0; ++img; } }
+  };
+  auto store_chunk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+      const int q = lane + 64 * i, px = q / (Ci / 4), c4 = q - px * (Ci / 4);
+      if (q < XV) *reinterpret_cast<float4*>(xs + px * LDX + 4 * c4) = xg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NDV; ++i) {
+      const int q = lane + 64 * i, row = q / 9, f = q - row * 9;
+      if (q < DV) *reinterpret_cast<float4*>(dsl + row * LDD + 4 * f) = dg[i];
+    }
+  };
+  if (g0 < g1) { load_chunk(); store_chunk(); }
+  for (int g = g0; g < g1; ++g) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slab is written (wave-private: no workgroup barrier)
+    __builtin_amdgcn_wave_barrier();
+    if (g + 1 < g1) load_chunk();                            // the next chunk's global loads fly under this chunk's MFMAs
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {                         // MFMA step: pixels 4 st .. 4 st + 3 of the chunk, this lane's pixel 4 st + kq
+      const int px = 4 * st + kq;
+      float a[RB], b[NCB];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) a[rb] = xs[px * LDX + 16 * rb + r];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) b[cb] = boff[cb] >= 0 ? dsl[boff[cb] + 2 * px] : 0.f;
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb], b[cb], acc[rb][cb], 0, 0, 0);
+    }
+    if (g + 1 < g1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every operand read of this chunk has returned
+      __builtin_amdgcn_wave_barrier();
+      store_chunk();
+    }
+  }
+  float* out = part + (long)blockIdx.x * Ci * (16 * NCB);
+  float (*red)[NCB * 4][64] = reinterpret_cast<float (*)[NCB * 4][64]>(lds);
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) red[wave][cb * 4 + v][lane] = acc[rb][cb][v];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NCB * 4 * 64; idx += 256) {
+      const int l = idx & 63, cv = idx >> 6, cb = cv >> 2, v = cv & 3;
+      const float sum = red[0][cv][l] + red[1][cv][l] + red[2][cv][l] + red[3][cv][l];
+      const int j = 16 * cb + (l & 15);
+      if (j < K) {
+        const int c = j / (k * k), rem = j - c * (k * k), kh = rem / k, kw = rem - kh * k;
+        out[(long)(16 * rb + 4 * (l >> 4) + v) * (16 * NCB) + (kh * k + kw) * Co + c] = sum;
+      }
+    }
+  }
+}
+
 __global__ void convt_small_co_wreduce_kernel(const float* __restrict__ part, int nparts, int Ci, int ldp, int K, float* __restrict__ dW) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Ci * K) return;
@@ -731,7 +846,7 @@ __global__ void convt_small_co_wreduce_kernel(const float* __restrict__ part, in
 
 /* Backward of genrl_convt_small_co_fwd for an NCHW output gradient dy [Nimg][Co][Ho][Wo]: dx (fp32 NHWC [Nimg][Hi][Wi][Ci], may be NULL)
  * and dWp ([Ci][k k Co], the permuted weight's layout; may be NULL).  ws: genrl_convt_small_co_bwd_ws_floats() floats.  k = 6, Ci = 48. */
-extern "C" long genrl_convt_small_co_bwd_ws_floats(int Ci, int Co) { return 512L * Ci * 16 * ((36 * Co + 15) / 16); }
+extern "C" long genrl_convt_small_co_bwd_ws_floats(int Ci, int Co) { return 1024L * Ci * 16 * ((36 * Co + 15) / 16); }
 extern "C" int genrl_convt_small_co_bwd(const float* x, const float* Wp, const float* dy, float* dx, float* dWp, float* ws, int Nimg, int Hi,
                                         int Wi, int Ci, int Co, int k, void* stream) {
   GENRL_ENTER();
@@ -745,8 +860,13 @@ extern "C" int genrl_convt_small_co_bwd(const float* x, const float* Wp, const f
     GENRL_CHECK_LAUNCH();
   }
   if (dWp) {
-    const int nparts = 512;
-    hipLaunchKernelGGL((convt_small_co_wgrad_kernel<3, 7>), dim3(nparts), dim3(256), 0, s, x, dy, ws, Nimg, Hi, Wi, Co);
+    const int Wo = 2 * (Wi - 1) + k;
+    static const int wg_lds = getenv("GENRL_CONVT_WGRAD_LDS") ? atoi(getenv("GENRL_CONVT_WGRAD_LDS")) : 1;       // 0: the round-4 kernel everywhere
+    static const int wg_parts = getenv("GENRL_CONVT_WGRAD_WGS") ? std::min(1024, std::max(64, atoi(getenv("GENRL_CONVT_WGRAD_WGS")))) : 512;
+    const bool staged = wg_lds && (Wo & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+    const int nparts = staged ? wg_parts : 512;
+    if (staged) hipLaunchKernelGGL((convt_small_co_wgrad_lds_kernel<3, 7>), dim3(nparts), dim3(256), 0, s, x, dy, ws, Nimg, Hi, Wi, Co);
+    else hipLaunchKernelGGL((convt_small_co_wgrad_kernel<3, 7>), dim3(nparts), dim3(256), 0, s, x, dy, ws, Nimg, Hi, Wi, Co);
     GENRL_CHECK_LAUNCH();
     const int K = k * k * Co;
     hipLaunchKernelGGL(convt_small_co_wreduce_kernel, dim3(cdiv((long)Ci * K, 256)), dim3(256), 0, s, ws, nparts, Ci, 16 * 7, K, dWp);
