@@ -67,6 +67,7 @@ def _uniform_split(x2d):
 
 
 LAZY_FP32 = os.environ.get('GENRL_CONV_LAZY_FP32', '1') != '0'
+KEEP_COLS = os.environ.get('GENRL_CONV_KEEP_COLS', '1') != '0'      # the u8 first layer's patch matrix is kept for its weight gradient (one im2col launch less)
 
 
 def _ln_fwd(pre2d, gamma, beta, eps, want_planes, want_fp32=True):
@@ -263,6 +264,8 @@ class _Conv2dS2P(Function):
             else:
                 cols = ops._im2col(x, Nimg, Hi, Wi, C, k, 2 if u8 else 0)
                 sgemm(cols, K, 1, Wp, K, 1, y, Co, b, M, Co, K)
+                if u8 and KEEP_COLS and ctx.needs_input_grad[1]:
+                    ctx.cols = cols          # (the frames' patch matrix serves the weight gradient again: 0.15 GB at c2, 0.8 GB at c4, of 288)
         out, mean, rstd, outp, lazy = _ln_fwd(y, gamma, beta, eps, want_planes=planes_out and M >= min_rows(), want_fp32=fp32_out)
         holder.append(outp); holder.append(lazy)
         ctx.dims = (Nimg, Hi, Wi, C, k, u8)
@@ -296,8 +299,11 @@ class _Conv2dS2P(Function):
             elif ops._implicit_conv(x, C) and Co % 4 == 0:
                 sgemm_conv(dy2, 1, Co, x, 1, K, dW, K, None, Co, K, M, 2, (Hi, Wi, C, k))
             else:
-                cols = ops._im2col(x, Nimg, Hi, Wi, C, k, 2 if u8 else 0)
+                cols = getattr(ctx, 'cols', None)
+                if cols is None:
+                    cols = ops._im2col(x, Nimg, Hi, Wi, C, k, 2 if u8 else 0)
                 sgemm(dy2, 1, Co, cols, 1, K, dW, K, None, Co, K, M)
+                ctx.cols = None
                 del cols
         if need_dx and sp_maybe and subpixel_ok(dyp, Nimg, Ho, Wo, Co, C, k):
             # gather form: dx[n][2 py + a][2 px + b][ci] = sum over the T x T patch of the zero-padded dy and co -- no cols, no col2im
