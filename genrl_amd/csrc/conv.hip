@@ -874,3 +874,231 @@ extern "C" int genrl_convt_small_co_bwd(const float* x, const float* Wp, const f
   }
   return GENRL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The first encoder layer straight from the u8 frames (round 5): nn.Conv2d(3 -> 48, k = 4, stride 2) on x / 255 - 0.5
+// (agent/dreamer_utils.py:604-621, WorldModel.preprocess :139-151 fused).  It used to be im2col (0.8 GB of fp32 patch rows written at c4's
+// size) + a tall GEMM that read them back + the same patch matrix again for the weight gradient.  Here the MFMA operands come from the
+// frames themselves: forward -- a wave owns 16 consecutive output pixels of one image row, lane (r, kq) reads the four bytes of window row
+// kh = kq in each of the three channel planes (six 2-byte loads) and they are its A operands for the twelve MFMA steps (kw, c) of that kh;
+// the 36 weight words per lane stay in registers; the 16 x 48 output block leaves through a per-wave LDS transpose as whole rows.
+// Weight gradient -- contraction over the pixels, 16 per chunk: the chunk's dy rows (16-byte loads) and the 3 x 4 frame row segments of
+// its windows (converted once) are staged in a wave-private LDS slab a chunk ahead, 36 MFMAs per chunk, one partial matrix per workgroup,
+// summed in workgroup order (convt_small_co_wreduce_kernel).  Same arithmetic per element as the im2col path: (float)u8 / 255 - 0.5, fp32 MFMAs.
+namespace {
+template <int CB>      // Co = 16 CB
+__global__ __launch_bounds__(256) void conv1_u8_fwd_kernel(const uint8_t* __restrict__ in, const float* __restrict__ Wp,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int Nimg, int Hi, int Wi,
+                                                           int Ho, int Wo) {
+  constexpr int Co = 16 * CB, K = 48, LDT = Co + 4;
+  __shared__ __attribute__((aligned(16))) float tr[4][16][LDT];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, kq = lane >> 4;
+  const int bpr = (Wo + 15) / 16;
+  const long nblk = (long)Nimg * Ho * bpr;
+  // weights: MFMA step s = (kw, c) of window row kh = kq multiplies k = 12 kq + s; this lane's column n = 16 cb + r
+  float bf[12][CB];
+#pragma unroll
+  for (int s = 0; s < 12; ++s)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) bf[s][cb] = Wp[(long)(16 * cb + r) * K + 12 * kq + s];
+  float bs[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) bs[cb] = bias ? bias[16 * cb + r] : 0.f;
+  const int blk0 = blockIdx.x * 4 + wave, bstep = gridDim.x * 4;
+  int bx = blk0 % bpr, a = (blk0 / bpr) % Ho, img = (blk0 / bpr) / Ho;
+  const int sbx = bstep % bpr, sa = (bstep / bpr) % Ho, simg = (bstep / bpr) / Ho;
+  auto load_blk = [&](int bx_, int a_, int img_, unsigned short (&q)[6]) __attribute__((always_inline)) {
+    const int b = min(16 * bx_ + r, Wo - 1);              // (pixels beyond the row: a valid address, rows never stored)
+    const uint8_t* src = in + ((long)img_ * 3 * Hi + 2 * a_ + kq) * Wi + 2 * b;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const uint8_t* p = src + (long)c * Hi * Wi;
+      q[2 * c] = *reinterpret_cast<const unsigned short*>(p);
+      q[2 * c + 1] = *reinterpret_cast<const unsigned short*>(p + 2);
+    }
+  };
+  unsigned short cur[6], nxt[6];
+  if (blk0 < (int)nblk) load_blk(bx, a, img, cur);
+  for (int blk = blk0; blk < (int)nblk; blk += bstep) {        // (nblk < 2^31: checked by the host)
+    int nbx = bx + sbx, na = a + sa, nimg = img + simg;
+    if (nbx >= bpr) { nbx -= bpr; ++na; }
+    if (na >= Ho) { na -= Ho; ++nimg; }
+    const bool more = blk + bstep < (int)nblk;
+    if (more) load_blk(nbx, na, nimg, nxt);
+    f32x4 acc[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) acc[cb] = f32x4{bs[cb], bs[cb], bs[cb], bs[cb]};
+#pragma unroll
+    for (int kw = 0; kw < 4; ++kw)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const unsigned w16 = cur[2 * c + (kw >> 1)];
+        const float av = (float)((kw & 1) ? (w16 >> 8) : (w16 & 255u)) / 255.0f - 0.5f;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bf[kw * 3 + c][cb], acc[cb], 0, 0, 0);
+      }
+    // D[i = 4 kq + v][j = r]: pixel 16 bx + i, channel 16 cb + r
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) tr[wave][4 * kq + v][16 * cb + r] = acc[cb][v];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    float* orow = y + (((long)img * Ho + a) * Wo + 16 * bx) * Co;
+#pragma unroll
+    for (int q = lane; q < 16 * (Co / 4); q += 64) {
+      const int px = q / (Co / 4), c4 = q - px * (Co / 4);
+      if (16 * bx + px < Wo)
+        *reinterpret_cast<float4*>(orow + px * Co + 4 * c4) = *reinterpret_cast<const float4*>(&tr[wave][px][4 * c4]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) cur[i] = nxt[i];
+    }
+    bx = nbx; a = na; img = nimg;
+  }
+}
+
+template <int RB>      // Co = 16 RB output channels; K = 48 = 3 column blocks
+__global__ __launch_bounds__(256, 2) void conv1_u8_wgrad_kernel(const uint8_t* __restrict__ in, const float* __restrict__ dy,
+                                                                float* __restrict__ part, int Nimg, int Hi, int Wi, int Ho, int Wo) {
+  constexpr int Co = 16 * RB, K = 48, NCB = 3, LDY = Co + 4, LDR = 36, YS = 16 * LDY, RS = 12 * LDR, SLAB = YS + RS;
+  constexpr int YV = 16 * Co / 4, NYV = (YV + 63) / 64, RV = 12 * 17, NRV = (RV + 63) / 64;      // float4 pieces of dy; 2-byte pieces of the frame rows
+  constexpr int RED = 4 * NCB * 4 * 64;
+  __shared__ __attribute__((aligned(16))) float lds[RED > 4 * SLAB ? RED : 4 * SLAB];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, kq = lane >> 4;
+  const int bpr = (Wo + 15) / 16;
+  const long nchunk = (long)Nimg * Ho * bpr;
+  float* const ys = lds + wave * SLAB;
+  float* const rs = ys + YS;
+  // column j = 16 cb + r of the weight matrix is k = (kh, kw, c) = (j / 12, (j % 12) / 3, j % 3): frame row (c 4 + kh) of the slab, word kw
+  int boff[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int j = 16 * cb + r, kh = j / 12, kw = (j % 12) / 3, c = j % 3;
+    boff[cb] = (c * 4 + kh) * LDR + kw;
+  }
+  f32x4 acc[RB][NCB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nw = gridDim.x * 4, wid = blockIdx.x * 4 + wave;
+  const int per = (int)((nchunk + nw - 1) / nw), g0 = wid * per, g1 = (int)min(nchunk, (long)g0 + per);
+  int bx = g0 % bpr, a = (g0 / bpr) % Ho, img = (g0 / bpr) / Ho;        // the chunk the NEXT load_chunk fetches
+  float4 yg[NYV];
+  unsigned short rg[NRV];
+  auto load_chunk = [&]() __attribute__((always_inline)) {
+    const int b0 = 16 * bx;
+    const float* yp = dy + (((long)img * Ho + a) * Wo + b0) * Co;
+#pragma unroll
+    for (int i = 0; i < NYV; ++i) {
+      const int q = lane + 64 * i, px = q / (Co / 4);
+      const bool ok = q < YV && b0 + px < Wo;                          // (pixels beyond the row contribute zeros)
+      yg[i] = ok ? *reinterpret_cast<const float4*>(yp + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NRV; ++i) {
+      const int q = lane + 64 * i, row = q / 17, f = q - row * 17;     // row = c 4 + kh, piece f = columns 2 b0 + 2 f, + 1
+      const int c = row >> 2, kh = row & 3, col = 2 * b0 + 2 * f;
+      const bool ok = q < RV && col + 1 < Wi;
+      rg[i] = ok ? *reinterpret_cast<const unsigned short*>(in + ((long)(img * 3 + c) * Hi + 2 * a + kh) * Wi + col) : (unsigned short)0;
+    }
+    if (++bx == bpr) { bx = 0; if (++a == Ho) { a = 0; ++img; } }
+  };
+  auto store_chunk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NYV; ++i) {
+      const int q = lane + 64 * i, px = q / (Co / 4), c4 = q - px * (Co / 4);
+      if (q < YV) *reinterpret_cast<float4*>(ys + px * LDY + 4 * c4) = yg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NRV; ++i) {
+      const int q = lane + 64 * i, row = q / 17, f = q - row * 17;
+      if (q < RV) {
+        const unsigned w16 = rg[i];
+        *reinterpret_cast<float2*>(rs + row * LDR + 2 * f) = make_float2((float)(w16 & 255u) / 255.0f - 0.5f, (float)(w16 >> 8) / 255.0f - 0.5f);
+      }
+    }
+  };
+  if (g0 < g1) { load_chunk(); store_chunk(); }
+  for (int g = g0; g < g1; ++g) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (g + 1 < g1) load_chunk();
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int px = 4 * st + kq;
+      float av[RB], bv[NCB];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) av[rb] = ys[px * LDY + 16 * rb + r];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) bv[cb] = rs[boff[cb] + 2 * px];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rb], bv[cb], acc[rb][cb], 0, 0, 0);
+    }
+    if (g + 1 < g1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      store_chunk();
+    }
+  }
+  // the workgroup's four waves meet in LDS (fixed order): one partial matrix [Co][48] per workgroup
+  float* out = part + (long)blockIdx.x * Co * K;
+  float (*red)[NCB * 4][64] = reinterpret_cast<float (*)[NCB * 4][64]>(lds);
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) red[wave][cb * 4 + v][lane] = acc[rb][cb][v];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NCB * 4 * 64; idx += 256) {
+      const int l = idx & 63, cv = idx >> 6, cb = cv >> 2, v = cv & 3;
+      // D[i = 4 (l / 16) + v][j = l % 16]
+      out[(long)(16 * rb + 4 * (l >> 4) + v) * K + 16 * cb + (l & 15)] = red[0][cv][l] + red[1][cv][l] + red[2][cv][l] + red[3][cv][l];
+    }
+  }
+}
+}  // namespace
+
+/* nn.Conv2d(3 -> Co, k = 4, stride 2) on x / 255 - 0.5 straight from u8 NCHW frames [Nimg][3][Hi][Wi]: y fp32 [Nimg Ho Wo][Co] (+ bias), Wp = the
+ * weight permuted to (co, kh, kw, c).  Supported: Co = 48, k = 4, Wi even, 2-byte aligned frames, 16-byte aligned y; GENRL_EINVAL otherwise (the
+ * caller keeps im2col + GEMM). */
+extern "C" int genrl_conv1_u8_fwd(const uint8_t* in, const float* Wp, const float* bias, float* y, int Nimg, int Hi, int Wi, int Co, int k,
+                                  void* stream) {
+  GENRL_ENTER();
+  const int Ho = (Hi - k) / 2 + 1, Wo = (Wi - k) / 2 + 1;
+  if (Nimg <= 0 || Co != 48 || k != 4 || Hi < 4 || Wi < 4 || (Wi & 1) || (reinterpret_cast<uintptr_t>(in) & 1) || (reinterpret_cast<uintptr_t>(y) & 15) ||
+      (long)Nimg * Ho * ((Wo + 15) / 16) > 0x3fffffffL)
+    return GENRL_EINVAL;
+  const long nblk = (long)Nimg * Ho * ((Wo + 15) / 16);
+  static const int cap = getenv("GENRL_CONV1_WGS") ? atoi(getenv("GENRL_CONV1_WGS")) : 1024;
+  const int blocks = (int)(cdiv(nblk, 4) < cap ? cdiv(nblk, 4) : cap);
+  hipLaunchKernelGGL((conv1_u8_fwd_kernel<3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, Wp, bias, y, Nimg, Hi, Wi, Ho, Wo);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}
+
+/* its weight gradient dWp[co][(kh, kw, c)] = sum over the pixels of dy[m][co] patch(m)[(kh, kw, c)]; dy fp32 [Nimg Ho Wo][Co] (16-byte aligned), ws:
+ * genrl_conv1_u8_wgrad_ws_floats(Co) floats.  Same preconditions as genrl_conv1_u8_fwd. */
+extern "C" long genrl_conv1_u8_wgrad_ws_floats(int Co) { return 512L * Co * 48; }
+extern "C" int genrl_conv1_u8_wgrad(const uint8_t* in, const float* dy, float* dWp, float* ws, int Nimg, int Hi, int Wi, int Co, int k,
+                                    void* stream) {
+  GENRL_ENTER();
+  const int Ho = (Hi - k) / 2 + 1, Wo = (Wi - k) / 2 + 1;
+  if (Nimg <= 0 || Co != 48 || k != 4 || Hi < 4 || Wi < 4 || (Wi & 1) || !ws || (reinterpret_cast<uintptr_t>(in) & 1) ||
+      (reinterpret_cast<uintptr_t>(dy) & 15) || (long)Nimg * Ho * ((Wo + 15) / 16) > 0x3fffffffL)
+    return GENRL_EINVAL;
+  const int nparts = 512;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL((conv1_u8_wgrad_kernel<3>), dim3(nparts), dim3(256), 0, s, in, dy, ws, Nimg, Hi, Wi, Ho, Wo);
+  GENRL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(convt_small_co_wreduce_kernel, dim3(cdiv((long)Co * 48, 256)), dim3(256), 0, s, ws, nparts, Co, 48, 48, dWp);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}

@@ -67,6 +67,7 @@ def _uniform_split(x2d):
 
 
 LAZY_FP32 = os.environ.get('GENRL_CONV_LAZY_FP32', '1') != '0'
+CONV1_DIRECT = os.environ.get('GENRL_CONV1_DIRECT', '1') != '0'
 KEEP_COLS = os.environ.get('GENRL_CONV_KEEP_COLS', '1') != '0'      # the u8 first layer's patch matrix is kept for its weight gradient (one im2col launch less)
 
 
@@ -233,6 +234,11 @@ KR_MIN_K = int(os.environ.get('GENRL_PLANES_KR_MIN_K', '512'))      # GEMM -> co
 #                     64 KiB store -- the write-bound fp32-operand kernel is faster there (173056 x 1728 x 96: 0.55 vs 1.0 ms)
 
 
+def _conv1_direct(x, C, k, Co, Wi):
+    """may genrl_conv1_u8_fwd / _wgrad take the first encoder layer?  (precision 16 rounds operands in the GEMM kernels proper: it keeps im2col + GEMM)"""
+    return CONV1_DIRECT and C == 3 and k == 4 and Co == 48 and Wi % 2 == 0 and x.data_ptr() % 2 == 0 and not ops._p16()
+
+
 def _gather_ok(M, C, k=1):
     return M * k * k >= min_rows() and C % 8 == 0 and C >= 48
 
@@ -257,6 +263,10 @@ class _Conv2dS2P(Function):
         on_planes = (not u8) and xp is not None and _gather_ok(M, C)
         if on_planes:
             _gemm_conv(xp, Nimg, Hi, Wi, C, k, _wplanes(ctx.wsrc, Wp, False), y, Co, b, Co)
+        elif u8 and _conv1_direct(x, C, k, Co, Wi):
+            # the first layer straight from the frames (genrl_conv1_u8_fwd): no patch matrix, forward or backward
+            check(lib().genrl_conv1_u8_fwd(_p(x), _p(Wp), _p(b), _p(y), Nimg, Hi, Wi, Co, k, _stream()), 'conv1_u8_fwd')
+            ctx.direct1 = True
         else:
             _need_fp32(x, ctx.xlazy, xp)
             if ops._implicit_conv(x, C):
@@ -294,7 +304,10 @@ class _Conv2dS2P(Function):
             dW = torch.empty(Co, K, device=dy.device)
             if not (tn and dyp is not None):
                 _need_fp32(x, ctx.xlazy, xp)
-            if tn and dyp is not None:
+            if getattr(ctx, 'direct1', False):
+                ws = torch.empty(lib().genrl_conv1_u8_wgrad_ws_floats(Co), device=dy.device)
+                check(lib().genrl_conv1_u8_wgrad(_p(x), _p(dy2), _p(dW), _p(ws), Nimg, Hi, Wi, Co, k, _stream()), 'conv1_u8_wgrad')
+            elif tn and dyp is not None:
                 _gemm_tn_conv(dyp, xp, Nimg, Hi, Wi, C, k, dW, K, Co, M)
             elif ops._implicit_conv(x, C) and Co % 4 == 0:
                 sgemm_conv(dy2, 1, Co, x, 1, K, dW, K, None, Co, K, M, 2, (Hi, Wi, C, k))

@@ -158,6 +158,14 @@ int genrl_pad_planes(const uint16_t* src, long splane, const float* sinv, uint16
  * and the strides of (cout, cin) in the weight's storage. */
 int genrl_subpixel_weight(const float* W, long s_ci, long s_co, long s_tap, int Ci, int Co, int k, int T, float* Wsub, const float* bias,
                           float* bias4, void* stream);
+/* The first encoder layer straight from the u8 frames (agent/dreamer_utils.py:604-621 with WorldModel.preprocess :139-151 fused): nn.Conv2d(3 -> Co,
+ * k = 4, stride 2) on x / 255 - 0.5; in u8 NCHW [Nimg][3][Hi][Wi], Wp = the weight permuted to (co, kh, kw, c), y fp32 [Nimg Ho Wo][Co] (+ bias).  The
+ * MFMA operands are read from the frames themselves (no patch matrix); exact fp32 arithmetic, the same per element as genrl_im2col_s2 mode 2 + genrl_sgemm.
+ * genrl_conv1_u8_wgrad: dWp[co][(kh, kw, c)] = sum over the pixels of dy[m][co] patch(m)[..] (ws: genrl_conv1_u8_wgrad_ws_floats(Co) floats; summed in a
+ * fixed order).  Supported: Co = 48, k = 4, Wi even, frames 2-byte / y, dy 16-byte aligned; GENRL_EINVAL otherwise. */
+int genrl_conv1_u8_fwd(const uint8_t* in, const float* Wp, const float* bias, float* y, int Nimg, int Hi, int Wi, int Co, int k, void* stream);
+long genrl_conv1_u8_wgrad_ws_floats(int Co);
+int genrl_conv1_u8_wgrad(const uint8_t* in, const float* dy, float* dWp, float* ws, int Nimg, int Hi, int Wi, int Co, int k, void* stream);
 /* nn.ConvTranspose2d(Ci -> Co, k, stride 2) forward for Co <= 4 output channels -- the decoder's last layer
  * (agent/dreamer_utils.py:686-706) -- in gather form on the fp32 matrix cores (csrc/conv.hip): every wave owns 16 consecutive patch
  * positions, all four output parity classes x Co channels are the 16 MFMA columns, the weights live in registers; exact fp32, no cols

@@ -185,3 +185,37 @@ def test_direct_three_channel_transposed_convolution(N, Hi, Wi, Co, nchw, bwd, m
     err = (y.cpu().double() - r).abs().max().item() / r.abs().max().item()
     assert err < 2e-6, err
     _check(hip, ref, [x, W, b], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('N,Hi,Wi', [(8, 64, 64), (3, 64, 64), (2, 128, 128), (5, 34, 30), (4, 20, 66), (1, 6, 4), (33, 64, 64)])
+def test_first_layer_straight_from_the_u8_frames(N, Hi, Wi, monkeypatch):
+    """genrl_conv1_u8_fwd / genrl_conv1_u8_wgrad (the first encoder layer without a patch matrix, ops_conv_planes._conv1_direct) against torch's
+    conv2d on x / 255 - 0.5 in float64 + LayerNorm + SiLU -- output, weight / bias / LayerNorm gradients -- and against the im2col + GEMM
+    path it replaces (GENRL_CONV1_DIRECT=0) at fp32 rounding; row widths that end inside a 16-pixel block (Wo = 31, 63, 14), one that fills
+    its blocks exactly (Wo = 32), a single-pixel row"""
+    from genrl_amd import ops_conv_planes as cp
+    x = torch.randint(0, 256, (N, 3, Hi, Wi), generator=g(1), dtype=torch.uint8)
+    W = torch.randn(48, 3, 4, 4, generator=g(2)) / 48 ** .5; b = 0.1 * torch.randn(48, generator=g(3))
+    ga, be = 1 + 0.1 * torch.randn(48, generator=g(4)), 0.1 * torch.randn(48, generator=g(5))
+    Ho, Wo = (Hi - 4) // 2 + 1, (Wi - 4) // 2 + 1
+    wgt = torch.randn(N, Ho, Wo, 48, generator=g(6))
+
+    def run(direct):
+        monkeypatch.setattr(cp, 'CONV1_DIRECT', direct)
+        ps = [t.clone().cuda().requires_grad_(True) for t in (W, b, ga, be)]
+        y = cp.conv2d_s2(x.cuda(), ps[0], ps[1], (ps[2], ps[3], 1e-3), fp32_out=True)
+        (y * wgt.cuda()).sum().backward()
+        return [y.detach()] + [p.grad.detach() for p in ps]
+    new, old = run(True), run(False)
+    xd = (x.double() / 255.0 - 0.5)
+    ps = [t.clone().double().requires_grad_(True) for t in (W, b, ga, be)]
+    ref = _ln_silu(F.conv2d(xd, ps[0], ps[1], stride=2).permute(0, 2, 3, 1), ps[2], ps[3])
+    (ref * wgt.double()).sum().backward()
+    refs = [ref.detach()] + [p.grad for p in ps]
+    for name, a, o, rf in zip(('y', 'dW', 'db', 'dgamma', 'dbeta'), new, old, refs):
+        scale = max(1e-6, rf.abs().max().item())
+        assert a.shape == rf.shape and torch.isfinite(a).all(), name
+        e_new = (a.cpu().double() - rf).abs().max().item() / scale
+        e_old = (o.cpu().double() - rf).abs().max().item() / scale
+        assert e_new <= 2e-5, (name, e_new, e_old)
+        assert e_new <= 4 * e_old + 2e-6, (name, e_new, e_old)        # no worse than the path it replaces (fp32 summation orders differ)
