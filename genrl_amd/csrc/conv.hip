@@ -356,9 +356,12 @@ extern "C" int genrl_subpixel_weight(const float* W, long s_ci, long s_co, long 
 #ifndef CONVT_ABL
 #define CONVT_ABL 0
 #endif
+#ifndef CONVT_FWD_WLDS
+#define CONVT_FWD_WLDS 1      /* the 3-channel forward kernel's weights in LDS (0: in 108 registers, round 4) */
+#endif
 namespace {
 template <int T, int J>      // k = 2T taps per dimension pair; Ci = 16 J
-__global__ __launch_bounds__(256, 3) void convt_small_co_fwd_kernel(const float* __restrict__ x, const float* __restrict__ Wp,
+__global__ __launch_bounds__(256, CONVT_FWD_WLDS ? 4 : 3) void convt_small_co_fwd_kernel(const float* __restrict__ x, const float* __restrict__ Wp,
                                                                  const float* __restrict__ bias, float* __restrict__ out, int Nimg,
                                                                  int Hi, int Wi, int Co, int out_nchw) {
   constexpr int Ci = 16 * J, NS = T * T * J * 4, k = 2 * T;
@@ -370,7 +373,13 @@ __global__ __launch_bounds__(256, 3) void convt_small_co_fwd_kernel(const float*
   const long nblk = (long)Nimg * Hq * bpr;
   // ---- weight fragments: step s = ((u T + v) J + j) 4 + e multiplies k = (u, v, ci = 16 j + 4 kq + e); this lane's column n = r
   const int n = r, cls = n / Co, c_n = n - cls * Co, a_n = cls >> 1, b_n = cls & 1;
+#if CONVT_FWD_WLDS
+  // (round 5: the NS = 108 weight words per lane live in LDS -- one table for the four waves, a 16-byte conflict-free read per 4 MFMAs --
+  // instead of 108 registers: more waves per SIMD to hide the tap loads behind)
+  __shared__ float4 wl[NS / 4][64];
+#else
   float bf[NS];
+#endif
 #pragma unroll
   for (int u = 0; u < T; ++u)
 #pragma unroll
@@ -380,8 +389,17 @@ __global__ __launch_bounds__(256, 3) void convt_small_co_fwd_kernel(const float*
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int kh = a_n + 2 * (T - 1 - u), kw = b_n + 2 * (T - 1 - v), ci = 16 * j + 4 * kq + e;
-          bf[((u * T + v) * J + j) * 4 + e] = (n < 4 * Co) ? Wp[(long)ci * (k * k * Co) + (kh * k + kw) * Co + c_n] : 0.f;
+          const int s = ((u * T + v) * J + j) * 4 + e;
+#if CONVT_FWD_WLDS
+          if ((s / 4) % 4 == wave)
+            reinterpret_cast<float*>(&wl[s / 4][lane])[e] = (n < 4 * Co) ? Wp[(long)ci * (k * k * Co) + (kh * k + kw) * Co + c_n] : 0.f;
+#else
+          bf[s] = (n < 4 * Co) ? Wp[(long)ci * (k * k * Co) + (kh * k + kw) * Co + c_n] : 0.f;
+#endif
         }
+#if CONVT_FWD_WLDS
+  __syncthreads();
+#endif
   const float bias_n = (bias && n < 4 * Co) ? bias[c_n] : 0.f;
   // taps in flight: the loads of tap t + 1 are issued before the 4 J MFMAs of tap t (two register sets), and the loads of the NEXT block's
   // first tap before the last tap's MFMAs and this block's epilogue (they were exposed once per block: 9 taps of ~400 MFMA cycles each
@@ -428,13 +446,19 @@ __global__ __launch_bounds__(256, 3) void convt_small_co_fwd_kernel(const float*
       for (int j = 0; j < J; ++j) {
         const int s = (tap * J + j) * 4;
         const float4 a4 = av[(tap + PAR) & 1][j];
-#if CONVT_ABL == 1       /* ablation 1: no MFMAs (operands kept live) */
-        asm volatile("" ::"v"(a4.x), "v"(a4.y), "v"(a4.z), "v"(a4.w), "v"(bf[s]), "v"(bf[s + 3]));
+#if CONVT_FWD_WLDS
+        const float4 w4 = wl[s / 4][lane];
+        const float bw[4] = {w4.x, w4.y, w4.z, w4.w};
 #else
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bf[s + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bf[s + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bf[s + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bf[s + 3], acc, 0, 0, 0);
+        const float* bw = bf + s;
+#endif
+#if CONVT_ABL == 1       /* ablation 1: no MFMAs (operands kept live) */
+        asm volatile("" ::"v"(a4.x), "v"(a4.y), "v"(a4.z), "v"(a4.w), "v"(bw[0]), "v"(bw[3]));
+#else
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bw[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bw[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bw[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bw[3], acc, 0, 0, 0);
 #endif
       }
     }
@@ -494,8 +518,8 @@ extern "C" int genrl_convt_small_co_fwd(const float* x, const float* Wp, const f
   if (Nimg <= 0 || Hi <= 0 || Wi <= 0 || Co < 1 || Co > 4 || k != 6 || Ci != 48 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15))
     return GENRL_EINVAL;
   const long nblk = (long)Nimg * (Hi + 2) * ((Wi + 2 + 15) / 16);
-  /* resident waves only (3 per SIMD at 153 VGPRs): a wave builds its 108 weight fragments once and then walks many blocks */
-  static const int wg_cap = getenv("GENRL_CONVT_WGS") ? atoi(getenv("GENRL_CONVT_WGS")) : 768;
+  /* resident waves only (5 per SIMD with the weights in LDS: 678 us at 4 096 images against 727 with them in registers, 3 per SIMD) */
+  static const int wg_cap = getenv("GENRL_CONVT_WGS") ? atoi(getenv("GENRL_CONVT_WGS")) : (CONVT_FWD_WLDS ? 1280 : 768);
   const int blocks = (int)(cdiv(nblk, 4) < wg_cap ? cdiv(nblk, 4) : wg_cap);
   hipLaunchKernelGGL((convt_small_co_fwd_kernel<3, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, Wp, bias, out, Nimg, Hi, Wi, Co,
                      out_nchw);
