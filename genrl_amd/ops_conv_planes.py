@@ -265,7 +265,12 @@ class _Conv2dS2P(Function):
             _gemm_conv(xp, Nimg, Hi, Wi, C, k, _wplanes(ctx.wsrc, Wp, False), y, Co, b, Co)
         elif u8 and _conv1_direct(x, C, k, Co, Wi):
             # the first layer straight from the frames (genrl_conv1_u8_fwd): no patch matrix, forward or backward
+            if planes.gemm_profile is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e0.record()
             check(lib().genrl_conv1_u8_fwd(_p(x), _p(Wp), _p(b), _p(y), Nimg, Hi, Wi, Co, k, _stream()), 'conv1_u8_fwd')
+            if planes.gemm_profile is not None:
+                e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                planes.gemm_profile.append((M, Co, K, e0, e1, 'kk/conv1_direct'))
             ctx.direct1 = True
         else:
             _need_fp32(x, ctx.xlazy, xp)
@@ -306,7 +311,12 @@ class _Conv2dS2P(Function):
                 _need_fp32(x, ctx.xlazy, xp)
             if getattr(ctx, 'direct1', False):
                 ws = torch.empty(lib().genrl_conv1_u8_wgrad_ws_floats(Co), device=dy.device)
+                if planes.gemm_profile is not None:
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record()
                 check(lib().genrl_conv1_u8_wgrad(_p(x), _p(dy2), _p(dW), _p(ws), Nimg, Hi, Wi, Co, k, _stream()), 'conv1_u8_wgrad')
+                if planes.gemm_profile is not None:
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                    planes.gemm_profile.append((Co, K, M, e0, e1, 'rr/conv1_direct_bwd'))
             elif tn and dyp is not None:
                 _gemm_tn_conv(dyp, xp, Nimg, Hi, Wi, C, k, dW, K, Co, M)
             elif ops._implicit_conv(x, C) and Co % 4 == 0:
