@@ -12,10 +12,18 @@ UNIMIX = 0.99
 gemm_profile = None      # set to a list to record (M, N, K, start_event, end_event) per sgemm launch
 
 
+_cuda_ok = None
+
+
 def _stream():
-    if not torch.cuda.is_available():
+    """raw handle of torch's current stream on the current device (the C call behind torch.cuda.current_stream(): that wrapper costs ~8 us
+    of host time per call and an eager iteration asks ~300 times)"""
+    global _cuda_ok
+    if _cuda_ok is None:
+        _cuda_ok = torch.cuda.is_available()
+    if not _cuda_ok:
         raise GenrlHipError('genrl_amd ops need an MI355X (torch.cuda unavailable); there is no CPU fallback')
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _p(t):
