@@ -21,6 +21,8 @@ def _stream():
     global _cuda_ok
     if _cuda_ok is None:
         _cuda_ok = torch.cuda.is_available()
+        if _cuda_ok:
+            torch.cuda.init()            # (the raw calls below skip torch.cuda's lazy initialisation)
     if not _cuda_ok:
         raise GenrlHipError('genrl_amd ops need an MI355X (torch.cuda unavailable); there is no CPU fallback')
     return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
