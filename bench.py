@@ -41,6 +41,8 @@ def synth_batch(B, T, A=10, img=64, seed=0):
 
 class TextStub:
     """InternVideo2 text embedder stand-in (weights are not available offline): seeded unit vector."""
+    ignores_text = True          # (tools/genrl_utils: no missing-prompt warning for an embedder that never reads the prompt)
+
     def get_txt_feat(self, text):
         g = torch.Generator().manual_seed(123)
         return torch.nn.functional.normalize(torch.randn(1, 512, generator=g), dim=-1)

@@ -374,8 +374,10 @@ class Encoder(Module):  # ref :558-628
         last = len(self._cnn_kernels) - 1
         for i in range(last + 1):
             conv, ln = self._conv_model[3 * i], self._conv_model[3 * i + 1]
-            # (an inner layer's fp32 activation has no reader when the next layer gathers from its planes: ops_conv_planes._ln_fwd)
-            x = conv2d(x, conv.weight, conv.bias, ln=(ln.norm.weight, ln.norm.bias, ln.norm.eps), fp32_out=i == last, planes_out=i != last)
+            # (an inner layer's fp32 activation has no reader when the next layer gathers from its planes forward AND backward: decided by
+            # the next layer's own predicates, ops_conv_planes.consumer_reads_planes_only -- not by position)
+            nxt = True if i == last else ('conv', self._cnn_kernels[i + 1])
+            x = conv2d(x, conv.weight, conv.bias, ln=(ln.norm.weight, ln.norm.bias, ln.norm.eps), fp32_out=nxt, planes_out=i != last)
         n, h, w, c = x.shape
         return ops.transpose_last2(x.reshape(n, h * w, c)).reshape(n, c * h * w)    # NCHW flatten, ref :621
 
@@ -418,8 +420,11 @@ class Decoder(Module):  # ref :631-715
             conv = self._conv_model[3 * i]
             if i != n - 1:
                 ln = self._conv_model[3 * i + 1]
-                # (the 3-channel last layer reads fp32 values, no planes; the inner layers read planes)
-                x = convT2d(x, conv.weight, conv.bias, ln=(ln.norm.weight, ln.norm.bias, ln.norm.eps), fp32_out=i == n - 2, planes_out=i != n - 2)
+                # (the 3-channel last layer reads fp32 values, no planes; an inner layer's fp32 output is skipped when the next layer's own
+                # predicates say it reads planes only)
+                nconv = self._conv_model[3 * (i + 1)]
+                nxt = True if i == n - 2 else ('convT', nconv.out_channels, self._cnn_kernels[i + 1])
+                x = convT2d(x, conv.weight, conv.bias, ln=(ln.norm.weight, ln.norm.bias, ln.norm.eps), fp32_out=nxt, planes_out=i != n - 2)
             else:
                 x = ops.convT2d_s2(x, conv.weight, conv.bias, out_nchw=True)     # frames leave in the reference's NCHW
         return {key: MSEDist(x.reshape(tuple(lead) + tuple(x.shape[1:]))) for key in self.channels}

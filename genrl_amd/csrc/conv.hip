@@ -298,6 +298,23 @@ __global__ __launch_bounds__(256) void pad_planes_kernel(const uint4* __restrict
   }
 }
 
+// y[r][c .. c+3] = (h + l / 2^11) inv[r]: the fp32 values of h2 planes, for a consumer that reads fp32 after the producer wrote planes only
+// (ops_conv_planes._need_fp32).  One 8-byte load per plane and one 16-byte store per lane; the value is the planes' 22-bit representation.
+__global__ __launch_bounds__(256) void planes_to_f32_kernel(const uint2* __restrict__ p, long ld4, long plane4, const float* __restrict__ inv,
+                                                            float4* __restrict__ y, long ldy4, long rows, int cols4) {
+  const long total = rows * cols4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / cols4;
+    const int c = (int)(i - r * cols4);
+    const uint2 h = p[r * ld4 + c], l = p[plane4 + r * ld4 + c];
+    const float iv = inv[r];
+    const h2_f32x2 h0 = __builtin_convertvector(__builtin_bit_cast(h2_f16x2, h.x), h2_f32x2), h1 = __builtin_convertvector(__builtin_bit_cast(h2_f16x2, h.y), h2_f32x2);
+    const h2_f32x2 l0 = __builtin_convertvector(__builtin_bit_cast(h2_f16x2, l.x), h2_f32x2), l1 = __builtin_convertvector(__builtin_bit_cast(h2_f16x2, l.y), h2_f32x2);
+    y[r * ldy4 + c] = make_float4((h0[0] + l0[0] * (1.f / 2048.f)) * iv, (h0[1] + l0[1] * (1.f / 2048.f)) * iv,
+                                  (h1[0] + l1[0] * (1.f / 2048.f)) * iv, (h1[1] + l1[1] * (1.f / 2048.f)) * iv);
+  }
+}
+
 // Wsub[(a, b, co)][(u, v, ci)] = w(ci, co, a + 2 (T - 1 - u), b + 2 (T - 1 - v)) (0 where the tap index reaches k); one thread per
 // output element (<= 2.7 M elements per layer, once per optimiser step)
 __global__ __launch_bounds__(256) void subpixel_weight_kernel(const float* __restrict__ W, long s_ci, long s_co, long s_tap, int Ci, int Co, int k, int T,
@@ -328,6 +345,19 @@ extern "C" int genrl_pad_planes(const uint16_t* src, long splane, const float* s
   const int blocks = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
   hipLaunchKernelGGL(pad_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint4*>(src), splane / 8,
                      sinv, reinterpret_cast<uint4*>(dst), dplane / 8, dinv, Nimg, H, W, (int)(ld / 8), pad);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
+}
+
+extern "C" int genrl_planes_to_f32(const uint16_t* p, long ld, long plane, const float* inv, float* y, long ldy, long rows, int cols, void* stream) {
+  GENRL_ENTER();
+  if (rows <= 0 || cols <= 0 || (cols & 3) || (ld & 3) || (plane & 3) || (ldy & 3) || cols > ld || cols > ldy ||
+      (reinterpret_cast<uintptr_t>(p) & 7) || (reinterpret_cast<uintptr_t>(y) & 15))
+    return GENRL_EINVAL;
+  const long total = rows * (cols / 4);
+  const int blocks = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
+  hipLaunchKernelGGL(planes_to_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint2*>(p), ld / 4, plane / 4, inv,
+                     reinterpret_cast<float4*>(y), ldy / 4, rows, cols / 4);
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }

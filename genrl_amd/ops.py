@@ -12,20 +12,7 @@ UNIMIX = 0.99
 gemm_profile = None      # set to a list to record (M, N, K, start_event, end_event) per sgemm launch
 
 
-_cuda_ok = None
-
-
-def _stream():
-    """raw handle of torch's current stream on the current device (the C call behind torch.cuda.current_stream(): that wrapper costs ~8 us
-    of host time per call and an eager iteration asks ~300 times)"""
-    global _cuda_ok
-    if _cuda_ok is None:
-        _cuda_ok = torch.cuda.is_available()
-        if _cuda_ok:
-            torch.cuda.init()            # (the raw calls below skip torch.cuda's lazy initialisation)
-    if not _cuda_ok:
-        raise GenrlHipError('genrl_amd ops need an MI355X (torch.cuda unavailable); there is no CPU fallback')
-    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+from .streams import raw_current_stream as _stream      # raw hipStream_t of torch's current stream (private fast call, public fallback)
 
 
 def _p(t):

@@ -95,9 +95,12 @@ def _ln_fwd(pre2d, gamma, beta, eps, want_planes, want_fp32=True):
 
 
 def _need_fp32(x, cell, xp):
-    """x's fp32 values are about to be read: fill them from the planes if the producer skipped them (see _ln_fwd)"""
+    """x's fp32 values are about to be read: fill them from the planes if the producer skipped them (see _ln_fwd).  One HBM pass of a
+    dedicated kernel (genrl_planes_to_f32: no float64, no temporaries -- inside a hipGraph capture temporaries would stay in the graph's pool)"""
     if cell is not None and cell[0]:
-        x.data.view(xp.rows, xp.cols).copy_(xp.float())      # (.data: the values autograd saw were never defined -- no version bump)
+        assert x.is_contiguous() and x.numel() == xp.rows * xp.cols
+        # (x.data_ptr(): the values autograd saw were never defined -- written behind its back, no version bump)
+        check(lib().genrl_planes_to_f32(xp.ptr(), xp.ld, xp.plane, xp.inv_ptr(), x.data_ptr(), xp.cols, xp.rows, xp.cols, _stream()), 'planes_to_f32')
         cell[0] = False
 
 
@@ -172,12 +175,11 @@ def _hl_on():
     return os.environ.get('GENRL_PLANES_HL', '1')[:1] != '0'
 
 
-def subpixel_ok(xp, Nimg, Hi, Wi, Cs, Cp, k):
-    """may genrl_gemm_h2_subpixel take this layer?  xp: planes of the [Nimg Hi Wi][Cs] input (must be uniform-scale); Cs summed
-    channels, Cp produced channels, k the stride-2 kernel"""
+def _subpixel_dims_ok(Nimg, Hi, Wi, Cs, Cp, k):
+    """the shape side of subpixel_ok (what a PRODUCER can know about its consumer before the planes exist)"""
     T = (k + 1) // 2
-    if not (SUBPIXEL and _hl_on() and xp is not None and xp.uniform and (k % 2 == 0 or SUBPIXEL_ODD) and Cs % 8 == 0 and Cs >= 48 and Cp % 4 == 0
-            and xp.cols == Cs and T * T * Cs >= 64 and Nimg * (Hi + T - 1) * (Wi + T - 1) >= min_rows() // 4):
+    if not (SUBPIXEL and _hl_on() and (k % 2 == 0 or SUBPIXEL_ODD) and Cs % 8 == 0 and Cs >= 48 and Cp % 4 == 0
+            and T * T * Cs >= 64 and Nimg * (Hi + T - 1) * (Wi + T - 1) >= min_rows() // 4):
         return False
     # the kernel's own size limits (genrl_gemm_h2_subpixel: 32-bit byte offsets into the padded planes, 31-bit row count): a layer beyond
     # them -- larger frames at a larger per-GPU batch -- keeps the GEMM -> col2im form instead of failing
@@ -185,6 +187,34 @@ def subpixel_ok(xp, Nimg, Hi, Wi, Cs, Cp, k):
     ld = (Cs + 63) // 64 * 64
     plane = Nimg * Hp * Wp * ld
     return (Nimg * Hp * Wp * ld + plane) * 2 < 0xffffffff and Nimg * (Hp - T + 1) * (Wp - T + 1) <= 0x7fffffff
+
+
+def subpixel_ok(xp, Nimg, Hi, Wi, Cs, Cp, k):
+    """may genrl_gemm_h2_subpixel take this layer?  xp: planes of the [Nimg Hi Wi][Cs] input (must be uniform-scale); Cs summed
+    channels, Cp produced channels, k the stride-2 kernel"""
+    return xp is not None and xp.uniform and xp.cols == Cs and _subpixel_dims_ok(Nimg, Hi, Wi, Cs, Cp, k)
+
+
+def consumer_reads_planes_only(consumer, Nimg, H, W, C):
+    """Will the NEXT layer read this layer's (Nimg, H, W, C) output from its uniform planes alone -- forward product AND weight gradient --
+    so that the channel-LayerNorm need not write the fp32 activation at all?  consumer: ('conv', k) = a stride-2 convolution of this module,
+    ('convT', Co, k) = a stride-2 transposed convolution.  The very predicates the consumers apply (a wrong 'yes' is still correct: the
+    consumer fills the fp32 values from the planes, _need_fp32 -- one extra pass; a wrong 'no' writes an activation nobody reads)."""
+    if not consumer or not LAZY_FP32:
+        return False
+    if consumer[0] == 'conv':
+        k = consumer[1]
+        Ho, Wo = (H - k) // 2 + 1, (W - k) // 2 + 1
+        M = Nimg * Ho * Wo
+        return Ho > 0 and Wo > 0 and _gather_ok(M, C) and M % 64 == 0 and (C * k * k) % 8 == 0
+    if consumer[0] == 'convT':
+        _, Co, k = consumer
+        M = Nimg * H * W
+        on_planes = M * k * k >= min_rows()
+        fwd = on_planes and ((H > 1 and _subpixel_dims_ok(Nimg, H, W, C, Co, k)) or C >= KR_MIN_K)
+        tn = _gather_ok(M, Co, k) and C % 4 == 0 and M % 64 == 0
+        return fwd and tn
+    return False
 
 
 def _subpixel(xp, Nimg, Hi, Wi, Cs, Cp, k, Wsrc, s_ci, s_co, s_tap, bias, out, wkey=None):
@@ -281,6 +311,8 @@ class _Conv2dS2P(Function):
                 sgemm(cols, K, 1, Wp, K, 1, y, Co, b, M, Co, K)
                 if u8 and KEEP_COLS and ctx.needs_input_grad[1]:
                     ctx.cols = cols          # (the frames' patch matrix serves the weight gradient again: 0.15 GB at c2, 0.8 GB at c4, of 288)
+        if isinstance(fp32_out, tuple):       # the consumer's description: decided by ITS predicates, not by the layer's position
+            fp32_out = not consumer_reads_planes_only(fp32_out, Nimg, Ho, Wo, Co)
         out, mean, rstd, outp, lazy = _ln_fwd(y, gamma, beta, eps, want_planes=planes_out and M >= min_rows(), want_fp32=fp32_out)
         holder.append(outp); holder.append(lazy)
         ctx.dims = (Nimg, Hi, Wi, C, k, u8)
@@ -375,6 +407,8 @@ class _ConvT2dS2P(Function):
             y = ops._col2im(cols, b, Nimg, Hi, Wi, Co, k)
             del cols
         Ho, Wo = y.shape[1], y.shape[2]
+        if isinstance(fp32_out, tuple):
+            fp32_out = not consumer_reads_planes_only(fp32_out, Nimg, Ho, Wo, Co)
         out, mean, rstd, outp, lazy = _ln_fwd(y.reshape(-1, Co), gamma, beta, eps, want_planes=planes_out and Nimg * Ho * Wo >= min_rows(),
                                               want_fp32=fp32_out)
         holder.append(outp); holder.append(lazy)
@@ -428,7 +462,9 @@ class _ConvT2dS2P(Function):
 def conv2d_s2(x, W, b, ln, fp32_out=True, planes_out=True):
     """ops.conv2d_s2 with the fused channel-LayerNorm; the output carries ._planes (uniform planes of its pixel rows) for the
     next layer when it was worth making them.  fp32_out False: the caller passes the output to another layer of this module only,
-    which reads the planes (the fp32 values are then filled on demand: ._lazy); planes_out False: nothing reads the planes"""
+    which reads the planes (the fp32 values are then filled on demand: ._lazy); fp32_out = ('conv', k) / ('convT', Co, k): the NEXT
+    layer's description -- the fp32 activation is skipped exactly when that layer's own predicates say it reads planes only
+    (consumer_reads_planes_only); planes_out False: nothing reads the planes"""
     Co, Ci, k, _ = W.shape
     Wp = ops._PermuteWeight.apply(W).reshape(Co, k * k * Ci)
     holder = []

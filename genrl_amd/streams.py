@@ -15,6 +15,37 @@ _side = {}
 _dirty = set()
 
 
+def _resolve_raw_stream():
+    """-> callable returning the raw hipStream_t of torch's current stream on the current device.  torch._C._cuda_getCurrentRawStream is
+    the C call behind torch.cuda.current_stream() (that wrapper costs ~8 us of host time per call and an eager iteration asks ~300 times);
+    it is a private name, so a torch build without it gets the public call instead (same handle, slower)."""
+    get_raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+    get_dev = getattr(torch._C, '_cuda_getDevice', None)
+    if callable(get_raw) and callable(get_dev):
+        try:
+            get_raw(get_dev())
+            return lambda: get_raw(get_dev())
+        except Exception:           # signature changed: fall through to the public API
+            pass
+    return lambda: torch.cuda.current_stream().cuda_stream
+
+
+_raw = None
+
+
+def raw_current_stream():
+    """raw handle of torch's current stream (no CPU fallback: raises without a GPU).  Availability is asked for on every call until it
+    holds (a device that appears later is noticed), the resolved getter is kept."""
+    global _raw
+    if _raw is None:
+        if not torch.cuda.is_available():
+            from ._lib import GenrlHipError
+            raise GenrlHipError('genrl_amd ops need an MI355X (torch.cuda unavailable); there is no CPU fallback')
+        torch.cuda.init()            # (the raw call skips torch.cuda's lazy initialisation)
+        _raw = _resolve_raw_stream()
+    return _raw()
+
+
 def _stream(name):
     dev = torch.cuda.current_device()
     key = (name, dev)

@@ -144,8 +144,9 @@ def _text_feature(agent, task_prompt):
         # the reference raises KeyError here (its prompt table is host-side data outside this path); an
         # integrator fills TASK2PROMPT from it.  Until then: the task name in words, said out loud.
         prompt = agent.cfg.task.replace('_', ' ')
-        _warn_once(f"TASK2PROMPT has no entry for task '{agent.cfg.task}': using '{prompt}' as the language target "
-                   "(fill genrl_amd.tools.genrl_utils.TASK2PROMPT from the reference's table, INTEGRATION.md)")
+        if not getattr(wm.viclip_model, 'ignores_text', False):      # (a stand-in embedder that returns a fixed vector has nothing to be warned about)
+            _warn_once(f"TASK2PROMPT has no entry for task '{agent.cfg.task}': using '{prompt}' as the language target "
+                       "(fill genrl_amd.tools.genrl_utils.TASK2PROMPT from the reference's table, INTEGRATION.md)")
     with torch.no_grad():
         return wm.viclip_model.get_txt_feat(prompt).to(agent.device).float()
 

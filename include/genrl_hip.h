@@ -150,6 +150,10 @@ int genrl_gemm_h2_subpixel(const uint16_t* img, long ld_img, long plane_img, con
  * dinv[0 .. Nimg (H + 2 pad)(W + 2 pad)) = sinv[0] (uniform scale).  ld % 8 == 0. */
 int genrl_pad_planes(const uint16_t* src, long splane, const float* sinv, uint16_t* dst, long dplane, float* dinv, int Nimg, int H, int W,
                      long ld, int pad, void* stream);
+/* fp32 values of h2 planes: y[r][c] = (h + l / 2^11) inv[r], rows x cols (cols % 4 == 0, y 16-byte aligned, ldy % 4 == 0).  Used when an
+ * inner convolution layer's channel-LayerNorm (agent/dreamer_utils.py:590-612, 686-706) wrote ONLY the planes of its output and a consumer
+ * off the plane path reads fp32 after all. */
+int genrl_planes_to_f32(const uint16_t* p, long ld, long plane, const float* inv, float* y, long ldy, long rows, int cols, void* stream);
 /* The rearranged weight of genrl_gemm_h2_subpixel as an fp32 matrix [4 Co][T T Ci] (+ the bias repeated per class, 4 Co floats, if
  * bias4 != NULL):  Wsub[(a, b, co)][(u, v, ci)] = w(ci, co, a + 2 (T - 1 - u), b + 2 (T - 1 - v)), zero where a tap index reaches k
  * (odd k: the kernel is treated as k + 1 with a zero last tap).  w(ci, co, kh, kw) = W[ci s_ci + co s_co + (kh k + kw) s_tap]:

@@ -87,6 +87,61 @@ def test_decoder_chain_on_planes(N, Hi, C0, C1, C2, k1, k2, inner_fp32):
     _check(hip, ref, [x, W1, b1, g1, e1, W2, b2, g2, e2], rtol=3e-4, atol=3e-4)
 
 
+@pytest.mark.parametrize('C1,subpixel', [(32, True), (96, True), (96, False)])
+def test_fp32_output_follows_the_consumers_predicate(C1, subpixel, monkeypatch):
+    """an inner layer skips its fp32 activation exactly when the NEXT layer's own predicates say it reads planes only --
+    not by position.  cnn_depth = 32 (C1 = 32 < 48: the next convolution cannot gather from planes) and GENRL_SUBPIXEL=0 (the next
+    transposed convolution with C < 512 input channels runs GEMM -> col2im on fp32 operands) keep the fp32 output; the default
+    shapes skip it and never fill it.  Values and every gradient against torch either way."""
+    from genrl_amd import ops_conv_planes as cp
+    monkeypatch.setattr(cp, 'SUBPIXEL', subpixel)
+    N, Hi, C0, C2 = 64, 31, 48, 64
+    x = torch.randn(N, Hi, Hi, C0, generator=g(1))
+    W1 = torch.randn(C1, C0, 4, 4, generator=g(2)) / (C0 * 16) ** .5; b1 = 0.1 * torch.randn(C1, generator=g(3))
+    W2 = torch.randn(C2, C1, 4, 4, generator=g(4)) / (C1 * 16) ** .5; b2 = 0.1 * torch.randn(C2, generator=g(5))
+    g1, e1 = 1 + 0.1 * torch.randn(C1, generator=g(6)), 0.1 * torch.randn(C1, generator=g(7))
+    g2, e2 = 1 + 0.1 * torch.randn(C2, generator=g(8)), 0.1 * torch.randn(C2, generator=g(9))
+    cells = {}
+
+    def ref(x, W1, b1, g1, e1, W2, b2, g2, e2):
+        y = _ln_silu(F.conv2d(x.permute(0, 3, 1, 2), W1, b1, stride=2).permute(0, 2, 3, 1), g1, e1)
+        return _ln_silu(F.conv2d(y.permute(0, 3, 1, 2), W2, b2, stride=2).permute(0, 2, 3, 1), g2, e2)
+
+    def hip(x, W1, b1, g1, e1, W2, b2, g2, e2):
+        xin = x * 1.0
+        xin._planes = cp._uniform_split(xin.detach().reshape(-1, C0))
+        y = cp.conv2d_s2(xin, W1, b1, (g1, e1, 1e-3), fp32_out=('conv', 4))
+        cells['enc'] = y._lazy
+        return cp.conv2d_s2(y, W2, b2, (g2, e2, 1e-3))
+    _check(hip, ref, [x, W1, b1, g1, e1, W2, b2, g2, e2], rtol=3e-4, atol=3e-4)
+    if C1 < 48:
+        assert cells['enc'] is None                      # the consumer reads fp32: written by the LayerNorm, no rebuild
+    else:
+        assert cells['enc'] == [True]                    # skipped and never needed (N H2 H2 = 64 * 36 rows: a multiple of 64)
+
+    # decoder: 5 x 5 x 192 -> 13 x 13 x 96 -> 30 x 30 x 48; the second layer takes the sub-pixel form unless it is switched off
+    Nd, Hd, D0, D1, D2, k1, k2 = 64, 5, 192, 96, 48, 5, 6
+    xd = torch.randn(Nd, Hd, Hd, D0, generator=g(11))
+    V1 = torch.randn(D0, D1, k1, k1, generator=g(12)) / (D0 * k1) ** .5; c1 = 0.1 * torch.randn(D1, generator=g(13))
+    V2 = torch.randn(D1, D2, k2, k2, generator=g(14)) / (D1 * k2) ** .5; c2 = 0.1 * torch.randn(D2, generator=g(15))
+    h1, f1 = 1 + 0.1 * torch.randn(D1, generator=g(16)), 0.1 * torch.randn(D1, generator=g(17))
+    h2, f2 = 1 + 0.1 * torch.randn(D2, generator=g(18)), 0.1 * torch.randn(D2, generator=g(19))
+
+    def dref(x, W1, b1, g1, e1, W2, b2, g2, e2):
+        y = _ln_silu(F.conv_transpose2d(x.permute(0, 3, 1, 2), W1, b1, stride=2).permute(0, 2, 3, 1), g1, e1)
+        return _ln_silu(F.conv_transpose2d(y.permute(0, 3, 1, 2), W2, b2, stride=2).permute(0, 2, 3, 1), g2, e2)
+
+    def dhip(x, W1, b1, g1, e1, W2, b2, g2, e2):
+        y = cp.convT2d_s2(x * 1.0, W1, b1, (g1, e1, 1e-3), fp32_out=('convT', D2, k2))
+        cells['dec'] = y._lazy
+        return cp.convT2d_s2(y, W2, b2, (g2, e2, 1e-3))
+    _check(dhip, dref, [xd, V1, c1, h1, f1, V2, c2, h2, f2], rtol=3e-4, atol=3e-4)
+    if subpixel:
+        assert cells['dec'] == [True]                    # sub-pixel gather forward, gathered weight gradient: fp32 never read
+    else:
+        assert cells['dec'] is None                      # GEMM -> col2im on fp32 operands: the LayerNorm wrote them
+
+
 def test_uniform_planes_of_the_channel_layernorm():
     """genrl_ln_act_fwd_h2u: one scale for the whole tensor, from the parameters alone; the planes reproduce the fp32 output to
     2^-22 of the scale's range; genrl_split_h2u: the exact-maximum variant"""

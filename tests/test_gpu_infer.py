@@ -21,6 +21,8 @@ B, T, A, S, K, NVID, SEED = [int(x) for x in G['meta']]
 
 
 class FakeClip:
+    ignores_text = True
+
     def get_txt_feat(self, text):
         g = torch.Generator().manual_seed(123)
         return torch.nn.functional.normalize(torch.randn(1, 512, generator=g), dim=-1)

@@ -22,6 +22,8 @@ B, T, A, H, SEED, STEPS, SLOW = 4, 16, 10, 16, 21, 3, 2
 
 
 class FakeClip:
+    ignores_text = True
+
     def get_txt_feat(self, text):
         g = torch.Generator().manual_seed(123)
         return torch.nn.functional.normalize(torch.randn(1, 512, generator=g), dim=-1)

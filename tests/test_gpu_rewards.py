@@ -18,6 +18,8 @@ CASES = [(s, m, w) for s in SCORES for m in ('none', 'initial', 'sequence') for 
 
 
 class FakeClip:
+    ignores_text = True
+
     def get_txt_feat(self, text):
         g = torch.Generator().manual_seed(123)
         return torch.nn.functional.normalize(torch.randn(1, 512, generator=g), dim=-1)
