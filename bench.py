@@ -559,7 +559,7 @@ def main():
                'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
                'dtype': ('f32' if (ops.F32_MODE == 'f32' and not planes.ENABLED) else
                          'f32 (storage, accumulation, every non-GEMM kernel and the fp32-MFMA GEMMs; the forward / dgrad / weight-gradient '
-                         'products of the imagination rollout, of the Dense+LN+SiLU chains from 320 rows up and of the encoder / decoder '
+                         'products of the imagination rollout, of the Dense+LN+SiLU chains from 192 rows up and of the encoder / decoder '
                          'convolutions take fp32 operands pre-split into two fp16 planes of the scaled value (22 mantissa bits + fp32 '
                          'accumulation of 3 fp16-MFMA products), any remaining 128x128-tile GEMM splits each fp32 operand exactly into 3 bf16 '
                          'terms in registers (6 bf16-MFMA products).  Error vs float64: same order as the fp32 MFMAs\' -- measured 0.4-2x theirs for '
@@ -581,10 +581,19 @@ def main():
                           'eager_leg': eager_detail},
                'algorithmic_gflop_per_step': fl['total'], 'executed_gflop_per_step': fl['executed'],
                # priced on the work this build EXECUTES (SURVEY's algorithmic count includes the policy's entropy re-evaluation,
-               # 421 GF at c2, which contributes nothing with actor_ent = 0 and is not run here); the algorithmic figure beside it
-               'step_roofline': {'bound': 'mfma', 'achieved': fl['executed'] * sps / 1e3 / world, 'peak': PEAK_F32_MFMA_TFLOPS,
-                                 'unit': 'TFLOP/s', 'frac': fl['executed'] * sps / 1e3 / world / PEAK_F32_MFMA_TFLOPS,
-                                 'on': 'executed GF per step', 'frac_on_algorithmic_gflop': fl['total'] * sps / 1e3 / world / PEAK_F32_MFMA_TFLOPS},
+               # 421 GF at c2, which contributes nothing with actor_ent = 0 and is not run here) and against the pipe that executes it:
+               # with plane operands ~93 % of the FLOPs run as 3 fp16-MFMA products per fp32 product on the 16-bit pipe (2.5 PFLOP/s dense),
+               # so `frac` = 3 x executed GF / step time / 2.5 PF (an upper bound on the 16-bit work: the fp32-MFMA remainder counts 3 x too);
+               # with fp32 MFMAs throughout it is executed GF / step time / 157.3 TF.  The fp32-EQUIVALENT rate stands beside it as a rate
+               # only (it exceeds the fp32 MFMA peak by construction and is not a roofline fraction).
+               'step_roofline': (lambda eq, on16: {
+                   'bound': 'mfma', 'unit': 'TFLOP/s', 'on': 'executed GF per step',
+                   'pipe': 'fp16 MFMA (3 products per fp32 product)' if on16 else 'fp32 MFMA',
+                   'achieved': (3.0 if on16 else 1.0) * eq, 'peak': PEAK_BF16_MFMA_TFLOPS if on16 else PEAK_F32_MFMA_TFLOPS,
+                   'frac': (3.0 if on16 else 1.0) * eq / (PEAK_BF16_MFMA_TFLOPS if on16 else PEAK_F32_MFMA_TFLOPS),
+                   'fp32_equivalent_TFLOPs': eq, 'fp32_equivalent_on_algorithmic_gflop_TFLOPs': fl['total'] * sps / 1e3 / world,
+                   'fp32_mfma_peak_TFLOPs_for_scale': PEAK_F32_MFMA_TFLOPS})(
+                       fl['executed'] * sps / 1e3 / world, bool(planes.ENABLED and args.precision == 32)),
                'final_model_loss': loss, 'final_loss_key': loss_key, 'fp32_mfma_mode': fp32_mode}
 
     # ---- data parallel over RCCL: now that a line is measured in the safe mode, try the collectives INSIDE the graph (the connector's side
@@ -715,6 +724,34 @@ def main():
             else:
                 d.update(achieved=eq, peak=PEAK_BF16_MFMA_TFLOPS, unit='TFLOP/s', frac=eq / PEAK_BF16_MFMA_TFLOPS,
                          kernel='sgemm_rr_kernel<BF=1>: bf16-rounded operands (precision 16)')
+        # kernel families of the profiled launches (the library's tile choice: 64x64 plane tiles below 2048 64-tiles, 128x128 from there)
+        def family_of(p_):
+            tag = p_[5]
+            if tag.endswith('/pipe4'):
+                if 'h2tn' in tag:
+                    return 'gemm_planes_tn_kernel (weight gradients, 128x128)'
+                if 'conv' in tag or 'subpixel' in tag:
+                    return 'gemm_planes_hl(w)_kernel<CONV> (patch-gathering 128-wide tiles)'
+                t64 = -(-p_[0] // 64) * -(-p_[1] // 64)
+                return 'gemm_planes_kernel 64x64 tile' if t64 < 2048 else 'gemm_planes_hl_kernel 128x128 tile'
+            return {'bf16_split': 'sgemm_rr_kernel<BF=3>', 'bf16': 'sgemm_rr_kernel<BF=1>'}.get(pipe_of(tag), 'fp32-MFMA kernels (sgemm_rr / tall / direct 3-channel)')
+        fams = {}
+        for p_ in prof:
+            d = fams.setdefault(family_of(p_), dict(launches=0, ms=0.0, flop=0.0, pipe=pipe_of(p_[5])))
+            d['launches'] += 1; d['ms'] += p_[3].elapsed_time(p_[4]); d['flop'] += 2.0 * p_[0] * p_[1] * p_[2]
+        dk = max(fams, key=lambda k_: fams[k_]['ms'])
+        mult = {'fp16_split': 3.0, 'bf16_split': 6.0}.get(fams[dk]['pipe'], 1.0)
+        pk = PEAK_F32_MFMA_TFLOPS if fams[dk]['pipe'] == 'fp32_mfma' else PEAK_BF16_MFMA_TFLOPS
+        dominant_kernel = {'name': dk, 'launches': fams[dk]['launches'], 'ms_per_step': fams[dk]['ms'],
+                           'avg_launch_us': 1e3 * fams[dk]['ms'] / fams[dk]['launches'],
+                           'achieved': mult * fams[dk]['flop'] / (fams[dk]['ms'] * 1e-3) / 1e12, 'peak': pk, 'unit': 'TFLOP/s (MFMA work executed)',
+                           'frac': mult * fams[dk]['flop'] / (fams[dk]['ms'] * 1e-3) / 1e12 / pk,
+                           'families': {k_: {'launches': v['launches'], 'ms_per_step': v['ms'],
+                                             'frac': ({'fp16_split': 3.0, 'bf16_split': 6.0}.get(v['pipe'], 1.0) * v['flop'] / (v['ms'] * 1e-3) / 1e12
+                                                      / (PEAK_F32_MFMA_TFLOPS if v['pipe'] == 'fp32_mfma' else PEAK_BF16_MFMA_TFLOPS))}
+                                        for k_, v in fams.items()},
+                           'note': 'HIP-event time of one single-stream eager step (includes launch gaps; NOT under rocprofv3, whose per-kernel '
+                                   'durations in profiles/*kernel_table* run ~15 % higher than untraced)'}
         tot_ms = sum(d['ms_per_step'] for d in pipes.values())
         tot_fl = sum(d['gflop_per_step'] for d in pipes.values()) * 1e9
         dom = max(pipes, key=lambda k_: pipes[k_]['ms_per_step'])      # the pipe with the most kernel time leads the line
@@ -745,9 +782,14 @@ def main():
                            # per kernel family: measured HBM-side read / write bytes per launch (PMC passes above) next to the UNIQUE bytes of
                            # its operands (A + B + C as they lie in memory: the image of a gathered operand, not its expanded patch matrix)
                            'per_kernel': per_kernel,
-                           'all_gemm_fp32_equivalent': {'achieved': tot_fl / (tot_ms * 1e-3) / 1e12, 'peak': 157.3,
-                                                        'frac': tot_fl / (tot_ms * 1e-3) / 1e12 / 157.3,
-                                                        'note': '2MNK of every MFMA GEMM launch / HIP-event time, both pipes'},
+                           # all MFMA GEMM launches of the step as RATES (no fraction: the fp32-equivalent rate of the split-operand
+                           # kernels exceeds the fp32 MFMA peak by construction); the fractions are per pipe above and in dominant_kernel
+                           'all_gemm': {'fp32_equivalent_TFLOPs': tot_fl / (tot_ms * 1e-3) / 1e12,
+                                        'executed_mfma_TFLOPs': sum(d['achieved'] * d['ms_per_step'] for d in pipes.values()) / tot_ms,
+                                        'matrix_pipe_time_at_peak_over_gemm_time': sum(d['frac'] * d['ms_per_step'] for d in pipes.values()) / tot_ms,
+                                        'note': '2MNK (fp32-equivalent) and executed MFMA work (3x / 6x for the split-operand kernels) of every '
+                                                'MFMA GEMM launch / HIP-event time; the last field is the time-weighted mean of the per-pipe fractions (<= 1)'},
+                           'dominant_kernel': dominant_kernel,
                            'method': 'HIP events (torch.cuda.Event on the launch stream) around every GEMM launch of one extra '
                                      'single-stream eager step; the rocprofv3 summary of the same command is under profiles/',
                            'launches_per_step': len(prof), 'avg_launch_us': 1e3 * tot_ms / max(len(prof), 1),

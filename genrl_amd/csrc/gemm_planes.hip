@@ -84,6 +84,26 @@ struct ConvGather {
   int sHo, sWo, sCo;
 };
 
+// Optional epilogue of the 64x64 h2 kernel (LNE instantiation): the LayerNorm (+ SiLU) that follows the product in every Dense -> LayerNorm ->
+// SiLU layer of the path (agent/dreamer_utils.py:718-747 MLP, :459-473 img_step), in the SAME launch.  A LayerNorm row spans all N / 64
+// column tiles of its 64-row block, so the tiles exchange per-row partial statistics -- but only with each other: the launch places all
+// column tiles of a row block on ONE XCD (workgroup b runs on XCD b % 8; row block = 8 (i / tiles_n) + b % 8, column tile = i % tiles_n with
+// i = b / 8) and the exchange goes through that XCD's L2 behind a barrier of tiles_n workgroups: plain stores, s_waitcnt vmcnt(0), one
+// atomic add, a poll with L2-served (sc1) loads, sc1 loads of the peers' records -- no fence, no cache write-back / invalidate, nothing
+// crosses the fabric (scripts/micro/xcd_barrier.hip, profiles/r06_xcd_barrier.txt: 0.71 us for 16 workgroups against 3.9 us chip-wide).
+// Every workgroup then normalises its own tile from registers and writes y as fp32 (optional) and as h2 planes with ONE scale for the
+// whole tensor, known from gamma / beta alone (|gamma x^ + beta| <= max|gamma| sqrt(N) + max|beta|, |SiLU z| <= |z|: no second exchange
+// for a row maximum; fp16 is a floating-point format, so elements down to 2^-25 of the bound keep all 22 bits).
+struct LnEpi {
+  const float* gamma; const float* beta;     // [N]; 16-byte aligned
+  float eps; int act;                        // act: 1 = SiLU
+  float* y; long ldy;                        // fp32 output rows (may be null: planes only)
+  u16* yp; long yld, yplane; float* yinv;    // h2 planes of y (+ per-row inverse scale: the same value in every row)
+  float* mean; float* rstd;                  // [M] row statistics (for the backward)
+  float* part;                               // exchange slab: [row blocks][tiles_n][64][2] floats
+  unsigned* sync;                            // word 0: failure flag; row block rb: arrive counter at word 32 (1 + 2 rb), exit counter at 32 (2 + 2 rb)
+};
+
 // a / b for exact powers of two (exponent arithmetic; clamped to the normal range)
 __device__ __forceinline__ float pow2_ratio(float a, float b) {
   const int ea = (int)((__builtin_bit_cast(unsigned, a) >> 23) & 255u), eb = (int)((__builtin_bit_cast(unsigned, b) >> 23) & 255u);
@@ -103,12 +123,13 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 
 // TM x TN 32x32 blocks per wave (2x2 waves per workgroup); BK = 64 (TM*TN == 1) or 32; NACC class accumulators;
 // FMT 0: x3 (three bf16 planes, six products), 1: h2 (two fp16 planes of the row-scaled value, three products); NS LDS stages
-template <int TM, int TN, int BK, int NACC, int FMT, int NS, bool FOLD = true, bool CONV = false, int PF = 0>
+template <int TM, int TN, int BK, int NACC, int FMT, int NS, bool FOLD = true, bool CONV = false, int PF = 0, bool LNE = false>
 // (TM TN == 1 with a ring of TWO stages: 64.75 KiB of LDS and <= 256 registers -- two workgroups per CU, for launches of 257 .. 512
 // tiles, whose second round would otherwise wait for the first one's epilogues)
 __global__ __launch_bounds__(256, (TM * TN == 1 && NS == 2 && FMT == 1) ? 2 : 1) void gemm_planes_kernel(PlaneSeg s0, PlaneSeg s1, float* __restrict__ C, long ldc,
                                                          const float* __restrict__ bias, int M, int N, int accumulate,
-                                                         int tiles_m, int tiles_n, int xcd_m, SampleEpi smp, ConvGather cg) {
+                                                         int tiles_m, int tiles_n, int xcd_m, SampleEpi smp, ConvGather cg, LnEpi ln) {
+  static_assert(!LNE || (TM * TN == 1 && FMT == 1 && !CONV && PF == 0), "LayerNorm epilogue: 64x64 h2 tile");
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int NPL = FMT ? 2 : 3, NPROD = FMT ? 3 : 6;
   constexpr int ROWB = BK * 2;                         // bytes per tile row per plane
@@ -131,7 +152,10 @@ __global__ __launch_bounds__(256, (TM * TN == 1 && NS == 2 && FMT == 1) ? 2 : 1)
   // BEFORE the first stage (older than every stage DMA: the counted waits and the first barrier cover them), instead of as global
   // loads behind the last MFMA, where their latency was exposed once per workgroup
   constexpr int EPI = FMT == 1 ? 4 * (BM + 2 * BN) : 0, EPI_AT = NS * STAGE + (PF ? 1024 : 0);
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[EPI_AT + EPI];
+  // LNE: gamma / beta of all N <= 1024 columns (2 x 4 KiB), the exchange records of the row block (8 KiB), row statistics, reduction scratch
+  constexpr int LN_AT = EPI_AT + EPI, LN_G = LN_AT, LN_B = LN_AT + 4096, LN_X = LN_AT + 8192, LN_S = LN_AT + 16384, LN_R = LN_AT + 16896,
+                LN_U = LN_AT + 17920, LN_BYTES = LNE ? 18432 : 0;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[EPI_AT + EPI + LN_BYTES];
 #if PLANES_ABL == 6       /* ablation 6 (scripts/intercept64.py): the launch alone -- same grid, LDS and register footprint, no work */
   if (M > 0) { if (threadIdx.x == 1023) lds[0] = 0; return; }
 #endif
@@ -141,7 +165,10 @@ __global__ __launch_bounds__(256, (TM * TN == 1 && NS == 2 && FMT == 1) ? 2 : 1)
   {
     const int ntiles = tiles_m * tiles_n;
     const int x = bid % 8, i = bid / 8;
-    if (xcd_m > 0) {
+    if constexpr (LNE) {                  // all column tiles of a row block on one XCD (see LnEpi)
+      tile_n = i % tiles_n; tile_m = (i / tiles_n) * 8 + x;
+      if (tile_m >= tiles_m) return;      // (a whole group: nobody waits for it)
+    } else if (xcd_m > 0) {
       const int sub_m = tiles_m / xcd_m, sub_n = tiles_n / (8 / xcd_m);
       const int xm = x / (8 / xcd_m), xn = x % (8 / xcd_m);
       tile_m = xm * sub_m + i / sub_n;
@@ -291,6 +318,13 @@ __global__ __launch_bounds__(256, (TM * TN == 1 && NS == 2 && FMT == 1) ? 2 : 1)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + min(base + 64 * j + lane, lim)),
                                            (__attribute__((address_space(3))) void*)(uintptr_t)(dst + 256 * j), 4, 0, 0);
     }
+  }
+  if constexpr (LNE) {       // gamma / beta of ALL columns (scale bound + this tile's slice), 1 KiB per wave-instruction, ahead of the stages
+    const int f0 = min(256 * wave + 4 * lane, N - 4);                 // (N % 64 == 0, N <= 1024; beyond N: a valid duplicate, never read)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ln.gamma + f0),
+                                     (__attribute__((address_space(3))) void*)(uintptr_t)(lds0 + LN_G + 1024 * wave), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ln.beta + f0),
+                                     (__attribute__((address_space(3))) void*)(uintptr_t)(lds0 + LN_B + 1024 * wave), 16, 0, 0);
   }
   const int nk0 = s0.k / BK, nk = nk0 + s1.k / BK;
   static_assert(NPA == NPB, "square wave grids only (one DMA count per wave)");
@@ -458,6 +492,157 @@ __global__ __launch_bounds__(256, (TM * TN == 1 && NS == 2 && FMT == 1) ? 2 : 1)
   wait_vm<0>();
 #endif
 
+  if constexpr (LNE) {
+    // ---- LayerNorm (+ SiLU) epilogue (see LnEpi).  Lane (l32, h32) of wave (wm, wn) holds row wm 32 + l32, columns wn 32 + 8 gq + 4 h32 + v.
+    typedef __attribute__((address_space(1))) unsigned gu32_;
+    auto ldsf = [&](int byte_off) __attribute__((always_inline)) -> float {
+      return *reinterpret_cast<const __attribute__((address_space(3))) float*>((uintptr_t)(lds0 + byte_off));
+    };
+    auto ldsw = [&](int byte_off, float v) __attribute__((always_inline)) {
+      *reinterpret_cast<__attribute__((address_space(3))) float*>((uintptr_t)(lds0 + byte_off)) = v;
+    };
+    auto ldsf4 = [&](int byte_off) __attribute__((always_inline)) -> f32x4 {
+      return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((uintptr_t)(lds0 + byte_off));
+    };
+    const int rl = wm * 32 + l32, row = m0 + rl;
+    const float ra = ainv_l ? ldsf(EPI_AT + 4 * rl) : 1.f;
+    float o[16];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int ci = wn * 32 + 8 * gq + 4 * h32;
+      f32x4 cb = {1.f, 1.f, 1.f, 1.f}, bs = {0.f, 0.f, 0.f, 0.f};
+      if (binv_l) cb = ldsf4(EPI_AT + 4 * (BM + ci));
+      if (bias) bs = ldsf4(EPI_AT + 4 * (BM + BN + ci));
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float lo = acc[0][0][0][4 * gq + v] + acc[2][0][0][4 * gq + v];
+        o[4 * gq + v] = (lo * (1.f / 2048.f) + acc[1][0][0][4 * gq + v]) * ra * cb[v] + bs[v];
+      }
+    }
+    // statistics of this tile's 64 columns per row: mean, then the centred sum of squares (two-pass, as the row kernels do)
+    float sm = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) sm += o[v];
+    sm += __shfl_xor(sm, 32, 64);
+    if (h32 == 0) ldsw(LN_R + 4 * (wave * 32 + l32), sm);
+    __syncthreads();
+    const float mean_t = (ldsf(LN_R + 4 * (wm * 64 + l32)) + ldsf(LN_R + 4 * (wm * 64 + 32 + l32))) * (1.f / 64.f);
+    float sq = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { const float d = o[v] - mean_t; sq += d * d; }
+    sq += __shfl_xor(sq, 32, 64);
+    if (h32 == 0) ldsw(LN_R + 512 + 4 * (wave * 32 + l32), sq);
+    __syncthreads();
+    float* const part_rb = ln.part + (long)tile_m * tiles_n * 128;
+    if (wn == 0 && h32 == 0) {
+      const float m2 = ldsf(LN_R + 512 + 4 * (wm * 64 + l32)) + ldsf(LN_R + 512 + 4 * (wm * 64 + 32 + l32));
+      *reinterpret_cast<h2_f32x2*>(part_rb + (tile_n * 64 + rl) * 2) = h2_f32x2{mean_t, m2};
+    }
+    wait_vm<0>();                       // the record has reached the L2 (and the ring's trailing DMAs have landed)
+    __syncthreads();
+    gu32_* const arrive = (gu32_*)(ln.sync + 32 * (1 + 2 * tile_m));
+    gu32_* const leave = (gu32_*)(ln.sync + 32 * (2 + 2 * tile_m));
+    gu32_* const failw = (gu32_*)ln.sync;
+    if (tid == 0) asm volatile("global_atomic_add %0, %1, off" ::"v"(arrive), "v"(1u) : "memory");
+    // (while the peers arrive) the pre-activation for the backward, and the scale bound from gamma / beta of all N columns
+    if (row < M) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int col = n0 + wn * 32 + 8 * gq + 4 * h32;
+        *reinterpret_cast<float4*>(C + (long)row * ldc + col) = make_float4(o[4 * gq], o[4 * gq + 1], o[4 * gq + 2], o[4 * gq + 3]);
+      }
+    }
+    {
+      float gm = 0.f, bm = 0.f;
+      if (4 * tid < N) {
+        const f32x4 g = ldsf4(LN_G + 16 * tid), b = ldsf4(LN_B + 16 * tid);
+        gm = fmaxf(fmaxf(fabsf(g[0]), fabsf(g[1])), fmaxf(fabsf(g[2]), fabsf(g[3])));
+        bm = fmaxf(fmaxf(fabsf(b[0]), fabsf(b[1])), fmaxf(fabsf(b[2]), fabsf(b[3])));
+      }
+      gm = wave_max(gm); bm = wave_max(bm);
+      if (lane == 0) { ldsw(LN_U + 8 * wave, gm); ldsw(LN_U + 8 * wave + 4, bm); }
+    }
+    if (tid == 0) {                     // bounded poll (L2-served loads); a timeout or a misplaced workgroup raises the failure word
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      bool ok = (xcc & 7u) == (unsigned)(blockIdx.x & 7);
+      if (ok) {
+        ok = false;
+        for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+          if (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)tiles_n) { ok = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      if (!ok) __hip_atomic_store(failw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    // the row block's records -> LDS (sc1 loads: served by the L2, the L1 is never consulted)
+    {
+      const int nq = tiles_n * 32;      // float4 records' quads: tiles_n x 64 rows x 2 floats / 4
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+      const float* p0 = part_rb + 4 * min(tid, nq - 1);
+      const float* p1 = part_rb + 4 * min(tid + 256, nq - 1);
+      asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                   : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
+      *reinterpret_cast<__attribute__((address_space(3))) f32x4*>((uintptr_t)(lds0 + LN_X + 16 * tid)) = v0;
+      *reinterpret_cast<__attribute__((address_space(3))) f32x4*>((uintptr_t)(lds0 + LN_X + 16 * (tid + 256))) = v1;
+    }
+    __syncthreads();
+    const float u_inv = h2_inv_of(fmaxf(fmaxf(ldsf(LN_U), ldsf(LN_U + 8)), fmaxf(ldsf(LN_U + 16), ldsf(LN_U + 24))) * sqrtf((float)N) +
+                                  fmaxf(fmaxf(ldsf(LN_U + 4), ldsf(LN_U + 12)), fmaxf(ldsf(LN_U + 20), ldsf(LN_U + 28))));
+    const float u_sc = h2_scale_of(u_inv);
+    if (tid < 64) {                     // Chan's combination of the tiles' (mean, M2) in tile order: the same result in every workgroup
+      float cnt = 0.f, mu = 0.f, m2 = 0.f;
+      for (int j = 0; j < tiles_n; ++j) {
+        const float mb = ldsf(LN_X + 8 * (j * 64 + tid)), qb = ldsf(LN_X + 8 * (j * 64 + tid) + 4);
+        const float tot = cnt + 64.f, d = mb - mu;
+        mu += d * (64.f / tot);
+        m2 += qb + d * d * (cnt * 64.f / tot);
+        cnt = tot;
+      }
+      const float rs = 1.0f / sqrtf(m2 / (float)N + ln.eps);
+      ldsw(LN_S + 8 * tid, mu); ldsw(LN_S + 8 * tid + 4, rs);
+      if (tile_n == 0 && m0 + tid < M) {
+        if (ln.mean) ln.mean[m0 + tid] = mu;
+        if (ln.rstd) ln.rstd[m0 + tid] = rs;
+        if (ln.yinv) ln.yinv[m0 + tid] = u_inv;
+      }
+    }
+    __syncthreads();
+    const float mu = ldsf(LN_S + 8 * rl), rs = ldsf(LN_S + 8 * rl + 4);
+    if (row < M) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int col = n0 + wn * 32 + 8 * gq + 4 * h32;
+        const f32x4 g = ldsf4(LN_G + 4 * col), b = ldsf4(LN_B + 4 * col);
+        float y[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const float z = (o[4 * gq + v] - mu) * rs * g[v] + b[v];
+          y[v] = ln.act ? siluf_(z) : z;
+        }
+        if (ln.y) *reinterpret_cast<float4*>(ln.y + (long)row * ln.ldy + col) = make_float4(y[0], y[1], y[2], y[3]);
+        if (ln.yp) {
+          h2_u32x2 hh, ll;
+          unsigned a, bq;
+          h2_split2(y[0] * u_sc, y[1] * u_sc, a, bq); hh[0] = a; ll[0] = bq;
+          h2_split2(y[2] * u_sc, y[3] * u_sc, a, bq); hh[1] = a; ll[1] = bq;
+          u16* qd = ln.yp + (long)row * ln.yld + col;
+          *reinterpret_cast<h2_u32x2*>(qd) = hh;
+          *reinterpret_cast<h2_u32x2*>(qd + ln.yplane) = ll;
+        }
+      }
+    }
+    // the group's last workgroup to leave re-arms the counters for the next launch on this workspace (every member has passed its poll by then)
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(leave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old + 1 == (unsigned)tiles_n) {
+        __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(leave, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return;
+  }
   // ---- epilogue: lane (l32, h32), register v of block (i, j) = C[m = l32][n = 8 (v/4) + 4 h32 + v%4]
   const float* ainv = ainv_l;
   const float* binv = binv_l;
@@ -1487,12 +1672,12 @@ int genrl_gemm_x3(const uint16_t* a0, long a0_ld, long a0_plane, const uint16_t*
     const int tm = cdiv(M, 128), tn = cdiv(N, 128);
     log_launch("x3/128", M, N, k0 + k1, 6.0 * ((double)M + N) * (k0 + k1) + 4.0 * M * N);
     gemm_planes_kernel<2, 2, 32, 1, 0, 3><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, s1, C, ldc, bias, M, N, accumulate, tm, tn,
-                                                                                xcd_split(tm, tn), SampleEpi{}, ConvGather{});
+                                                                                xcd_split(tm, tn), SampleEpi{}, ConvGather{}, LnEpi{});
   } else {
     const int tm = cdiv(M, 64), tn = cdiv(N, 64);
     log_launch("x3/64", M, N, k0 + k1, 6.0 * ((double)M + N) * (k0 + k1) + 4.0 * M * N);
     gemm_planes_kernel<1, 1, 64, 3, 0, 3><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, s1, C, ldc, bias, M, N, accumulate, tm, tn,
-                                                                                xcd_split(tm, tn), SampleEpi{}, ConvGather{});
+                                                                                xcd_split(tm, tn), SampleEpi{}, ConvGather{}, LnEpi{});
   }
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
@@ -1596,14 +1781,14 @@ static int gemm_h2_impl(const uint16_t* a0, long a0_ld, long a0_plane, const flo
       log_launch("h2/128", M, N, sg.k, kk_bytes(M, N, sg.k));
       if (bk32)
         gemm_planes_kernel<2, 2, 32, 2, 1, 4, false><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
-                                                                                           xcd_split(tm, tn), SampleEpi{}, ConvGather{});
+                                                                                           xcd_split(tm, tn), SampleEpi{}, ConvGather{}, LnEpi{});
 #ifdef PLANES_EXPERIMENTS
       else if (g_planes_variant == 1 || g_planes_variant == 6)
         gemm_planes_kernel<2, 2, 64, 2, 1, 2, false, false, 2><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
-                                                                                           xcd_split(tm, tn), SampleEpi{}, ConvGather{});
+                                                                                           xcd_split(tm, tn), SampleEpi{}, ConvGather{}, LnEpi{});
       else if (g_planes_variant == 2 || g_planes_variant == 3)
         gemm_planes_kernel<2, 2, 64, 2, 1, 2, false, false, 4><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
-                                                                                           xcd_split(tm, tn), SampleEpi{}, ConvGather{});
+                                                                                           xcd_split(tm, tn), SampleEpi{}, ConvGather{}, LnEpi{});
 #endif
       else if (hl_on() && use_wide(N)) {
         const int tw = cdiv(N, 192);
@@ -1612,7 +1797,7 @@ static int gemm_h2_impl(const uint16_t* a0, long a0_ld, long a0_plane, const flo
         gemm_planes_hl_kernel<false><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, C, ldc, bs, M, N, acc, tm, tn, xcd_split(tm, tn) | (hl_order() << 8), ConvGather{});
       else
         gemm_planes_kernel<2, 2, 64, 2, 1, 2, false><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
-                                                                                           xcd_split(tm, tn), SampleEpi{}, ConvGather{});
+                                                                                           xcd_split(tm, tn), SampleEpi{}, ConvGather{}, LnEpi{});
       GENRL_CHECK_LAUNCH();
     }
   } else {
@@ -1621,7 +1806,7 @@ static int gemm_h2_impl(const uint16_t* a0, long a0_ld, long a0_plane, const flo
     // taken, the other streams' small kernels (32 KiB weight-streaming workgroups) cannot share a CU with this one
     log_launch("h2/64", M, N, k0 + k1, kk_bytes(M, N, k0 + k1));
 #define L64(NS_, PF_) gemm_planes_kernel<1, 1, 64, 3, 1, NS_, true, false, PF_><<<tm * tn, 256, 0, (hipStream_t)stream>>>( \
-    s0, s1, C, ldc, bias, M, N, accumulate, tm, tn, xcd_split(tm, tn), smp, ConvGather{})
+    s0, s1, C, ldc, bias, M, N, accumulate, tm, tn, xcd_split(tm, tn), smp, ConvGather{}, LnEpi{})
 #ifdef PLANES_EXPERIMENTS      /* ring depth / L2 prefetch variants for scripts/cold_bench.py (hipcc -DPLANES_EXPERIMENTS) */
     switch (g_planes_variant) {
       case 1: L64(3, 3); break;
@@ -1682,7 +1867,7 @@ int genrl_gemm_h2_conv(const uint16_t* img, long ld_img, long plane_img, const f
   else
     gemm_planes_kernel<2, 2, 64, 2, 1, 2, false, true><<<tm * tn, 256, 0, (hipStream_t)stream>>>(s0, none, C, ldc, bias, M, N, accumulate, tm, tn,
                                                                                              xcd_split(tm, tn), SampleEpi{},
-                                                                                             ConvGather{H, W, Cc, k, Ho, Wo, K, 2, 0, 0, 0});
+                                                                                             ConvGather{H, W, Cc, k, Ho, Wo, K, 2, 0, 0, 0}, LnEpi{});
   GENRL_CHECK_LAUNCH();
   return GENRL_OK;
 }
@@ -1728,6 +1913,47 @@ int genrl_gemm_h2(const uint16_t* a0, long a0_ld, long a0_plane, const float* a0
                   float* C, long ldc, const float* bias, int M, int N, int accumulate, void* stream) {
   return gemm_h2_impl(a0, a0_ld, a0_plane, a0_inv, b0, b0_ld, b0_plane, b0_inv, k0, a1, a1_ld, a1_plane, a1_inv, b1, b1_ld, b1_plane,
                       b1_inv, k1, C, ldc, bias, M, N, accumulate, stream, SampleEpi{});
+}
+
+/* Dense -> LayerNorm (-> SiLU) in ONE launch (LnEpi above): C = A0 B0^T (+ A1 B1^T) + bias as genrl_gemm_h2 (C keeps the pre-activation for the
+ * backward), then y = act(LayerNorm(C) gamma + beta) written as fp32 rows (y may be NULL) and as h2 planes with one scale for the tensor
+ * (yinv[row] the same in every row), mean / rstd [M].  The N / 64 column tiles of a 64-row block exchange their partial row statistics
+ * inside ONE XCD's L2 behind a barrier of N / 64 workgroups.  Shapes: N % 64 == 0, N <= 1024, cdiv(M, 64) <= 8 (32 / (N / 64)) (every workgroup
+ * of the launch resident at once, one per CU: genrl_gemm_h2_ln_ok); gamma / beta / C / y 16-byte aligned, ldc / ldy / yld % 4 == 0.
+ * part: genrl_gemm_h2_ln_part_floats(M, N) floats of scratch; sync: genrl_gemm_h2_ln_sync_words() uint32 words, ZEROED ONCE by the caller and
+ * then owned by launches of ONE stream at a time (the counters re-arm themselves; two launches sharing them concurrently, or two such launches
+ * running concurrently on different streams at all -- each waits for workgroups the other keeps off the CUs -- are the caller's to avoid).
+ * sync[0] != 0 afterwards: a barrier timed out or the workgroup placement was not b % 8 (results invalid). */
+int genrl_gemm_h2_ln_ok(int M, int N) {
+  if (M <= 0 || N <= 0 || (N & 63) || N > 1024) return 0;
+  static int cus = -1;
+  if (cus < 0) { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0; cus = v; }
+  if (cus < 256) return 0;
+  const int tn = N / 64, tm = cdiv(M, 64);
+  return tm <= 8 * (32 / tn) ? 1 : 0;
+}
+long genrl_gemm_h2_ln_part_floats(int M, int N) { return (long)cdiv(M, 64) * (N / 64) * 128; }
+long genrl_gemm_h2_ln_sync_words(void) { return 32L * (2 + 2 * 256); }
+int genrl_gemm_h2_ln(const uint16_t* a0, long a0_ld, long a0_plane, const float* a0_inv, const uint16_t* b0, long b0_ld, long b0_plane,
+                     const float* b0_inv, int k0, const uint16_t* a1, long a1_ld, long a1_plane, const float* a1_inv,
+                     const uint16_t* b1, long b1_ld, long b1_plane, const float* b1_inv, int k1,
+                     float* C, long ldc, const float* bias, int M, int N, const float* gamma, const float* beta, float eps, int act,
+                     float* y, long ldy, float* mean, float* rstd, uint16_t* yp, long yld, long yplane, float* yinv,
+                     float* part, unsigned* sync, void* stream) {
+  GENRL_ENTER();
+  if (!genrl_gemm_h2_ln_ok(M, N) || k0 <= 0 || (k0 & 63) || (k1 & 63) || k1 < 0 || !gamma || !beta || !part || !sync || !C) return GENRL_EINVAL;
+  if ((a0_ld & 7) || (b0_ld & 7) || (k1 && ((a1_ld & 7) || (b1_ld & 7))) || (ldc & 3) || (y && (ldy & 3)) || (yp && ((yld & 3) || !yinv))) return GENRL_EINVAL;
+  if (((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
+        reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(part)) & 15) != 0 || (reinterpret_cast<uintptr_t>(yp) & 7) != 0)
+    return GENRL_EINVAL;
+  PlaneSeg s0{a0, a0_ld, a0_plane, b0, b0_ld, b0_plane, k0, a0_inv, b0_inv}, s1{a1, a1_ld, a1_plane, b1, b1_ld, b1_plane, k1, a1_inv, b1_inv};
+  const int tm = cdiv(M, 64), tn = N / 64;
+  const LnEpi ln{gamma, beta, eps, act, y, ldy, yp, yld, yplane, yinv, mean, rstd, part, sync};
+  log_launch("h2/64ln", M, N, k0 + k1, kk_bytes(M, N, k0 + k1));
+  gemm_planes_kernel<1, 1, 64, 3, 1, 3, true, false, 0, true><<<8 * cdiv(tm, 8) * tn, 256, 0, (hipStream_t)stream>>>(
+      s0, s1, C, ldc, bias, M, N, 0, tm, tn, 0, SampleEpi{}, ConvGather{}, ln);
+  GENRL_CHECK_LAUNCH();
+  return GENRL_OK;
 }
 
 /* One-segment product whose output rows are the logits of N / 32 categorical latents of 32 classes each (the RSSM's prior head,

@@ -250,6 +250,76 @@ def gemm(A, B, C, ldc, bias, M, N, accumulate=False, a_row0=0, A1=None, B1=None,
         gemm_profile.append((M, N, A.cols + (A1.cols if A1 is not None else 0), e0, e1, 'kk/h2/pipe4'))
 
 
+# ---- Dense -> LayerNorm (-> SiLU) in one launch (genrl_gemm_h2_ln: the column tiles of a row block exchange their row statistics inside ONE
+# XCD's L2 behind a barrier of N / 64 workgroups, csrc/gemm_planes.hip LnEpi).  Two such launches must never run concurrently (each would wait
+# for workgroups the other keeps off the CUs), so the fused form is taken on the iteration's MAIN stream only -- never on a side stream of
+# genrl_amd/streams.py -- and its workspace (barrier counters, zeroed once; exchange slab) is one per device, created outside graph capture.
+LN_FUSED = os.environ.get('GENRL_GEMM_LN', '1') != '0'
+_ln_ws = {}              # device index -> (sync words (int32, zeroed once), exchange slab (fp32))
+
+
+def _ln_workspace(dev):
+    d = torch.device(dev).index
+    d = torch.cuda.current_device() if d is None else d
+    ws = _ln_ws.get(d)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None              # (first use inside a capture: that call stays unfused; the warm-up iterations create it)
+        L = lib()
+        ws = _ln_ws[d] = (torch.zeros(L.genrl_gemm_h2_ln_sync_words(), dtype=torch.int32, device=f'cuda:{d}'),
+                          torch.empty(L.genrl_gemm_h2_ln_part_floats(1024, 1024) + 4, device=f'cuda:{d}'))
+    return ws
+
+
+def gemm_ln_ok(M, N, dev=None):
+    """may y = act(LayerNorm(A B^T + b)) run as ONE launch here?  (shape: N % 64 == 0, N <= 1024, every workgroup resident at once; stream: not
+    one of the side streams; workspace present)"""
+    if not (LN_FUSED and ENABLED):
+        return False
+    from . import streams
+    return (lib().genrl_gemm_h2_ln_ok(M, N) == 1 and not streams.on_side_stream()
+            and _ln_workspace(dev if dev is not None else torch.cuda.current_device()) is not None)
+
+
+def gemm_ln(A, B, C, bias, M, N, gamma, beta, eps, out_p, out_row0, y=None, mean=None, rstd=None, act=True, a_row0=0, A1=None, B1=None,
+            a1_row0=0, c_off=0, y_off=0, m_off=0):
+    """C[M, N] = A[a_row0.., :] B^T (+ A1 B1^T) + bias (row stride N) and, in the same launch, y = act(LayerNorm(C) gamma + beta): fp32 rows
+    into `y` (row stride N, y_off elements in; None: planes only), planes into rows out_row0.. of out_p (uniform scale), mean / rstd (m_off in)"""
+    assert A.ld == B.ld and a_row0 + M <= A.rows and N <= B.rows and out_p.cols == N and out_row0 + M <= out_p.rows
+    if gemm_profile is not None:
+        e0 = torch.cuda.Event(enable_timing=True); e0.record()
+    k1 = 0
+    a1 = b1 = (None, 0, 0, None)
+    if A1 is not None:
+        assert A1.ld == B1.ld and a1_row0 + M <= A1.rows and N <= B1.rows
+        k1 = A1.ld
+        a1, b1 = (A1.ptr(a1_row0), A1.ld, A1.plane, A1.inv_ptr(a1_row0)), (B1.ptr(0), B1.ld, B1.plane, B1.inv_ptr(0))
+    sync, part = _ln_workspace(C.device)
+    check(lib().genrl_gemm_h2_ln(A.ptr(a_row0), A.ld, A.plane, A.inv_ptr(a_row0), B.ptr(0), B.ld, B.plane, B.inv_ptr(0), A.ld, *a1, *b1, k1,
+                                 C.data_ptr() + 4 * c_off, N, bias.data_ptr() if bias is not None else None, M, N,
+                                 gamma.data_ptr(), beta.data_ptr(), float(eps), int(act),
+                                 (y.data_ptr() + 4 * y_off) if y is not None else None, N,
+                                 (mean.data_ptr() + 4 * m_off) if mean is not None else None,
+                                 (rstd.data_ptr() + 4 * m_off) if rstd is not None else None,
+                                 out_p.ptr(out_row0), out_p.ld, out_p.plane, out_p.inv_ptr(out_row0),
+                                 (part.data_ptr() + 15) // 16 * 16, sync.data_ptr(), _stream()), 'gemm_h2_ln')
+    if gemm_profile is not None:
+        e1 = torch.cuda.Event(enable_timing=True); e1.record()
+        gemm_profile.append((M, N, A.cols + (A1.cols if A1 is not None else 0), e0, e1, 'kk/h2ln/pipe4'))
+
+
+def check_ln_failure():
+    """(synchronises) did a fused Dense -> LayerNorm launch raise its failure word -- a barrier that timed out (its workgroups were not
+    co-resident) or a workgroup placement other than b % 8?  Turns the fused form off and raises: results since the last check are invalid."""
+    global LN_FUSED
+    for d, (sync, _) in _ln_ws.items():
+        if int(sync[0].item()) != 0:
+            LN_FUSED = False
+            sync.zero_()
+            raise GenrlHipError('genrl_gemm_h2_ln: an XCD-local barrier timed out or workgroups were not placed b % 8; '
+                                'the fused Dense -> LayerNorm form is now off (GENRL_GEMM_LN=0 turns it off from the start)')
+
+
 def gemm_sample(A, B, C, ldc, bias, M, N, q, ldq, unimix, sample, lds, SP=None, a_row0=0, c_off=0, q_off=0, s_off=0, sp_row0=0):
     """C[M, N] = A[a_row0.., :] B^T + bias AND, in the same launch, the categorical sample of every 32-class latent of the
     rows (genrl_gemm_h2_sample): one-hot rows into `sample` (fp32, s_off elements in) and their planes into SP (rows sp_row0..)"""

@@ -74,3 +74,10 @@ def join(name=None):
 def pending(name):
     """has work been forked onto side stream `name` (on the current device) that nobody has joined yet?"""
     return (name, torch.cuda.current_device()) in _dirty
+
+
+def on_side_stream():
+    """is torch's current stream one of the side streams created here (on the current device)?"""
+    cur = raw_current_stream()
+    dev = torch.cuda.current_device()
+    return any(k[1] == dev and s.cuda_stream == cur for k, s in _side.items())

@@ -93,6 +93,27 @@ int genrl_gemm_h2_sample(const uint16_t* a0, long a0_ld, long a0_plane, const fl
                          long b0_plane, const float* b0_inv, int k0, float* C, long ldc, const float* bias, int M, int N,
                          const float* q, long ldq, float unimix, float* sample, long lds, uint16_t* sp, long sld, long splane,
                          float* sinv, void* stream);
+/* Dense -> LayerNorm (-> SiLU) in ONE launch (round 6; replaces genrl_gemm_h2 + genrl_ln_act_fwd_h2 for the MLP / img_step layers of
+ * agent/dreamer_utils.py:718-747, :459-473 at <= 1024 columns): C = A0 B0^T (+ A1 B1^T) + bias as genrl_gemm_h2 (C keeps the pre-activation the
+ * LayerNorm backward reads), then y = act(LayerNorm(C) gamma + beta) as fp32 rows (y may be NULL) and as h2 planes with ONE scale for the
+ * whole tensor (the bound max|gamma| sqrt(N) + max|beta|; yinv[row] holds the same value in every row), mean / rstd [M].  A LayerNorm row spans
+ * the N / 64 column tiles of its 64-row block: the launch places those workgroups on ONE XCD (workgroup b runs on XCD b % 8) and they exchange
+ * partial row statistics through that XCD's L2 behind a barrier of N / 64 workgroups (0.7 us; a chip-wide barrier costs 3.9,
+ * profiles/r06_xcd_barrier.txt) -- no fence, no cache write-back or invalidate.  genrl_gemm_h2_ln_ok(M, N): N % 64 == 0, N <= 1024 and all
+ * cdiv(M, 64) N / 64 workgroups resident at once, at most 32 per XCD (1024 rows at N = 1024).  gamma / beta / C / y / part 16-byte aligned;
+ * ldc / ldy / yld % 4 == 0.  part: genrl_gemm_h2_ln_part_floats(M, N) floats of scratch.  sync: genrl_gemm_h2_ln_sync_words() uint32 words,
+ * ZEROED ONCE by the caller, then owned by the launches of one stream (the counters re-arm themselves at the end of every launch).  Two such
+ * launches must not run concurrently (each would wait for workgroups the other keeps off the CUs): the caller uses it on one stream at a time.
+ * sync[0] != 0 after a launch: a barrier timed out or the placement was not b % 8 -- the results are invalid (bounded spin, no hang). */
+int genrl_gemm_h2_ln_ok(int M, int N);
+long genrl_gemm_h2_ln_part_floats(int M, int N);
+long genrl_gemm_h2_ln_sync_words(void);
+int genrl_gemm_h2_ln(const uint16_t* a0, long a0_ld, long a0_plane, const float* a0_inv, const uint16_t* b0, long b0_ld, long b0_plane,
+                     const float* b0_inv, int k0, const uint16_t* a1, long a1_ld, long a1_plane, const float* a1_inv,
+                     const uint16_t* b1, long b1_ld, long b1_plane, const float* b1_inv, int k1,
+                     float* C, long ldc, const float* bias, int M, int N, const float* gamma, const float* beta, float eps, int act,
+                     float* y, long ldy, float* mean, float* rstd, uint16_t* yp, long yld, long yplane, float* yinv,
+                     float* part, unsigned* sync, void* stream);
 /* UNIFORM-scale h2 planes (one power-of-two scale for the whole tensor, inv[row] the same in every row): what the convolution
  * products need -- a patch row gathers from several pixel rows, a weight gradient sums over them (csrc/gemm_planes*.hip).
  * genrl_split_h2u: from an fp32 matrix, exact tensor maximum (two launches; ws >= 1024 floats).  genrl_ln_act_fwd_h2u: the channel

@@ -95,6 +95,7 @@ def test_fp32_output_follows_the_consumers_predicate(C1, subpixel, monkeypatch):
     shapes skip it and never fill it.  Values and every gradient against torch either way."""
     from genrl_amd import ops_conv_planes as cp
     monkeypatch.setattr(cp, 'SUBPIXEL', subpixel)
+    monkeypatch.setattr(cp, 'KR_MIN_K', 512)             # the product's default (the suite's environment lowers it to 0: GEMM -> col2im on planes at every width)
     N, Hi, C0, C2 = 64, 31, 48, 64
     x = torch.randn(N, Hi, Hi, C0, generator=g(1))
     W1 = torch.randn(C1, C0, 4, 4, generator=g(2)) / (C0 * 16) ** .5; b1 = 0.1 * torch.randn(C1, generator=g(3))

@@ -88,7 +88,7 @@ def test_imagination_update_fused_forward_equals_unfused(BS, BL, monkeypatch):
     from genrl_amd import config, noise as gnoise, ops
     from genrl_amd.agent import dreamer_utils as common
     from test_gpu_iteration import FakeClip
-    monkeypatch.delenv('GENRL_PLANES_MIN_ROWS', raising=False)        # the product's default threshold (320 rows): fp32-operand rollout
+    monkeypatch.setenv('GENRL_PLANES_MIN_ROWS', '320')        # the fp32-operand rollout (the product's policy below 192 rows) at both sizes
     A, S, K, H, seed = 10, 32, 32, 15, 8
     ocfg = O.make_cfg(stoch=S, discrete=K, act_dim=A, horizon=H)
     p = detgen.det_state_dict(agent_param_shapes(ocfg), seed)

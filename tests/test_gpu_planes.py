@@ -301,13 +301,13 @@ def test_mlp_chains_without_plane_operands_match_reference(monkeypatch):
 
 
 def test_small_rollouts_take_the_fp32_operand_path(monkeypatch):
-    """Default policy: below 320 rollout rows the imagination runs on the fp32-operand kernels (ops._Rollout /
+    """Default policy: below 192 rollout rows the imagination runs on the fp32-operand kernels (ops._Rollout /
     ops.ActorTape) -- and that path reproduces the reference's tiny iteration like the planes path does."""
     import numpy as np
     from genrl_amd import config, ops, ops_planes
     from test_gpu_iteration import run_product, check_vs_golden
     monkeypatch.delenv('GENRL_PLANES_MIN_ROWS', raising=False)
-    assert ops_planes.min_rows() == 320
+    assert ops_planes.min_rows() == 192
     seen = []
     orig = ops._Rollout.forward
     monkeypatch.setattr(ops._Rollout, 'forward', staticmethod(lambda *a, **k: (seen.append(1), orig(*a, **k))[1]))
@@ -522,7 +522,7 @@ def test_rollout_c_loop_is_the_python_loop(tiny, fp32_path, monkeypatch):
     """genrl_imagine_seq_fwd (csrc/seq.hip): the plane rollout's H-step launch loop from ONE C call -- the same 16 launches per step in the
     same order, so the imagination update's metrics and every actor / critic gradient are bit-identical to the per-launch Python loop
     (tiny widths: 4-class latents, the separate sampling kernel; full width: 32 classes, the sample in the product's epilogue).
-    fp32_path: the fp32-operand rollout of the product's default policy below 320 rows (genrl_imagine_seq_f32_fwd / _bwd, 20 + 14 launches
+    fp32_path: the fp32-operand rollout of the product's default policy below 192 rows (genrl_imagine_seq_f32_fwd / _bwd, 20 + 14 launches
     per step) instead of the plane rollout the suite forces on everywhere else"""
     if fp32_path:
         monkeypatch.delenv('GENRL_PLANES_MIN_ROWS', raising=False)
