@@ -6,7 +6,7 @@ import os, subprocess, sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = ['gemm.hip', 'gemm_planes.hip', 'gemm_planes_tn.hip', 'scan_coop.hip', 'rowops.hip', 'dist.hip', 'conv.hip', 'optim.hip', 'stats.hip', 'fused_small.hip', 'seq.hip']
+SRC = ['gemm.hip', 'gemm_planes.hip', 'gemm_planes_tn.hip', 'rowops.hip', 'dist.hip', 'conv.hip', 'optim.hip', 'stats.hip', 'seq.hip']
 HDR = ['common.h']
 OUT = os.path.join(HERE, 'libgenrl_hip.so')
 OBJ = os.path.join(HERE, 'csrc', 'build')

@@ -101,7 +101,7 @@ struct LnEpi {
   u16* yp; long yld, yplane; float* yinv;    // h2 planes of y (+ per-row inverse scale: the same value in every row)
   float* mean; float* rstd;                  // [M] row statistics (for the backward)
   float* part;                               // exchange slab: [row blocks][tiles_n][64][2] floats
-  unsigned* sync;                            // word 0: failure flag; row block rb: arrive counter at word 32 (1 + 2 rb), exit counter at 32 (2 + 2 rb)
+  unsigned* sync;                            // word 0: failure flag; row block rb: arrival counter at word 32 (1 + 2 rb), its epoch (launches so far) at 32 (2 + 2 rb)
 };
 
 // a / b for exact powers of two (exponent arithmetic; clamped to the normal range)
@@ -152,9 +152,8 @@ __global__ __launch_bounds__(256, (TM * TN == 1 && NS == 2 && FMT == 1) ? 2 : 1)
   // BEFORE the first stage (older than every stage DMA: the counted waits and the first barrier cover them), instead of as global
   // loads behind the last MFMA, where their latency was exposed once per workgroup
   constexpr int EPI = FMT == 1 ? 4 * (BM + 2 * BN) : 0, EPI_AT = NS * STAGE + (PF ? 1024 : 0);
-  // LNE: gamma / beta of all N <= 1024 columns (2 x 4 KiB), the exchange records of the row block (8 KiB), row statistics, reduction scratch
-  constexpr int LN_AT = EPI_AT + EPI, LN_G = LN_AT, LN_B = LN_AT + 4096, LN_X = LN_AT + 8192, LN_S = LN_AT + 16384, LN_R = LN_AT + 16896,
-                LN_U = LN_AT + 17920, LN_BYTES = LNE ? 18432 : 0;
+  // LNE: gamma / beta of all N <= 1024 columns (2 x 4 KiB), reduction scratch
+  constexpr int LN_AT = EPI_AT + EPI, LN_G = LN_AT, LN_B = LN_AT + 4096, LN_R = LN_AT + 8192, LN_U = LN_AT + 9216, LN_BYTES = LNE ? 9472 : 0;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[EPI_AT + EPI + LN_BYTES];
 #if PLANES_ABL == 6       /* ablation 6 (scripts/intercept64.py): the launch alone -- same grid, LDS and register footprint, no work */
   if (M > 0) { if (threadIdx.x == 1023) lds[0] = 0; return; }
@@ -164,8 +163,15 @@ __global__ __launch_bounds__(256, (TM * TN == 1 && NS == 2 && FMT == 1) ? 2 : 1)
   int bid = blockIdx.x, tile_m, tile_n;
   {
     const int ntiles = tiles_m * tiles_n;
-    const int x = bid % 8, i = bid / 8;
+    int x = bid % 8;
+    const int i = bid / 8;
     if constexpr (LNE) {                  // all column tiles of a row block on one XCD (see LnEpi)
+      // the XCD this workgroup really runs on: the dispatcher deals workgroups round-robin, but a dispatch does not always START at XCD 0
+      // (measured: under hipGraph replay and between back-to-back launches workgroup b may sit on XCD (b + d) % 8) -- with the real id
+      // every XCD still receives each local index i = b / 8 exactly once, whatever the rotation d
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      x = (int)(xcc & 7u);
       tile_n = i % tiles_n; tile_m = (i / tiles_n) * 8 + x;
       if (tile_m >= tiles_m) return;      // (a whole group: nobody waits for it)
     } else if (xcd_m > 0) {
@@ -538,12 +544,21 @@ __global__ __launch_bounds__(256, (TM * TN == 1 && NS == 2 && FMT == 1) ? 2 : 1)
       const float m2 = ldsf(LN_R + 512 + 4 * (wm * 64 + l32)) + ldsf(LN_R + 512 + 4 * (wm * 64 + 32 + l32));
       *reinterpret_cast<h2_f32x2*>(part_rb + (tile_n * 64 + rl) * 2) = h2_f32x2{mean_t, m2};
     }
-    wait_vm<0>();                       // the record has reached the L2 (and the ring's trailing DMAs have landed)
-    __syncthreads();
     gu32_* const arrive = (gu32_*)(ln.sync + 32 * (1 + 2 * tile_m));
-    gu32_* const leave = (gu32_*)(ln.sync + 32 * (2 + 2 * tile_m));
+    gu32_* const epochw = (gu32_*)(ln.sync + 32 * (2 + 2 * tile_m));
     gu32_* const failw = (gu32_*)ln.sync;
-    if (tid == 0) asm volatile("global_atomic_add %0, %1, off" ::"v"(arrive), "v"(1u) : "memory");
+    // the barrier's target: the counter never goes back -- launch e of this row block waits for (e + 1) tiles_n arrivals, and the LAST
+    // arriver of a launch (every member has read the epoch by then: it read it before its own arrival) moves the epoch on
+    unsigned epoch = 0;
+    if (tid == 0) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(epoch) : "v"(epochw) : "memory");
+    wait_vm<0>();                       // the record has reached the L2 (and the ring's trailing DMAs have landed); the epoch is here
+    if (tid == 0) asm volatile("" : "+v"(epoch));
+    __syncthreads();
+    const unsigned target = (epoch + 1u) * (unsigned)tiles_n;
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old + 1u == target) __hip_atomic_store(epochw, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // (while the peers arrive) the pre-activation for the backward, and the scale bound from gamma / beta of all N columns
     if (row < M) {
 #pragma unroll
@@ -562,54 +577,50 @@ __global__ __launch_bounds__(256, (TM * TN == 1 && NS == 2 && FMT == 1) ? 2 : 1)
       gm = wave_max(gm); bm = wave_max(bm);
       if (lane == 0) { ldsw(LN_U + 8 * wave, gm); ldsw(LN_U + 8 * wave + 4, bm); }
     }
-    if (tid == 0) {                     // bounded poll (L2-served loads); a timeout or a misplaced workgroup raises the failure word
-      unsigned xcc;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      bool ok = (xcc & 7u) == (unsigned)(blockIdx.x & 7);
-      if (ok) {
-        ok = false;
-        for (unsigned spins = 0; spins < (1u << 22); ++spins) {
-          if (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)tiles_n) { ok = true; break; }
-          __builtin_amdgcn_s_sleep(1);
-        }
+    if (tid == 0) {                     // bounded poll (L2-served loads); a timeout (the workgroups were not dealt round-robin) raises the failure word
+      bool ok = false;
+      for (unsigned spins = 0; spins < (1u << 20); ++spins) {
+        if (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(1);
       }
       if (!ok) __hip_atomic_store(failw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    // the row block's records -> LDS (sc1 loads: served by the L2, the L1 is never consulted)
+    // every lane fetches the tiles' records of ITS row (sc1 loads: served by the L2, the L1 is never consulted), all in flight at once, and
+    // combines them itself: mean = the mean of the tile means (equal counts), M2 = sum of the tiles' M2 + 64 sum (tile mean - mean)^2 --
+    // the same arithmetic in the same order in every lane of every workgroup of the row block
+    h2_f32x2 rec[16];
     {
-      const int nq = tiles_n * 32;      // float4 records' quads: tiles_n x 64 rows x 2 floats / 4
-      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
-      const float* p0 = part_rb + 4 * min(tid, nq - 1);
-      const float* p1 = part_rb + 4 * min(tid + 256, nq - 1);
-      asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
-                   : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
-      *reinterpret_cast<__attribute__((address_space(3))) f32x4*>((uintptr_t)(lds0 + LN_X + 16 * tid)) = v0;
-      *reinterpret_cast<__attribute__((address_space(3))) f32x4*>((uintptr_t)(lds0 + LN_X + 16 * (tid + 256))) = v1;
+      const float* rp = part_rb + rl * 2;
+#pragma unroll
+      for (int jt = 0; jt < 16; ++jt) {
+        const float* pj = rp + min(jt, tiles_n - 1) * 128;
+        asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(rec[jt]) : "v"(pj) : "memory");
+      }
+#pragma unroll
+      for (int jt = 0; jt < 16; ++jt) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rec[jt])::"memory");
     }
-    __syncthreads();
+    float mu = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 16; ++jt) mu += jt < tiles_n ? rec[jt][0] : 0.f;
+    mu *= 1.0f / (float)tiles_n;
+    float m2 = 0.f, dv = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 16; ++jt) {
+      const float d = rec[jt][0] - mu;
+      m2 += jt < tiles_n ? rec[jt][1] : 0.f;
+      dv += jt < tiles_n ? d * d : 0.f;
+    }
+    m2 += 64.f * dv;
+    const float rs = 1.0f / sqrtf(m2 / (float)N + ln.eps);
     const float u_inv = h2_inv_of(fmaxf(fmaxf(ldsf(LN_U), ldsf(LN_U + 8)), fmaxf(ldsf(LN_U + 16), ldsf(LN_U + 24))) * sqrtf((float)N) +
                                   fmaxf(fmaxf(ldsf(LN_U + 4), ldsf(LN_U + 12)), fmaxf(ldsf(LN_U + 20), ldsf(LN_U + 28))));
     const float u_sc = h2_scale_of(u_inv);
-    if (tid < 64) {                     // Chan's combination of the tiles' (mean, M2) in tile order: the same result in every workgroup
-      float cnt = 0.f, mu = 0.f, m2 = 0.f;
-      for (int j = 0; j < tiles_n; ++j) {
-        const float mb = ldsf(LN_X + 8 * (j * 64 + tid)), qb = ldsf(LN_X + 8 * (j * 64 + tid) + 4);
-        const float tot = cnt + 64.f, d = mb - mu;
-        mu += d * (64.f / tot);
-        m2 += qb + d * d * (cnt * 64.f / tot);
-        cnt = tot;
-      }
-      const float rs = 1.0f / sqrtf(m2 / (float)N + ln.eps);
-      ldsw(LN_S + 8 * tid, mu); ldsw(LN_S + 8 * tid + 4, rs);
-      if (tile_n == 0 && m0 + tid < M) {
-        if (ln.mean) ln.mean[m0 + tid] = mu;
-        if (ln.rstd) ln.rstd[m0 + tid] = rs;
-        if (ln.yinv) ln.yinv[m0 + tid] = u_inv;
-      }
+    if (tile_n == 0 && wn == 0 && h32 == 0 && row < M) {
+      if (ln.mean) ln.mean[row] = mu;
+      if (ln.rstd) ln.rstd[row] = rs;
+      if (ln.yinv) ln.yinv[row] = u_inv;
     }
-    __syncthreads();
-    const float mu = ldsf(LN_S + 8 * rl), rs = ldsf(LN_S + 8 * rl + 4);
     if (row < M) {
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
@@ -631,14 +642,6 @@ __global__ __launch_bounds__(256, (TM * TN == 1 && NS == 2 && FMT == 1) ? 2 : 1)
           *reinterpret_cast<h2_u32x2*>(qd) = hh;
           *reinterpret_cast<h2_u32x2*>(qd + ln.yplane) = ll;
         }
-      }
-    }
-    // the group's last workgroup to leave re-arms the counters for the next launch on this workspace (every member has passed its poll by then)
-    if (tid == 0) {
-      const unsigned old = __hip_atomic_fetch_add(leave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (old + 1 == (unsigned)tiles_n) {
-        __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(leave, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     return;
@@ -1921,9 +1924,9 @@ int genrl_gemm_h2(const uint16_t* a0, long a0_ld, long a0_plane, const float* a0
  * inside ONE XCD's L2 behind a barrier of N / 64 workgroups.  Shapes: N % 64 == 0, N <= 1024, cdiv(M, 64) <= 8 (32 / (N / 64)) (every workgroup
  * of the launch resident at once, one per CU: genrl_gemm_h2_ln_ok); gamma / beta / C / y 16-byte aligned, ldc / ldy / yld % 4 == 0.
  * part: genrl_gemm_h2_ln_part_floats(M, N) floats of scratch; sync: genrl_gemm_h2_ln_sync_words() uint32 words, ZEROED ONCE by the caller and
- * then owned by launches of ONE stream at a time (the counters re-arm themselves; two launches sharing them concurrently, or two such launches
+ * then owned by launches of ONE stream at a time (a launch leaves them ready for the next; two launches sharing them concurrently, or two such launches
  * running concurrently on different streams at all -- each waits for workgroups the other keeps off the CUs -- are the caller's to avoid).
- * sync[0] != 0 afterwards: a barrier timed out or the workgroup placement was not b % 8 (results invalid). */
+ * sync[0] != 0 afterwards: a barrier timed out -- the dispatcher did not deal the workgroups round-robin over the XCDs (results invalid). */
 int genrl_gemm_h2_ln_ok(int M, int N) {
   if (M <= 0 || N <= 0 || (N & 63) || N > 1024) return 0;
   static int cus = -1;

@@ -458,7 +458,6 @@ __global__ void actor_head_fwd_rows_kernel(const float* __restrict__ raw, const 
   for (int a = 0; a < A; ++a) h2_store1(xo, r * xo.ld + a, action[r * ld_action + a], sc);
 }
 
-struct HeadLN { const float* stats; int nparts; const float* gamma; const float* beta; float eps; };
 
 // fp32 -> nearest-even bf16 -> fp32 (finite inputs), componentwise
 __device__ __forceinline__ float bf16r(float x) {
@@ -477,36 +476,11 @@ __global__ __launch_bounds__(256) void actor_head_linear_fwd_kernel(const float*
                                                                     const float* __restrict__ b, const float* __restrict__ eps,
                                                                     float* __restrict__ raw, float* __restrict__ action, long R, int U,
                                                                     int A, float min_std, float max_std, long ld_action, PlaneOut xo,
-                                                                    int p16, HeadLN ln) {
+                                                                    int p16) {
   __shared__ float part[4][MAXO];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nv = U >> 2;
   const long row = blockIdx.x;
   const int O = 2 * A;
-  // ln.stats != NULL: y holds the RAW rows of the last trunk layer and the LayerNorm + SiLU in front of this layer happens here,
-  // from the producer's partial statistics (csrc/fused_small.hip: [nparts][R][2] = (mean, M2) per 16 columns; nparts <= 64):
-  // lane p takes partial p, a fixed-order butterfly (Chan's combination) leaves the row's moments in every lane of every wave
-  float ln_mu = 0.f, ln_rs = 1.f;
-  if (ln.stats) {
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    if (lane < ln.nparts) {
-      const float2 sp = *reinterpret_cast<const float2*>(ln.stats + ((long)lane * R + row) * 2);
-      n = (float)(U / ln.nparts); mean = sp.x; m2 = sp.y;
-    }
-#pragma unroll
-    for (int sh = 32; sh > 0; sh >>= 1) {
-      const float nb = __shfl_xor(n, sh, 64), mb = __shfl_xor(mean, sh, 64), qb = __shfl_xor(m2, sh, 64);
-      float na = n, ma = mean, qa = m2, nbb = nb, mbb = mb, qbb = qb;
-      if (lane & sh) { na = nb; ma = mb; qa = qb; nbb = n; mbb = mean; qbb = m2; }       // lower lane first: both partners get the same bits
-      const float nt = na + nbb;
-      if (nt > 0.f) {
-        const float d = mbb - ma;
-        ma += d * (nbb / nt);
-        qa += qbb + d * d * (na * nbb / nt);
-      }
-      n = nt; mean = ma; m2 = qa;
-    }
-    ln_mu = mean; ln_rs = rsqrtf(m2 / (float)U + ln.eps);
-  }
   float sacc[MAXO];
 #pragma unroll
   for (int u = 0; u < MAXO; ++u) sacc[u] = 0.f;
@@ -514,14 +488,6 @@ __global__ __launch_bounds__(256) void actor_head_linear_fwd_kernel(const float*
     const int j = j0 + threadIdx.x;
     const int jc = min(j, nv - 1);
     float4 v = reinterpret_cast<const float4*>(y + row * ldy)[jc];
-    if (ln.stats) {
-      const float4 g = reinterpret_cast<const float4*>(ln.gamma)[jc], be = reinterpret_cast<const float4*>(ln.beta)[jc];
-      float z;
-      z = (v.x - ln_mu) * ln_rs * g.x + be.x; v.x = z / (1.0f + __expf(-z));
-      z = (v.y - ln_mu) * ln_rs * g.y + be.y; v.y = z / (1.0f + __expf(-z));
-      z = (v.z - ln_mu) * ln_rs * g.z + be.z; v.z = z / (1.0f + __expf(-z));
-      z = (v.w - ln_mu) * ln_rs * g.w + be.w; v.w = z / (1.0f + __expf(-z));
-    }
     if (j >= nv) v = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 wv[MAXO];
 #pragma unroll
@@ -1827,27 +1793,15 @@ int genrl_actor_head_fwd_h2(const float* raw, const float* eps, float* action, f
  * optionally the action's h2 planes (ap != NULL).  U % 4 == 0, A <= 32, 16-byte aligned y rows and W. */
 static int actor_head_linear_fwd_impl(const float* y, long ldy, const float* W, const float* b, const float* eps, float* raw,
                                       float* action, long R, int U, int A, float min_std, float max_std, long ld_action, uint16_t* ap,
-                                      long ldp, long plane, float* inv, HeadLN hln, void* stream);
+                                      long ldp, long plane, float* inv, void* stream);
 int genrl_actor_head_linear_fwd(const float* y, long ldy, const float* W, const float* b, const float* eps, float* raw,
                                 float* action, long R, int U, int A, float min_std, float max_std, long ld_action, uint16_t* ap,
                                 long ldp, long plane, float* inv, void* stream) {
-  return actor_head_linear_fwd_impl(y, ldy, W, b, eps, raw, action, R, U, A, min_std, max_std, ld_action, ap, ldp, plane, inv,
-                                    HeadLN{nullptr, 0, nullptr, nullptr, 0.f}, stream);
-}
-/* the same with the LayerNorm + SiLU in front of the output layer taken from the producer's partial statistics (genrl_small_fused):
- * y = RAW rows of the last trunk layer, stats [nparts][R][2] (nparts <= 64, U % nparts == 0), gamma / beta [U] */
-int genrl_actor_head_ln_linear_fwd(const float* y, long ldy, const float* stats, int nparts, const float* gamma, const float* beta,
-                                   float ln_eps, const float* W, const float* b, const float* eps, float* raw, float* action, long R,
-                                   int U, int A, float min_std, float max_std, long ld_action, void* stream) {
-  if (!stats || nparts <= 0 || nparts > 64 || U % nparts || !gamma || !beta ||
-      ((reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) || (reinterpret_cast<uintptr_t>(stats) & 7))
-    return GENRL_EINVAL;
-  return actor_head_linear_fwd_impl(y, ldy, W, b, eps, raw, action, R, U, A, min_std, max_std, ld_action, nullptr, 0, 0, nullptr,
-                                    HeadLN{stats, nparts, gamma, beta, ln_eps}, stream);
+  return actor_head_linear_fwd_impl(y, ldy, W, b, eps, raw, action, R, U, A, min_std, max_std, ld_action, ap, ldp, plane, inv, stream);
 }
 static int actor_head_linear_fwd_impl(const float* y, long ldy, const float* W, const float* b, const float* eps, float* raw,
                                       float* action, long R, int U, int A, float min_std, float max_std, long ld_action, uint16_t* ap,
-                                      long ldp, long plane, float* inv, HeadLN hln, void* stream) {
+                                      long ldp, long plane, float* inv, void* stream) {
   GENRL_ENTER();
   if (R <= 0) return GENRL_OK;
   if (U <= 0 || (U & 3) || A <= 0 || A > 32 || (ldy & 3) || !raw || !action) return GENRL_EINVAL;
@@ -1857,7 +1811,7 @@ static int actor_head_linear_fwd_impl(const float* y, long ldy, const float* W, 
   const long lda = ld_action > 0 ? ld_action : (long)A;
   const dim3 grid((unsigned)R), block(256);
   hipStream_t s = (hipStream_t)stream;
-#define GO(MO) hipLaunchKernelGGL((actor_head_linear_fwd_kernel<MO>), grid, block, 0, s, y, ldy, W, b, eps, raw, action, R, U, A, min_std, max_std, lda, xo, (int)(genrl_gemm_precision() == 1), hln)
+#define GO(MO) hipLaunchKernelGGL((actor_head_linear_fwd_kernel<MO>), grid, block, 0, s, y, ldy, W, b, eps, raw, action, R, U, A, min_std, max_std, lda, xo, (int)(genrl_gemm_precision() == 1))
   if (2 * A <= 12) GO(12); else if (2 * A <= 20) GO(20); else if (2 * A <= 32) GO(32); else GO(64);
 #undef GO
   GENRL_CHECK_LAUNCH();

@@ -74,6 +74,17 @@ static inline int gemm2(const genrl_planes_ref& a, long ar, const genrl_planes_r
                        two ? b1->p : nullptr, two ? b1->ld : 0, two ? b1->plane : 0, two ? b1->inv : nullptr, two ? (int)a1->ld : 0,
                        C, ldc, bias, M, N, 0, st);
 }
+// product + LayerNorm + SiLU in one launch (genrl_gemm_h2_ln) -- same operands as gemm2, same outputs as gemm2 + ln_h2
+static inline int gemm2_ln(const genrl_rollout* r, const genrl_planes_ref& a, long ar, const genrl_planes_ref& b, const genrl_planes_ref* a1, long a1r,
+                           const genrl_planes_ref* b1, float* C, const float* bias, int M, int N, const float* g, const float* be, float eps,
+                           float* y, float* mean, float* rstd, const genrl_planes_ref& P, long row0, void* st) {
+  const bool two = a1 && a1->p;
+  return genrl_gemm_h2_ln(a.p + ar * a.ld, a.ld, a.plane, a.inv + ar, b.p, b.ld, b.plane, b.inv, (int)a.ld,
+                          two ? a1->p + a1r * a1->ld : nullptr, two ? a1->ld : 0, two ? a1->plane : 0, two ? a1->inv + a1r : nullptr,
+                          two ? b1->p : nullptr, two ? b1->ld : 0, two ? b1->plane : 0, two ? b1->inv : nullptr, two ? (int)a1->ld : 0,
+                          C, N, bias, M, N, g, be, eps, 1, y, N, mean, rstd, const_cast<uint16_t*>(P.p) + row0 * P.ld, P.ld, P.plane,
+                          const_cast<float*>(P.inv) + row0, r->ln_part, r->ln_sync, st);
+}
 static inline int ln_h2(const float* pre, const float* g, const float* be, float* y, float* mean, float* rstd, int M, int N, float eps,
                         const genrl_planes_ref& P, long row0, void* st) {
   return genrl_ln_act_fwd_h2(pre, N, g, be, y, N, mean, rstd, M, N, eps, 1, const_cast<uint16_t*>(P.p) + row0 * P.ld, P.ld, P.plane,
@@ -91,10 +102,18 @@ int genrl_imagine_seq_fwd(const genrl_rollout* r, void* st) {
     for (int l = 0; l < L; ++l) {
       const int Ul = r->pU[l];
       float* pre = r->ppre[l] + r0 * Ul;
+      if (r->ln_sync && genrl_gemm_h2_ln_ok(N, Ul)) {
+        if (l == 0) RC(gemm2_ln(r, r->stoch_p, r0, r->pw0s, &r->deter_p, r0, &r->pw0d, pre, r->pb[0], N, Ul, r->pg[l], r->pbe[l], r->peps[l],
+                                r->py[l] + r0 * Ul, r->pmean[l] + r0, r->prstd[l] + r0, r->pyp[l], r0, st));
+        else RC(gemm2_ln(r, r->pyp[l - 1], r0, r->pw[l], nullptr, 0, nullptr, pre, r->pb[l], N, Ul, r->pg[l], r->pbe[l], r->peps[l],
+                         r->py[l] + r0 * Ul, r->pmean[l] + r0, r->prstd[l] + r0, r->pyp[l], r0, st));
+        continue;
+      }
       if (l == 0) RC(gemm2(r->stoch_p, r0, r->pw0s, &r->deter_p, r0, &r->pw0d, pre, Ul, r->pb[0], N, Ul, st));
       else RC(gemm2(r->pyp[l - 1], r0, r->pw[l], nullptr, 0, nullptr, pre, Ul, r->pb[l], N, Ul, st));
       RC(ln_h2(pre, r->pg[l], r->pbe[l], r->py[l] + r0 * Ul, r->pmean[l] + r0, r->prstd[l] + r0, N, Ul, r->peps[l], r->pyp[l], r0, st));
     }
+    const bool fuse_u = r->ln_sync && genrl_gemm_h2_ln_ok(N, U);
     {
       const int Ul = r->pU[L - 1];
       RC(genrl_actor_head_linear_fwd(r->py[L - 1] + r0 * Ul, Ul, r->head_w, r->head_b, r->eps + r0 * A, r->raws + r0 * 2 * A,
@@ -103,16 +122,24 @@ int genrl_imagine_seq_fwd(const genrl_rollout* r, void* st) {
                                      const_cast<float*>(r->act_p.inv) + r1, st));
     }
     // img_in: [stoch_h | action_{h+1}] -> hidden, LN + SiLU
-    RC(gemm2(r->stoch_p, r0, r->w_in_s, &r->act_p, r1, &r->w_in_a, r->x_pre + r0 * U, U, r->in_b, N, U, st));
-    RC(ln_h2(r->x_pre + r0 * U, r->in_g, r->in_be, r->x, r->xm + r0, r->xr + r0, N, U, r->in_eps, r->x_p, 0, st));
+    if (fuse_u) RC(gemm2_ln(r, r->stoch_p, r0, r->w_in_s, &r->act_p, r1, &r->w_in_a, r->x_pre + r0 * U, r->in_b, N, U, r->in_g, r->in_be, r->in_eps,
+                            r->x, r->xm + r0, r->xr + r0, r->x_p, 0, st));
+    else {
+      RC(gemm2(r->stoch_p, r0, r->w_in_s, &r->act_p, r1, &r->w_in_a, r->x_pre + r0 * U, U, r->in_b, N, U, st));
+      RC(ln_h2(r->x_pre + r0 * U, r->in_g, r->in_be, r->x, r->xm + r0, r->xr + r0, N, U, r->in_eps, r->x_p, 0, st));
+    }
     // GRU: [x | deter_h] W_g^T -> LN + gates -> deter_{h+1}
     RC(gemm2(r->x_p, 0, r->w_g_x, &r->deter_p, r0, &r->w_g_h, r->g_pre + r0 * 3 * D, 3 * D, nullptr, N, 3 * D, st));
     RC(genrl_gru_gates_fwd_h2(r->g_pre + r0 * 3 * D, r->deter + r0 * D, D, r->gru_g, r->gru_be, r->deter + r1 * D, D, nullptr, nullptr,
                               r->gm + r0, r->gr + r0, N, D, 1e-5f, const_cast<uint16_t*>(r->deter_p.p) + r1 * r->deter_p.ld, r->deter_p.ld,
                               r->deter_p.plane, const_cast<float*>(r->deter_p.inv) + r1, st));
     // prior head: img_out (+ LN + SiLU), logits, sample
-    RC(gemm2(r->deter_p, r1, r->w_out, nullptr, 0, nullptr, r->o_pre + r0 * U, U, r->out_b, N, U, st));
-    RC(ln_h2(r->o_pre + r0 * U, r->out_g, r->out_be, r->o, r->om + r0, r->orr + r0, N, U, r->out_eps, r->o_p, 0, st));
+    if (fuse_u) RC(gemm2_ln(r, r->deter_p, r1, r->w_out, nullptr, 0, nullptr, r->o_pre + r0 * U, r->out_b, N, U, r->out_g, r->out_be, r->out_eps,
+                            r->o, r->om + r0, r->orr + r0, r->o_p, 0, st));
+    else {
+      RC(gemm2(r->deter_p, r1, r->w_out, nullptr, 0, nullptr, r->o_pre + r0 * U, U, r->out_b, N, U, st));
+      RC(ln_h2(r->o_pre + r0 * U, r->out_g, r->out_be, r->o, r->om + r0, r->orr + r0, N, U, r->out_eps, r->o_p, 0, st));
+    }
     if (r->K == 32 && r->dist_b) {
       RC(genrl_gemm_h2_sample(r->o_p.p, r->o_p.ld, r->o_p.plane, r->o_p.inv, r->w_dist.p, r->w_dist.ld, r->w_dist.plane, r->w_dist.inv,
                               (int)r->o_p.ld, r->logit + r1 * SK, SK, r->dist_b, N, (int)SK, r->q + r0 * SK, SK, r->unimix,

@@ -843,32 +843,6 @@ def actor_mean_std(raw, min_std=0.1, max_std=1.0):
     return mean.reshape(*raw.shape[:-1], A), std.reshape(*raw.shape[:-1], A)
 
 
-# ------------------------------------------------------------------ few-row layers with the LayerNorm in the consumer's loader
-# Built, parity-tested (tests/test_gpu_fused_small.py) and MEASURED SLOWER than the launches it removes -- opt-in (GENRL_FUSED_SMALL=1):
-# one layer at 128 rows takes 17.2 us with the LayerNorm in the loader against 12.4 us for the row kernel + the weight-streaming product
-# (8.0 us for the same fused kernel on plain rows): the 64 workgroups that share a row group each re-evaluate its exp / divide, and
-# that costs more than the ~5 us launch; the step goes 10.16 -> 10.63 ms at 4 sequences, 13.55 -> 15.86 at 8 (profiles/r04_fused_small.txt)
-FUSED_SMALL = os.environ.get('GENRL_FUSED_SMALL', '0') != '0'
-FUSED_SMALL_MAX_ROWS = int(os.environ.get('GENRL_FUSED_SMALL_MAX_ROWS', '256'))
-
-
-def small_fused(a0, a0_ld, w0, w0_ld, k0, C, ldc, M, N, ln=None, seg1=None, bias=None, stats_out=None):
-    """genrl_small_fused (csrc/fused_small.hip) on raw pointers: C[M, N] = act(A0) W0^T (+ A1 W1^T) + bias.
-    ln = (partial statistics pointer, nparts, gamma, beta, eps): LayerNorm + SiLU of A0's rows in this product's loader;
-    seg1 = (a1, a1_ld, w1, w1_ld, k1); stats_out: pointer for this product's own partial statistics ([N / 16][M][2])"""
-    st, npart, g, be, eps = ln if ln is not None else (None, 0, None, None, 0.0)
-    a1, a1_ld, w1, w1_ld, k1 = seg1 if seg1 is not None else (None, 0, None, 0, 0)
-    check(lib().genrl_small_fused(a0, a0_ld, w0, w0_ld, k0, st, npart, _p(g), _p(be), float(eps), a1, a1_ld, w1, w1_ld, k1, _p(bias),
-                                  C, ldc, M, N, stats_out, _stream()), 'small_fused')
-
-
-def fused_small_ok(N, U, dims4=()):
-    """may the rollout at N rows take the consumer-side-LayerNorm kernels?  (few rows; 16-column partial statistics, at most 64 of
-    them for the head kernel; fp32 arithmetic only -- precision 16 rounds its operands in the GEMM kernels proper)"""
-    return (FUSED_SMALL and N <= FUSED_SMALL_MAX_ROWS and U % 16 == 0 and U // 16 <= 64 and all(d % 4 == 0 for d in dims4)
-            and lib().genrl_gemm_precision() != 1)
-
-
 # ---- genrl_rollout_f32 (include/genrl_hip.h): the arguments of the fp32-operand rollout's launch loops in C (csrc/seq.hip)
 _FP, _CF, _CI = ctypes.c_void_p, ctypes.c_float, ctypes.c_int
 
@@ -934,8 +908,6 @@ class ActorTape:
         self.d_raw = torch.zeros(H, N, head_w.shape[0], device=dev)
         self.inputs = None                        # (x1 (H,N,K1), x2 (H,N,K2)) set by the caller after the rollout
         self.seen = 0
-        self.fused = False                        # forward_fused ran: y / mean / rstd are filled by _backward (one batched launch per layer)
-        self._stats = None                        # partial LayerNorm statistics per layer ([U / 16][N][2]), reused step after step
 
     head_leaves = None      # (W_mean, b_mean, W_std, b_std): the leaf parameters head_w / head_b were stacked from (set by the caller)
 
@@ -972,43 +944,6 @@ class ActorTape:
         else:
             dbh = colsum(d)
         return dWh, dbh
-
-    def forward_fused(self, t, x1_ptr, K1, x2_ptr, K2, eps_ptr, raw_ptr, action_ptr, ld_action, min_std, max_std):
-        """one policy evaluation at step t with the LayerNorms in the consumers' loaders (csrc/fused_small.hip): L products + the
-        head kernel = L + 1 launches instead of 2 L + 2; only the RAW pre-activations are written (self.pre)"""
-        N = self.N
-        dev = self.d_raw.device
-        if self._stats is None:
-            self._stats = [torch.empty(l[0].shape[0] // 16, N, 2, device=dev) for l in self.layers]
-        self.fused = True
-        prev = None
-        for l, (W, b, gamma, beta, eps) in enumerate(self.layers):
-            U, K = W.shape
-            cptr = self.pre[l].data_ptr() + 4 * t * N * U
-            if l == 0:
-                assert K == K1 + K2
-                small_fused(x1_ptr, K1, W.data_ptr(), K, K1, cptr, U, N, U, seg1=(x2_ptr, K2, W.data_ptr() + 4 * K1, K, K2), bias=b,
-                            stats_out=self._stats[l].data_ptr())
-            else:
-                Wp_, bp_, gp_, bep_, epsp_ = self.layers[l - 1]
-                Kx = Wp_.shape[0]
-                small_fused(self.pre[l - 1].data_ptr() + 4 * t * N * Kx, Kx, W.data_ptr(), K, Kx, cptr, U, N, U,
-                            ln=(self._stats[l - 1].data_ptr(), Kx // 16, gp_, bep_, epsp_), bias=b, stats_out=self._stats[l].data_ptr())
-        W, b, gamma, beta, eps = self.layers[-1]
-        U = W.shape[0]
-        A2 = self.head_w.shape[0]
-        check(lib().genrl_actor_head_ln_linear_fwd(self.pre[-1].data_ptr() + 4 * t * N * U, U, self._stats[-1].data_ptr(), U // 16, _p(gamma),
-                                                   _p(beta), float(eps), _p(self.head_w), _p(self.head_b), eps_ptr, raw_ptr, action_ptr, N, U,
-                                                   A2 // 2, min_std, max_std, ld_action, _stream()), 'actor_head_ln_linear_fwd')
-
-    def _materialise(self):
-        """after forward_fused: the activations and row statistics the backward reads, ONE LayerNorm launch per layer over all H N rows"""
-        M = self.H * self.N
-        for l, (W, b, gamma, beta, eps) in enumerate(self.layers):
-            U = W.shape[0]
-            check(lib().genrl_ln_act_fwd(_p(self.pre[l]), U, _p(gamma), _p(beta), _p(self.y[l]), U, _p(self.mean[l]), _p(self.rstd[l]),
-                                         M, U, eps, 1, _stream()), 'ln_act_fwd')
-        self.fused = False
 
     def step(self, t, x1, x2):
         flat = [q for l in self.layers for q in l[:4]]
@@ -1053,8 +988,6 @@ class ActorTape:
 
     def _backward(self):
         assert self.inputs is not None, 'ActorTape.inputs (time-major rollout states) not set'
-        if self.fused:
-            self._materialise()
         H, N = self.H, self.N
         M = H * N
         dev = self.d_raw.device
@@ -1182,33 +1115,13 @@ class _Rollout(Function):
         eps = _f32(eps).contiguous(); q = _f32(q).contiguous()
         Kin, Kg = sp.in_w.shape[1], sp.gru_w.shape[1]
         pt = lambda t, off: t.data_ptr() + 4 * off
-        fused = fused_small_ok(N, U, (SK, D, AP)) and all(l[0].shape[0] == U for l in tape.layers) and sp.out_w.shape[0] == U
-        if fused:
-            sx = torch.empty(U // 16, N, 2, device=dev); so = torch.empty(U // 16, N, 2, device=dev)
-        for h in (range(H) if fused else ()):
-            # 11 launches per step: every LayerNorm + SiLU happens in the loader of the product that consumes it (csrc/fused_small.hip)
-            sN, dN = h * N * SK, h * N * D
-            tape.forward_fused(h, pt(stoch, sN), SK, pt(deter, dN), D, pt(eps, h * N * A), pt(raws, h * N * 2 * A),
-                               pt(action, (h + 1) * N * AP), AP, sp.min_std, sp.max_std)
-            small_fused(pt(stoch, sN), SK, ws_in.data_ptr(), SK, SK, pt(x_pre, h * N * U), U, N, U,
-                        seg1=(pt(action, (h + 1) * N * AP), AP, wa.data_ptr(), AP, AP), bias=sp.in_b, stats_out=sx.data_ptr())
-            small_fused(pt(x_pre, h * N * U), U, sp.gru_w.data_ptr(), Kg, U, pt(g_pre, h * N * 3 * D), 3 * D, N, 3 * D,
-                        ln=(sx.data_ptr(), U // 16, sp.in_g, sp.in_be, sp.in_eps), seg1=(pt(deter, dN), D, sp.gru_w.data_ptr() + 4 * U, Kg, D))
-            _gru_fwd_raw(pt(g_pre, h * N * 3 * D), pt(deter, dN), sp.gru_g, sp.gru_be, pt(deter, dN + N * D), None, None,
-                         pt(st['gm'], h * N), pt(st['gr'], h * N), N, D)
-            small_fused(pt(deter, dN + N * D), D, sp.out_w.data_ptr(), D, D, pt(o_pre, h * N * U), U, N, U, bias=sp.out_b,
-                        stats_out=so.data_ptr())
-            small_fused(pt(o_pre, h * N * U), U, sp.dist_w.data_ptr(), U, U, pt(logit, sN + N * SK), SK, N, SK,
-                        ln=(so.data_ptr(), U // 16, sp.out_g, sp.out_be, sp.out_eps), bias=sp.dist_b)
-            check(lib().genrl_onehot_fwd(pt(logit, sN + N * SK), pt(q, h * N * SK), pt(stoch, sN + N * SK), None, N * S, K,
-                                         UNIMIX, _stream()), 'onehot_fwd')
-        seq_c = SEQ_C and not fused and gemm_profile is None and len(tape.layers) <= 8
+        seq_c = SEQ_C and gemm_profile is None and len(tape.layers) <= 8
         if seq_c:
             # the H-step launch loop in C (csrc/seq.hip: genrl_imagine_seq_f32_fwd -- the loop below, launch for launch)
             a, ws_keep = _rollout_f32_args(sp, tape, (H, N, S, K, D, A, U, AP), (stoch, deter, logit, action, raws, x_pre, g_pre, o_pre, st),
                                            ws_in, wa, x=x, o=o, eps=eps, q=q)
             check(lib().genrl_imagine_seq_f32_fwd(ctypes.addressof(a), _stream()), 'imagine_seq_f32_fwd')
-        for h in (() if (fused or seq_c) else range(H)):
+        for h in (() if seq_c else range(H)):
             sN, dN = h * N * SK, h * N * D
             tape._forward(h, stoch[h], deter[h], head=False)
             tape.head_fused(h, pt(eps, h * N * A), pt(raws, h * N * 2 * A), pt(action, (h + 1) * N * AP), AP, sp.min_std, sp.max_std)
@@ -1232,7 +1145,6 @@ class _Rollout(Function):
                                          UNIMIX, _stream()), 'onehot_fwd')
         tape.inputs = (stoch, deter)
         ctx.sp = sp
-        ctx.fused = fused          # (the backward then first materialises the row statistics of the two frozen LayerNorms)
         ctx.bufs = (stoch, deter, logit, raws, eps, x_pre, g_pre, o_pre, st, wa, ws_in)
         ctx.nparams = len(actor_params)
         ctx.dims = (H, N, S, K, D, A, U)
@@ -1264,11 +1176,6 @@ class _Rollout(Function):
         if da_in is not None:                 # upstream action gradients, once, in rows padded like the forward's actions
             dact_all = torch.zeros(H + 1, N, AP, device=dev)
             dact_all[:, :, :A].copy_(da_in)
-        if getattr(ctx, 'fused', False):
-            # the fused forward wrote raw rows only: mean / rstd of the two frozen LayerNorms for all H N rows, one launch each
-            scratch = f(H * N, U)
-            _ln_fwd_raw(_p(x_pre), sp.in_g, sp.in_be, _p(scratch), _p(st['xm']), _p(st['xr']), H * N, U, sp.in_eps)
-            _ln_fwd_raw(_p(o_pre), sp.out_g, sp.out_be, _p(scratch), _p(st['om']), _p(st['or']), H * N, U, sp.out_eps)
         seq_c = SEQ_C and gemm_profile is None and len(tape.layers) <= 8
         if seq_c:
             a, ws_keep = _rollout_f32_args(sp, tape, (H, N, S, K, D, A, U, AP), (None, deter, logit, None, raws, x_pre, g_pre, o_pre, st),
@@ -1745,21 +1652,6 @@ def gru_step(x, h, W, gamma, beta):
 SEQ_C = os.environ.get('GENRL_SEQ_C', '1') != '0'      # the scans' per-step launch loops run in C (csrc/seq.hip); 0: from Python
 
 
-def scan_coop_variant(B, D, T, I=0):
-    """0: the per-step launches (default); 1 / 2: the persistent scan kernel with one / two grid barriers per step
-    (GENRL_SCAN_COOP=1|2|auto; auto = one barrier where it exists (B <= 8), else two).  I: width of the input half of the GRU
-    weight (the W_h block starts at column I of each row: 16-byte aligned only when I % 4 == 0)."""
-    mode = os.environ.get('GENRL_SCAN_COOP', '0').strip().lower()
-    if mode in ('', '0', 'off') or _p16() or D % 4 or I % 4 or not (8 <= D // 4 <= 256) or B not in (4, 8, 16, 32):
-        return 0
-    if mode == 'auto':
-        return 1 if B <= 8 else 2
-    if mode not in ('1', '2'):
-        raise ValueError(f"GENRL_SCAN_COOP={mode!r}: expected 0, 1, 2 or auto")
-    v = int(mode)
-    return v if (v == 2 or B <= 8) else 0
-
-
 class _GRUSeq(Function):
     """The whole GRU recurrence of EnsembleRSSM.observe / VideoSSM.update over T steps with the
     non-recurrent half hoisted: pre_x = x W_x^T for all T at once; per step only
@@ -1785,29 +1677,14 @@ class _GRUSeq(Function):
         else:
             hm = None
         BD, B3D = B * D, B * 3 * D
-        variant = scan_coop_variant(B, D, T, I)
-        if variant:
-            # the whole recurrence in ONE persistent launch (csrc/scan_coop.hip): W_h resident in LDS, grid barriers per step
-            ws = torch.empty(lib().genrl_gru_scan_coop_ws_floats(B, D) + 64, device=dev)
-            wsp = (ws.data_ptr() + 255) // 256 * 256
-            check(lib().genrl_gru_scan_coop(_p(pre), W.data_ptr() + 4 * I, K, _p(gamma), _p(beta), _p(h0), _p(mask), _p(out),
-                                            _p(hm), _p(mean), _p(rstd), wsp, T, B, D, 1e-5, variant, _stream()), 'gru_scan_coop')
-            ctx._coop_ws = ws
-            # the kernel is a plain launch of D/4 workgroups that must all be resident (one per CU): with other streams' kernels on
-            # the GPU a barrier can time out, the kernel then exits early and sets its fail word (workspace word 416).  Outside graph
-            # capture the word is read back (one host sync; this path is opt-in) and a truncated scan is an error, never silent.
-            if not torch.cuda.is_current_stream_capturing():
-                off = (wsp - ws.data_ptr()) // 4
-                if int(ws.view(torch.int32)[off + 416].item()) != 0:
-                    raise GenrlHipError('gru_scan_coop: a grid barrier timed out (workgroups not co-resident); unset GENRL_SCAN_COOP')
-        seq_c = SEQ_C and not variant and gemm_profile is None
+        seq_c = SEQ_C and gemm_profile is None
         if seq_c:
             # the T-step launch loop in C (csrc/seq.hip: same launches, same order -- one host call instead of 2 T)
             nws = lib().genrl_gru_seq_ws_floats(B, D)
             ws = torch.empty(nws, device=dev) if nws > 0 else None
             check(lib().genrl_gru_seq_fwd(_p(pre), W.data_ptr() + 4 * I, K, _p(gamma), _p(beta), _p(h0), _p(mask), _p(out), _p(hm), _p(mean),
                                           _p(rstd), _p(ws), nws, T, B, D, 1e-5, _stream()), 'gru_seq_fwd')
-        for t in (range(T) if not (variant or seq_c) else ()):
+        for t in (range(T) if not seq_c else ()):
             if hm is not None:
                 hprev, hoff = hm, t * BD
             else:

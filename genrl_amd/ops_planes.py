@@ -39,7 +39,7 @@ class _RolloutArgs(_ct.Structure):
                    ('out_b', _FP), ('out_g', _FP), ('out_be', _FP), ('out_eps', _F), ('dist_b', _FP),
                    ('pw0s', _PRef), ('pw0d', _PRef), ('pw', _PRef * 8), ('pb', _FP * 8), ('pg', _FP * 8), ('pbe', _FP * 8),
                    ('peps', _F * 8), ('pU', _I * 8), ('ppre', _FP * 8), ('py', _FP * 8), ('pmean', _FP * 8), ('prstd', _FP * 8),
-                   ('pyp', _PRef * 8), ('head_w', _FP), ('head_b', _FP)])
+                   ('pyp', _PRef * 8), ('head_w', _FP), ('head_b', _FP), ('ln_part', _FP), ('ln_sync', _FP)])
 
 
 class _RolloutBwdArgs(_ct.Structure):
@@ -203,6 +203,9 @@ class _RolloutPlanes(Function):
         pt = lambda t, off: t.data_ptr() + 4 * off
         L = lib()
         seq_c = ops.SEQ_C and planes.gemm_profile is None and len(tape.layers) <= 8
+        # Dense -> LayerNorm -> SiLU as ONE launch where the shape allows (genrl_gemm_h2_ln: policy layers, img_in, img_out: 10 launches per step)
+        fuse_any = planes.ln_fused_here(dev)                 # (per layer: genrl_gemm_h2_ln_ok(N, width), in C and in the Python twin alike)
+        fuse_ln = fuse_any and planes.gemm_ln_ok(N, U, dev)
         if seq_c:
             # the H-step launch loop in C (csrc/seq.hip: genrl_imagine_seq_fwd -- the loop below, launch for launch, from one host call)
             a = _RolloutArgs()
@@ -226,14 +229,21 @@ class _RolloutPlanes(Function):
                 a.pb[l], a.pg[l], a.pbe[l], a.peps[l], a.pU[l] = _p(b_), _p(ga_), _p(be_), eps_, W_.shape[0]
                 a.ppre[l], a.py[l], a.pmean[l], a.prstd[l] = _p(tape.pre[l]), _p(tape.y[l]), _p(tape.mean[l]), _p(tape.rstd[l])
                 a.pyp[l] = _pref(tape.yp[l])
+            if fuse_any:
+                sync_, part_ = planes._ln_workspace(dev)
+                a.ln_part, a.ln_sync = (part_.data_ptr() + 15) // 16 * 16, sync_.data_ptr()
             check(L.genrl_imagine_seq_fwd(_ct.addressof(a), _stream()), 'imagine_seq_fwd')
         for h in (() if seq_c else range(H)):
             r0, r1 = h * N, (h + 1) * N
             tape._forward_planes(h, stoch_p, deter_p, None)
             tape.head_fused(h, pt(eps, h * N * A), pt(raws, h * N * 2 * A), pt(action, r1 * AP), AP, sp.min_std, sp.max_std, act_p, r1)
             # img_in: [stoch_h | action_{h+1}] -> hidden, LN + SiLU
-            planes.gemm(stoch_p, w_in_s, x_pre, U, sp.in_b, N, U, a_row0=r0, A1=act_p, B1=w_in_a, a1_row0=r1, c_off=h * N * U)
-            _ln_fwd(pt(x_pre, h * N * U), sp.in_g, sp.in_be, _p(x), pt(st['xm'], r0), pt(st['xr'], r0), N, U, sp.in_eps, x_p, 0)
+            if fuse_ln:
+                planes.gemm_ln(stoch_p, w_in_s, x_pre, sp.in_b, N, U, sp.in_g, sp.in_be, sp.in_eps, x_p, 0, y=x, mean=st['xm'], rstd=st['xr'],
+                               a_row0=r0, A1=act_p, B1=w_in_a, a1_row0=r1, c_off=h * N * U, m_off=r0)
+            else:
+                planes.gemm(stoch_p, w_in_s, x_pre, U, sp.in_b, N, U, a_row0=r0, A1=act_p, B1=w_in_a, a1_row0=r1, c_off=h * N * U)
+                _ln_fwd(pt(x_pre, h * N * U), sp.in_g, sp.in_be, _p(x), pt(st['xm'], r0), pt(st['xr'], r0), N, U, sp.in_eps, x_p, 0)
             # GRU: [x | deter_h] W_g^T -> LN + gates -> deter_{h+1}
             planes.gemm(x_p, w_g_x, g_pre, 3 * D, None, N, 3 * D, A1=deter_p, B1=w_g_h, a1_row0=r0, c_off=h * N * 3 * D)
             check(L.genrl_gru_gates_fwd_h2(pt(g_pre, h * N * 3 * D), pt(deter, r0 * D), D, _p(sp.gru_g), _p(sp.gru_be),
@@ -241,8 +251,12 @@ class _RolloutPlanes(Function):
                                            deter_p.ptr(r1), deter_p.ld, deter_p.plane, deter_p.inv_ptr(r1), _stream()),
                   'gru_gates_fwd_h2')
             # prior head: img_out (+LN+SiLU), dist, sample
-            planes.gemm(deter_p, w_out, o_pre, U, sp.out_b, N, U, a_row0=r1, c_off=h * N * U)
-            _ln_fwd(pt(o_pre, h * N * U), sp.out_g, sp.out_be, _p(o), pt(st['om'], r0), pt(st['or'], r0), N, U, sp.out_eps, o_p, 0)
+            if fuse_ln:
+                planes.gemm_ln(deter_p, w_out, o_pre, sp.out_b, N, U, sp.out_g, sp.out_be, sp.out_eps, o_p, 0, y=o, mean=st['om'], rstd=st['or'],
+                               a_row0=r1, c_off=h * N * U, m_off=r0)
+            else:
+                planes.gemm(deter_p, w_out, o_pre, U, sp.out_b, N, U, a_row0=r1, c_off=h * N * U)
+                _ln_fwd(pt(o_pre, h * N * U), sp.out_g, sp.out_be, _p(o), pt(st['om'], r0), pt(st['or'], r0), N, U, sp.out_eps, o_p, 0)
             if K == 32 and sp.dist_b is not None:
                 # prior logits AND their sample in one launch: softmax -> unimix -> exponential race in the product's epilogue
                 planes.gemm_sample(o_p, w_dist, logit, SK, sp.dist_b, N, SK, q, SK, UNIMIX, stoch, SK, stoch_p, c_off=r1 * SK,

@@ -271,14 +271,18 @@ def _ln_workspace(dev):
     return ws
 
 
-def gemm_ln_ok(M, N, dev=None):
-    """may y = act(LayerNorm(A B^T + b)) run as ONE launch here?  (shape: N % 64 == 0, N <= 1024, every workgroup resident at once; stream: not
-    one of the side streams; workspace present)"""
+def ln_fused_here(dev=None):
+    """the shape-independent half of gemm_ln_ok: switched on, not on a side stream, workspace present"""
     if not (LN_FUSED and ENABLED):
         return False
     from . import streams
-    return (lib().genrl_gemm_h2_ln_ok(M, N) == 1 and not streams.on_side_stream()
-            and _ln_workspace(dev if dev is not None else torch.cuda.current_device()) is not None)
+    return not streams.on_side_stream() and _ln_workspace(dev if dev is not None else torch.cuda.current_device()) is not None
+
+
+def gemm_ln_ok(M, N, dev=None):
+    """may y = act(LayerNorm(A B^T + b)) run as ONE launch here?  (shape: N % 64 == 0, N <= 1024, every workgroup resident at once; stream: not
+    one of the side streams; workspace present)"""
+    return LN_FUSED and ENABLED and lib().genrl_gemm_h2_ln_ok(M, N) == 1 and ln_fused_here(dev)
 
 
 def gemm_ln(A, B, C, bias, M, N, gamma, beta, eps, out_p, out_row0, y=None, mean=None, rstd=None, act=True, a_row0=0, A1=None, B1=None,

@@ -102,7 +102,7 @@ int genrl_gemm_h2_sample(const uint16_t* a0, long a0_ld, long a0_plane, const fl
  * profiles/r06_xcd_barrier.txt) -- no fence, no cache write-back or invalidate.  genrl_gemm_h2_ln_ok(M, N): N % 64 == 0, N <= 1024 and all
  * cdiv(M, 64) N / 64 workgroups resident at once, at most 32 per XCD (1024 rows at N = 1024).  gamma / beta / C / y / part 16-byte aligned;
  * ldc / ldy / yld % 4 == 0.  part: genrl_gemm_h2_ln_part_floats(M, N) floats of scratch.  sync: genrl_gemm_h2_ln_sync_words() uint32 words,
- * ZEROED ONCE by the caller, then owned by the launches of one stream (the counters re-arm themselves at the end of every launch).  Two such
+ * ZEROED ONCE by the caller, then owned by the launches of one stream (every launch leaves them ready for the next: an arrival counter that only grows + a launch count per row block).  Two such
  * launches must not run concurrently (each would wait for workgroups the other keeps off the CUs): the caller uses it on one stream at a time.
  * sync[0] != 0 after a launch: a barrier timed out or the placement was not b % 8 -- the results are invalid (bounded spin, no hang). */
 int genrl_gemm_h2_ln_ok(int M, int N);
@@ -130,23 +130,6 @@ int genrl_ln_act_bwd_h2u(const float* dy, long lddy, const float* x, long ldx, c
                          const float* mean, const float* rstd, float* dx, long lddx, float* dgamma, float* dbeta, float* dcolsum,
                          float* ws, int M, int N, int act, int accumulate_params, uint16_t* dxp, long ldp, long plane, float* inv,
                          float* amax_ws, void* stream);
-/* State-resident GRU scan, forward (csrc/scan_coop.hip): the recurrence of EnsembleRSSM.observe / VideoSSM.update
- * (agent/dreamer_utils.py:362-371,771-785) over T steps in ONE persistent launch -- D/4 workgroups, each with its 12 columns of
- * the recurrent weight block W_h (rows 0 .. 3D-1, columns 0 .. D-1, row stride ldw) resident in LDS for the whole sequence, the
- * LayerNorm statistics and the new state exchanged behind XCD-hierarchical grid barriers.  pre (T, B, 3D) holds x W_x^T on entry
- * and the full pre-LayerNorm values on return; out (T, B, D); hm (T, B, D) = masked previous states when mask (T, B) != NULL
- * (hm[0] = mask[0] * h0 is the caller's); mean / rstd (T, B): exactly what the backward (genrl_gru_gates_bwd per step) reads.
- * variant 2: two grid barriers per step, B in {4, 8, 16, 32}; variant 1: one barrier per step (every workgroup evaluates all
- * gates, state in LDS), B in {4, 8}.  D % 4 == 0, 8 <= D/4 <= 256 workgroups that must all be resident.  ws:
- * genrl_gru_scan_coop_ws_floats(B, D) floats, 256-byte aligned; ws word 416 (uint32) != 0 afterwards: a barrier timed out
- * (bounded spins: the launch ends early instead of hanging). */
-long genrl_gru_scan_coop_ws_floats(int B, int D);
-/* n XCD-hierarchical grid barriers over G <= 256 workgroups and nothing else (ws: >= 1088 floats, 256-byte aligned): the floor
- * under any per-step exchange of a persistent kernel (scripts/scan_proto.py) */
-int genrl_grid_barrier_bench(float* ws, int n, int G, void* stream);
-int genrl_gru_scan_coop(float* pre, const float* Wh, long ldw, const float* gamma, const float* beta, const float* h0,
-                        const float* mask, float* out, float* hm, float* mean, float* rstd, float* ws, int T, int B, int D,
-                        float eps, int variant, void* stream);
 /* The stride-2 convolution product on planes: C[m, n] (+)= sum_kk patch(m, kk) B[n, kk] (+ bias), the patch matrix of an NHWC image
  * (agent/dreamer_utils.py:604-621 forward; :686-706 input gradient of the transposed convolutions) gathered by the operand DMA
  * itself -- m = (image, oy, ox), kk = (kh k + kw) Cc + c, 16-byte chunks = 8 channels of one pixel.  img: UNIFORM-scale planes
@@ -198,20 +181,6 @@ int genrl_conv1_u8_wgrad(const uint8_t* in, const float* dy, float* dWp, float* 
  * [Nimg][Co][Ho][Wo] (out_nchw != 0) or [Nimg][Ho][Wo][Co], Ho = 2 (Hi - 1) + k.  Supported: k = 6, Ci = 48; GENRL_EINVAL otherwise. */
 int genrl_convt_small_co_fwd(const float* x, const float* Wp, const float* bias, float* out, int Nimg, int Hi, int Wi, int Ci, int Co,
                              int k, int out_nchw, void* stream);
-/* Few-row layers with the LayerNorm in the CONSUMER's loader (csrc/fused_small.hip; the imagination rollout at <= 256 rows, data
- * parallel): C[M][N] = act(A0) W0^T (+ A1 W1^T) + bias, M <= 512, where act = LayerNorm + SiLU of segment 0's rows taken from the
- * PRODUCER's partial statistics (stats0 != NULL: [nparts0][M][2] = (mean, M2) of k0 / nparts0 consecutive columns of every row;
- * gamma0 / beta0 [k0]) or the identity (stats0 == NULL); this product's own partial statistics go to stats_out (!= NULL:
- * [N / 16][M][2], N % 16 == 0) for the next consumer.  W0 [N][k0], W1 [N][k1] k-contiguous; k0, k1 % 4 == 0; 16-byte aligned rows.
- * agent/dreamer_utils.py:739-747 (Dense + LayerNorm + SiLU), :459-473 (img_step). */
-int genrl_small_fused(const float* a0, long a0_ld, const float* w0, long w0_ld, int k0, const float* stats0, int nparts0,
-                      const float* gamma0, const float* beta0, float eps0, const float* a1, long a1_ld, const float* w1, long w1_ld,
-                      int k1, const float* bias, float* C, long ldc, int M, int N, float* stats_out, void* stream);
-/* genrl_actor_head_linear_fwd with the LayerNorm + SiLU in front of the policy's output layer applied inside (y = the RAW rows of
- * the last trunk layer, stats [nparts][R][2] from genrl_small_fused, nparts <= 64) */
-int genrl_actor_head_ln_linear_fwd(const float* y, long ldy, const float* stats, int nparts, const float* gamma, const float* beta,
-                                   float ln_eps, const float* W, const float* b, const float* eps, float* raw, float* action, long R,
-                                   int U, int A, float min_std, float max_std, long ld_action, void* stream);
 /* Backward of genrl_convt_small_co_fwd for an NCHW output gradient dy [Nimg][Co][Ho][Wo] (the decoder's frames): the input gradient dx
  * (fp32 NHWC [Nimg][Hi][Wi][Ci]; NULL: skipped) and the weight gradient dWp ([Ci][k k Co], the permuted weight's own layout; NULL: skipped)
  * with the patch operands gathered from dy itself on the fp32 matrix cores -- no im2col matrix.  ws: genrl_convt_small_co_bwd_ws_floats
@@ -237,7 +206,7 @@ int genrl_gru_seq_bwd(const float* dout, const float* pre, const float* Wh, long
 /* The imagination rollout's H-step launch loop in C (csrc/seq.hip; SURVEY 8b imagine_seq; WorldModel.imagine, agent/dreamer.py:254-287,
  * with the policy of ActorCritic, :323-350): per step the policy's L Dense + LayerNorm + SiLU layers and its output layer + Normal head,
  * then img_step -- [stoch | action] -> hidden, [hidden | deter] -> GRU gates, deter -> hidden -> prior logits + categorical sample -- on
- * plane operands: 16 launches per step, exactly those of genrl_amd/ops_planes.py::_RolloutPlanes.forward in the same order (bit-identical),
+ * plane operands: 16 launches per step (10 with r->ln_sync, below), exactly those of genrl_amd/ops_planes.py::_RolloutPlanes.forward in the same order (bit-identical),
  * from ONE host call.  All buffers are the caller's (genrl_rollout names them); time-major rows h N + n; planes rows likewise. */
 typedef struct { const uint16_t* p; long ld, plane; const float* inv; } genrl_planes_ref;    /* h2 planes [2][rows][ld] + inverse row scales */
 typedef struct {
@@ -257,6 +226,9 @@ typedef struct {
   genrl_planes_ref pw[8]; const float* pb[8]; const float* pg[8]; const float* pbe[8]; float peps[8]; int pU[8];
   float* ppre[8]; float* py[8]; float* pmean[8]; float* prstd[8]; genrl_planes_ref pyp[8];
   const float* head_w; const float* head_b;
+  /* round 6: Dense -> LayerNorm in ONE launch (genrl_gemm_h2_ln) for the policy layers, img_in and img_out where genrl_gemm_h2_ln_ok(N, width):
+   * 10 launches per step instead of 16.  ln_sync == NULL: the 16-launch form.  ln_part / ln_sync: genrl_gemm_h2_ln's workspaces. */
+  float* ln_part; unsigned* ln_sync;
 } genrl_rollout;
 int genrl_imagine_seq_fwd(const genrl_rollout* r, void* stream);
 /* ... and its backward through the frozen dynamics (the dgrad chain of _RolloutPlanes.backward, 10 launches per step, same order): ds / dd
@@ -369,11 +341,6 @@ int genrl_split_x3(const float* x, long ldx, int R, int Cn, uint16_t* out, long 
 int genrl_gemm_x3(const uint16_t* a0, long a0_ld, long a0_plane, const uint16_t* b0, long b0_ld, long b0_plane, int k0,
                   const uint16_t* a1, long a1_ld, long a1_plane, const uint16_t* b1, long b1_ld, long b1_plane, int k1,
                   float* C, long ldc, const float* bias, int M, int N, int accumulate, void* stream);
-/* split-K products of the fp32-operand tile kernel (genrl_sgemm*: few tiles, long K -- the 256-row data-free block): 1
- * (GENRL_SPLITK_INKERNEL=1 in the environment) = the last split to finish a tile adds the partial tiles itself, in split order, and no
- * reduce launch follows; 0 (default: the in-kernel form measured slower) = partial tiles + reduce launch.  Same arithmetic bit
- * for bit.  Returns the previous setting. */
-int genrl_splitk_inkernel(int on);
 int genrl_planes_force_tile(int t);      /* experiments: 0 auto, 1 64x64 tiles, 2 128x128 tiles (both formats) */
 int genrl_planes_variant(int v);         /* experiments: ring depth / L2 prefetch distance of the plane kernels (scripts/cold_bench.py) */
 
