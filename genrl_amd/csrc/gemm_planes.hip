@@ -94,14 +94,17 @@ struct ConvGather {
 // Every workgroup then normalises its own tile from registers and writes y as fp32 (optional) and as h2 planes with ONE scale for the
 // whole tensor, known from gamma / beta alone (|gamma x^ + beta| <= max|gamma| sqrt(N) + max|beta|, |SiLU z| <= |z|: no second exchange
 // for a row maximum; fp16 is a floating-point format, so elements down to 2^-25 of the bound keep all 22 bits).
+// slab of the exchange records for launches with tn column tiles per row block (floats): per-tn slabs keep the record tags of a row block's
+// slots in lockstep (every slot of a slab's row block takes part in exactly the same launches)
+__device__ __host__ __forceinline__ long ln_slab(int tn) { return (long)(tn - 1) * 65536; }
 struct LnEpi {
   const float* gamma; const float* beta;     // [N]; 16-byte aligned
   float eps; int act;                        // act: 1 = SiLU
   float* y; long ldy;                        // fp32 output rows (may be null: planes only)
   u16* yp; long yld, yplane; float* yinv;    // h2 planes of y (+ per-row inverse scale: the same value in every row)
   float* mean; float* rstd;                  // [M] row statistics (for the backward)
-  float* part;                               // exchange slab: [row blocks][tiles_n][64][2] floats
-  unsigned* sync;                            // word 0: failure flag; row block rb: arrival counter at word 32 (1 + 2 rb), its epoch (launches so far) at 32 (2 + 2 rb)
+  float* part;                               // exchange records, ZEROED ONCE: slab ln_slab(tn): [row blocks][tn][64] x {mean, tag, M2, tag}
+  unsigned* sync;                            // word 0: failure flag
 };
 
 // a / b for exact powers of two (exponent arithmetic; clamped to the normal range)
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256, (TM * TN == 1 && NS == 2 && FMT == 1) ? 2 : 1)
   // loads behind the last MFMA, where their latency was exposed once per workgroup
   constexpr int EPI = FMT == 1 ? 4 * (BM + 2 * BN) : 0, EPI_AT = NS * STAGE + (PF ? 1024 : 0);
   // LNE: gamma / beta of all N <= 1024 columns (2 x 4 KiB), reduction scratch
-  constexpr int LN_AT = EPI_AT + EPI, LN_G = LN_AT, LN_B = LN_AT + 4096, LN_R = LN_AT + 8192, LN_U = LN_AT + 9216, LN_BYTES = LNE ? 9472 : 0;
+  constexpr int LN_AT = EPI_AT + EPI, LN_G = LN_AT, LN_B = LN_AT + 4096, LN_R = LN_AT + 8192, LN_U = LN_AT + 9216, LN_T = LN_AT + 9472, LN_BYTES = LNE ? 9728 : 0;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[EPI_AT + EPI + LN_BYTES];
 #if PLANES_ABL == 6       /* ablation 6 (scripts/intercept64.py): the launch alone -- same grid, LDS and register footprint, no work */
   if (M > 0) { if (threadIdx.x == 1023) lds[0] = 0; return; }
@@ -331,6 +334,10 @@ __global__ __launch_bounds__(256, (TM * TN == 1 && NS == 2 && FMT == 1) ? 2 : 1)
                                      (__attribute__((address_space(3))) void*)(uintptr_t)(lds0 + LN_G + 1024 * wave), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ln.beta + f0),
                                      (__attribute__((address_space(3))) void*)(uintptr_t)(lds0 + LN_B + 1024 * wave), 16, 0, 0);
+    // the tag this workgroup's record slot carries from its previous launch (this launch's records carry tag + 1)
+    if (wave == 3)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ln.part + ln_slab(tiles_n) + ((long)(tile_m * tiles_n + tile_n) * 64 + lane) * 4 + 1),
+                                       (__attribute__((address_space(3))) void*)(uintptr_t)(lds0 + LN_T), 4, 0, 0);
   }
   const int nk0 = s0.k / BK, nk = nk0 + s1.k / BK;
   static_assert(NPA == NPB, "square wave grids only (one DMA count per wave)");
@@ -539,25 +546,15 @@ __global__ __launch_bounds__(256, (TM * TN == 1 && NS == 2 && FMT == 1) ? 2 : 1)
     sq += __shfl_xor(sq, 32, 64);
     if (h32 == 0) ldsw(LN_R + 512 + 4 * (wave * 32 + l32), sq);
     __syncthreads();
-    float* const part_rb = ln.part + (long)tile_m * tiles_n * 128;
+    // this tile's record per row: {mean, tag, M2, tag} as ONE 16-byte store; the tag counts this slot's launches (every slot of a row block
+    // has taken part in the same launches: slabs are per column-tile count), so a reader knows a record of THIS launch by its tag -- the
+    // barrier IS the data: no counter, no store acknowledgement to wait for, no atomic
+    float* const part_rb = ln.part + ln_slab(tiles_n) + (long)tile_m * tiles_n * 256;
+    const unsigned tag = __builtin_bit_cast(unsigned, ldsf(LN_T)) + 1u;
+    const float tagf = __builtin_bit_cast(float, tag);
     if (wn == 0 && h32 == 0) {
       const float m2 = ldsf(LN_R + 512 + 4 * (wm * 64 + l32)) + ldsf(LN_R + 512 + 4 * (wm * 64 + 32 + l32));
-      *reinterpret_cast<h2_f32x2*>(part_rb + (tile_n * 64 + rl) * 2) = h2_f32x2{mean_t, m2};
-    }
-    gu32_* const arrive = (gu32_*)(ln.sync + 32 * (1 + 2 * tile_m));
-    gu32_* const epochw = (gu32_*)(ln.sync + 32 * (2 + 2 * tile_m));
-    gu32_* const failw = (gu32_*)ln.sync;
-    // the barrier's target: the counter never goes back -- launch e of this row block waits for (e + 1) tiles_n arrivals, and the LAST
-    // arriver of a launch (every member has read the epoch by then: it read it before its own arrival) moves the epoch on
-    unsigned epoch = 0;
-    if (tid == 0) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(epoch) : "v"(epochw) : "memory");
-    wait_vm<0>();                       // the record has reached the L2 (and the ring's trailing DMAs have landed); the epoch is here
-    if (tid == 0) asm volatile("" : "+v"(epoch));
-    __syncthreads();
-    const unsigned target = (epoch + 1u) * (unsigned)tiles_n;
-    if (tid == 0) {
-      const unsigned old = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (old + 1u == target) __hip_atomic_store(epochw, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *reinterpret_cast<f32x4*>(part_rb + (tile_n * 64 + rl) * 4) = f32x4{mean_t, tagf, m2, tagf};
     }
     // (while the peers arrive) the pre-activation for the backward, and the scale bound from gamma / beta of all N columns
     if (row < M) {
@@ -577,28 +574,35 @@ __global__ __launch_bounds__(256, (TM * TN == 1 && NS == 2 && FMT == 1) ? 2 : 1)
       gm = wave_max(gm); bm = wave_max(bm);
       if (lane == 0) { ldsw(LN_U + 8 * wave, gm); ldsw(LN_U + 8 * wave + 4, bm); }
     }
-    if (tid == 0) {                     // bounded poll (L2-served loads); a timeout (the workgroups were not dealt round-robin) raises the failure word
-      bool ok = false;
-      for (unsigned spins = 0; spins < (1u << 20); ++spins) {
-        if (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = true; break; }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (!ok) __hip_atomic_store(failw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     __syncthreads();
-    // every lane fetches the tiles' records of ITS row (sc1 loads: served by the L2, the L1 is never consulted), all in flight at once, and
-    // combines them itself: mean = the mean of the tile means (equal counts), M2 = sum of the tiles' M2 + 64 sum (tile mean - mean)^2 --
-    // the same arithmetic in the same order in every lane of every workgroup of the row block
-    h2_f32x2 rec[16];
+    // every lane fetches the tiles' records of ITS row (sc1 loads: served by the XCD's L2, the L1 is never consulted), all in flight at once,
+    // until all of them carry this launch's tag (bounded: a timeout raises the failure word), and combines them itself: mean = the mean of the
+    // tile means (equal counts), M2 = sum of the tiles' M2 + 64 sum (tile mean - mean)^2 -- the same arithmetic in every lane of the row block
+    f32x4 rec[16];
     {
-      const float* rp = part_rb + rl * 2;
+      const float* rp = part_rb + rl * 4;
+      bool ok = false;
+      // (bounded: ~20 ms; once the failure word is up -- this launch or an earlier one -- nobody spins any more: results are invalid anyway)
+      for (unsigned spins = 0; spins < (1u << 14); ++spins) {
+        if ((spins & 63u) == 0u && __hip_atomic_load((gu32_*)ln.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
 #pragma unroll
-      for (int jt = 0; jt < 16; ++jt) {
-        const float* pj = rp + min(jt, tiles_n - 1) * 128;
-        asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(rec[jt]) : "v"(pj) : "memory");
+        for (int jt = 0; jt < 16; ++jt) {
+          const float* pj = rp + min(jt, tiles_n - 1) * 256;
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(rec[jt]) : "v"(pj) : "memory");
+        }
+#pragma unroll
+        for (int jt = 0; jt < 16; ++jt) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rec[jt])::"memory");
+        bool all = true;
+#pragma unroll
+        for (int jt = 0; jt < 16; ++jt) {
+          // (element copies first: __builtin_bit_cast applied to the vector ELEMENT lvalue read element 0 -- found in the disassembly)
+          const float t1 = rec[jt][1], t3 = rec[jt][3];
+          all = all && (__builtin_bit_cast(unsigned, t1) == tag) && (__builtin_bit_cast(unsigned, t3) == tag);
+        }
+        if (__all(all)) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(2);
       }
-#pragma unroll
-      for (int jt = 0; jt < 16; ++jt) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rec[jt])::"memory");
+      if (!ok && lane == 0) __hip_atomic_store((gu32_*)ln.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     float mu = 0.f;
 #pragma unroll
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(256, (TM * TN == 1 && NS == 2 && FMT == 1) ? 2 : 1)
 #pragma unroll
     for (int jt = 0; jt < 16; ++jt) {
       const float d = rec[jt][0] - mu;
-      m2 += jt < tiles_n ? rec[jt][1] : 0.f;
+      m2 += jt < tiles_n ? rec[jt][2] : 0.f;
       dv += jt < tiles_n ? d * d : 0.f;
     }
     m2 += 64.f * dv;
@@ -1935,8 +1939,8 @@ int genrl_gemm_h2_ln_ok(int M, int N) {
   const int tn = N / 64, tm = cdiv(M, 64);
   return tm <= 8 * (32 / tn) ? 1 : 0;
 }
-long genrl_gemm_h2_ln_part_floats(int M, int N) { return (long)cdiv(M, 64) * (N / 64) * 128; }
-long genrl_gemm_h2_ln_sync_words(void) { return 32L * (2 + 2 * 256); }
+long genrl_gemm_h2_ln_part_floats(int M, int N) { (void)M; (void)N; return 16L * 65536; }
+long genrl_gemm_h2_ln_sync_words(void) { return 32L; }
 int genrl_gemm_h2_ln(const uint16_t* a0, long a0_ld, long a0_plane, const float* a0_inv, const uint16_t* b0, long b0_ld, long b0_plane,
                      const float* b0_inv, int k0, const uint16_t* a1, long a1_ld, long a1_plane, const float* a1_inv,
                      const uint16_t* b1, long b1_ld, long b1_plane, const float* b1_inv, int k1,

@@ -255,7 +255,7 @@ def gemm(A, B, C, ldc, bias, M, N, accumulate=False, a_row0=0, A1=None, B1=None,
 # for workgroups the other keeps off the CUs), so the fused form is taken on the iteration's MAIN stream only -- never on a side stream of
 # genrl_amd/streams.py -- and its workspace (barrier counters, zeroed once; exchange slab) is one per device, created outside graph capture.
 LN_FUSED = os.environ.get('GENRL_GEMM_LN', '1') != '0'
-_ln_ws = {}              # device index -> (sync words (int32, zeroed once), exchange slab (fp32))
+_ln_ws = {}              # device index -> (failure word (int32), exchange records (fp32; zeroed once: the records carry launch-count tags))
 
 
 def _ln_workspace(dev):
@@ -267,7 +267,7 @@ def _ln_workspace(dev):
             return None              # (first use inside a capture: that call stays unfused; the warm-up iterations create it)
         L = lib()
         ws = _ln_ws[d] = (torch.zeros(L.genrl_gemm_h2_ln_sync_words(), dtype=torch.int32, device=f'cuda:{d}'),
-                          torch.empty(L.genrl_gemm_h2_ln_part_floats(1024, 1024) + 4, device=f'cuda:{d}'))
+                          torch.zeros(L.genrl_gemm_h2_ln_part_floats(1024, 1024) + 4, device=f'cuda:{d}'))
     return ws
 
 
@@ -316,11 +316,11 @@ def check_ln_failure():
     """(synchronises) did a fused Dense -> LayerNorm launch raise its failure word -- a barrier that timed out (its workgroups were not
     co-resident) or a workgroup placement other than b % 8?  Turns the fused form off and raises: results since the last check are invalid."""
     global LN_FUSED
-    for d, (sync, _) in _ln_ws.items():
+    for d, (sync, part) in _ln_ws.items():
         if int(sync[0].item()) != 0:
             LN_FUSED = False
-            sync.zero_()
-            raise GenrlHipError('genrl_gemm_h2_ln: an XCD-local barrier timed out or workgroups were not placed b % 8; '
+            sync.zero_(); part.zero_()
+            raise GenrlHipError('genrl_gemm_h2_ln: the exchange of row statistics inside an XCD timed out (workgroups not dealt round-robin over the XCDs, or not co-resident); '
                                 'the fused Dense -> LayerNorm form is now off (GENRL_GEMM_LN=0 turns it off from the start)')
 
 

@@ -97,14 +97,16 @@ int genrl_gemm_h2_sample(const uint16_t* a0, long a0_ld, long a0_plane, const fl
  * agent/dreamer_utils.py:718-747, :459-473 at <= 1024 columns): C = A0 B0^T (+ A1 B1^T) + bias as genrl_gemm_h2 (C keeps the pre-activation the
  * LayerNorm backward reads), then y = act(LayerNorm(C) gamma + beta) as fp32 rows (y may be NULL) and as h2 planes with ONE scale for the
  * whole tensor (the bound max|gamma| sqrt(N) + max|beta|; yinv[row] holds the same value in every row), mean / rstd [M].  A LayerNorm row spans
- * the N / 64 column tiles of its 64-row block: the launch places those workgroups on ONE XCD (workgroup b runs on XCD b % 8) and they exchange
- * partial row statistics through that XCD's L2 behind a barrier of N / 64 workgroups (0.7 us; a chip-wide barrier costs 3.9,
- * profiles/r06_xcd_barrier.txt) -- no fence, no cache write-back or invalidate.  genrl_gemm_h2_ln_ok(M, N): N % 64 == 0, N <= 1024 and all
- * cdiv(M, 64) N / 64 workgroups resident at once, at most 32 per XCD (1024 rows at N = 1024).  gamma / beta / C / y / part 16-byte aligned;
- * ldc / ldy / yld % 4 == 0.  part: genrl_gemm_h2_ln_part_floats(M, N) floats of scratch.  sync: genrl_gemm_h2_ln_sync_words() uint32 words,
- * ZEROED ONCE by the caller, then owned by the launches of one stream (every launch leaves them ready for the next: an arrival counter that only grows + a launch count per row block).  Two such
- * launches must not run concurrently (each would wait for workgroups the other keeps off the CUs): the caller uses it on one stream at a time.
- * sync[0] != 0 after a launch: a barrier timed out or the placement was not b % 8 -- the results are invalid (bounded spin, no hang). */
+ * the N / 64 column tiles of its 64-row block: the launch places those workgroups on ONE XCD (the dispatcher deals workgroups round-robin; the kernel reads its XCD id) and they exchange
+ * partial row statistics through that XCD's L2 -- no fence, no cache write-back or invalidate, no atomic: every tile stores its rows' records
+ * {mean, tag, M2, tag} (one 16-byte store each) and reads its peers' with L2-served loads until all carry this launch's tag (the tag counts the
+ * slot's launches; profiles/r06_xcd_barrier.txt: a counter barrier of 16 workgroups inside one XCD costs 0.7 us, a chip-wide one 3.9).
+ * genrl_gemm_h2_ln_ok(M, N): N % 64 == 0, N <= 1024 and all cdiv(M, 64) N / 64 workgroups resident at once, at most 32 per XCD (1024 rows at
+ * N = 1024).  gamma / beta / C / y / part 16-byte aligned; ldc / ldy / yld % 4 == 0.  part: genrl_gemm_h2_ln_part_floats(M, N) floats, ZEROED
+ * ONCE by the caller and then owned by the launches of one stream (the record tags live there).  sync: genrl_gemm_h2_ln_sync_words() uint32
+ * words, zeroed once; sync[0] != 0 after a launch: the exchange timed out (bounded spin, no hang) -- the results are invalid and part / sync must
+ * be zeroed again.  Two such launches must not run concurrently (each would wait for workgroups the other keeps off the CUs): the caller
+ * uses it on one stream at a time. */
 int genrl_gemm_h2_ln_ok(int M, int N);
 long genrl_gemm_h2_ln_part_floats(int M, int N);
 long genrl_gemm_h2_ln_sync_words(void);
