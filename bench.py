@@ -138,7 +138,7 @@ WORKLOADS = {
 
 
 # kernel family (the label the library's launch log uses, csrc/common.h: genrl_log_launch) of a rocprofv3 kernel name
-_FAMILIES = (('h2/64', ('gemm_planes_kernel<1, 1, 64',)), ('h2/128', ('gemm_planes_hl_kernel<false>', 'gemm_planes_kernel<2, 2', 'gemm_planes_hlw_kernel<false')),
+_FAMILIES = (('h2/64ln', ('gemm_planes_kernel<1, 1, 64, 3, 1, 3, true, false, 0, true>',)), ('h2/64', ('gemm_planes_kernel<1, 1, 64',)), ('h2/128', ('gemm_planes_hl_kernel<false>', 'gemm_planes_kernel<2, 2', 'gemm_planes_hlw_kernel<false')),
              ('h2/gather128', ('gemm_planes_hl_kernel<true>', 'gemm_planes_hlw_kernel<true')), ('h2tn', ('gemm_planes_tn_kernel<false>',)),
              ('h2tn/conv', ('gemm_planes_tn_kernel<true>',)), ('f32/tile64', ('sgemm_rr_kernel<2', 'sgemm_kernel<64')),
              ('f32/tile128', ('sgemm_rr_kernel<4', 'sgemm_kernel<128')), ('f32/tall', ('sgemm_tall_kernel',)),
@@ -313,6 +313,7 @@ def main():
     ap.add_argument('--no-fp32-mode', action='store_true', help='skip the comparison run with fp32 MFMAs throughout')
     ap.add_argument('--no-traffic', action='store_true', help='skip the two rocprofv3 PMC passes (HBM bytes per GEMM launch)')
     ap.add_argument('--dump-gemm', default='')
+    ap.add_argument('--sync-each-step', action='store_true', help='diagnostic: synchronise after every step (the host never enqueues ahead of the GPU)')
     ap.add_argument('--no-overlap', action='store_true', help='keep the connector updates on the main stream')
     ap.add_argument('--input', default='replay', choices=['replay', 'fixed'],
                     help="replay: every step draws a fresh batch from the device-resident replay store "
@@ -430,12 +431,13 @@ def main():
         # one rank here, tests/test_gpu_bench_dp.py); the in-graph capture of the RCCL collectives, which only the driver's multi-GPU job
         # can execute with real peers, is tried AFTERWARDS under a watchdog (below), so that a hang there still leaves a measured line
         try_ingraph = world > 1 and (backend == 'nccl' or os.environ.get('GENRL_BENCH_FORCE_INGRAPH') == '1') and args.dp_graph != 'cut'   # (the env: tests only)
-        modes = ['cut']
+        modes = ['cut', 'cut'] if planes.LN_FUSED else ['cut']      # (a second try if the fused Dense -> LayerNorm launches had to be switched off)
         for mode in modes:
             try:
                 g_try = GraphedStep(ag, batch, step_fn, warmup=2, collectives=mode)
                 m_try = g_try()
                 torch.cuda.synchronize()
+                planes.check_ln_failure()      # (raises and turns the fused form off if an XCD-local exchange timed out: the next try captures without it)
                 if not ranks_agree(m_try):
                     raise RuntimeError('ranks disagree on the reduced gradient norms after a replayed step')
                 graphed, launch_mode = g_try, ('hipGraph replay' if world == 1 else f'hipGraph replay, collectives {mode}')
@@ -473,6 +475,8 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             m_ = step()
+            if args.sync_each_step:            # (diagnostic: the host never runs ahead of the GPU -- every replay's enqueue is exposed)
+                torch.cuda.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
@@ -489,6 +493,7 @@ def main():
             return step_
         return lambda: step_fn(ag, replay.sample())
     dt, mets = timed(run_step)
+    planes.check_ln_failure()          # (the timed steps' fused Dense -> LayerNorm launches all completed their exchanges: no invalid results in the measurement)
     loss_key = 'model_loss' if 'model_loss' in mets else 'imag_critic_loss'      # (configs[4] has no world-model phase)
     loss = float(mets[loss_key])
     assert np.isfinite(loss), (loss_key, loss)
@@ -732,6 +737,8 @@ def main():
                     return 'gemm_planes_tn_kernel (weight gradients, 128x128)'
                 if 'conv' in tag or 'subpixel' in tag:
                     return 'gemm_planes_hl(w)_kernel<CONV> (patch-gathering 128-wide tiles)'
+                if 'h2ln' in tag:
+                    return 'gemm_planes_kernel 64x64 tile + LayerNorm epilogue (one launch per Dense -> LayerNorm -> SiLU layer)'
                 t64 = -(-p_[0] // 64) * -(-p_[1] // 64)
                 return 'gemm_planes_kernel 64x64 tile' if t64 < 2048 else 'gemm_planes_hl_kernel 128x128 tile'
             return {'bf16_split': 'sgemm_rr_kernel<BF=3>', 'bf16': 'sgemm_rr_kernel<BF=1>'}.get(pipe_of(tag), 'fp32-MFMA kernels (sgemm_rr / tall / direct 3-channel)')
