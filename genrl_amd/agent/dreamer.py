@@ -212,7 +212,6 @@ class WorldModel(Module):  # ref :120-321
 
     def update(self, data, state=None):  # ref :166-187
         streams.join()
-        planes.prefetch()       # (weight planes / permuted conv weights made stale by the last optimiser steps: rebuilt beside the first layer)
         self.train()
         with common.RequiresGrad(self):
             assert not (getattr(self.cfg, 'freeze_decoder', False) or getattr(self.cfg, 'freeze_post', False)
@@ -224,7 +223,6 @@ class WorldModel(Module):  # ref :120-321
             metrics.update(self.model_opt(model_loss, self.parameters(), defer=len(self.detached_update_fns) > 0))
         if len(self.detached_update_fns) > 0:
             detached_loss, metrics = self.update_additional_detached_modules(data, outputs, metrics)
-        streams.join('wprep')   # (planes.prefetch's stream: its work was waited for build by build long ago; no fork outlives the update)
         self.model_opt.flush()
         self.eval()
         return state, outputs, metrics
@@ -279,7 +277,7 @@ class WorldModel(Module):  # ref :120-321
         # DESIGN par.6)
         fork = (getattr(self.cfg, 'overlap_detached', False) and self.rssm.single_obs_posterior
                 and self.cfg.decoder_inputs == 'stoch' and self.grad_heads == ['decoder']
-                and common.Optimizer.grad_reduce is None and os.environ.get('GENRL_FORK_PRIOR', '1') != '0')
+                and common.Optimizer.grad_reduce is None)
         self.rssm.fork_prior = fork
         post, prior = self.rssm.observe(embed, data['action'], data['is_first'], state)
         self.rssm.fork_prior = False
@@ -338,8 +336,7 @@ class WorldModel(Module):  # ref :120-321
         raws = []
         # training rollouts: the policy's H backward passes are batched into one over all H*N rows
         tape = None
-        if (torch.is_grad_enabled() and head_w.requires_grad and horizon > 1 and policy._norm != 'none'
-                and not os.environ.get('GENRL_NO_ACTOR_TAPE')):
+        if torch.is_grad_enabled() and head_w.requires_grad and horizon > 1 and policy._norm != 'none':
             layers = [(getattr(policy, f'dense{i}').weight, getattr(policy, f'dense{i}').bias,
                        getattr(policy, f'norm{i}')._layer.weight, getattr(policy, f'norm{i}')._layer.bias,
                        getattr(policy, f'norm{i}')._layer.eps) for i in range(policy._layers)]
@@ -348,8 +345,7 @@ class WorldModel(Module):  # ref :120-321
             use_planes = planes.ENABLED and N >= ops_planes.min_rows()
             tape = (ops_planes.ActorTapePlanes if use_planes else ops.ActorTape)(horizon, N, layers, head_w, head_b, dev)
             tape.head_leaves = (policy._out._out.weight, policy._out._out.bias, policy._out._std.weight, policy._out._std.bias)
-        fused = (tape is not None and not eval_policy and set(start) == {'stoch', 'deter', 'logit'}
-                 and not os.environ.get('GENRL_NO_ROLLOUT_NODE'))
+        fused = tape is not None and not eval_policy and set(start) == {'stoch', 'deter', 'logit'}
         if fused:
             # the whole H-step loop as one autograd node (ops._Rollout): dynamics dgrad chain + policy tape
             inl, inn = rssm._img_in[0], rssm._img_in[1]._layer

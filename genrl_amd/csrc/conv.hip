@@ -549,7 +549,7 @@ extern "C" int genrl_convt_small_co_fwd(const float* x, const float* Wp, const f
     return GENRL_EINVAL;
   const long nblk = (long)Nimg * (Hi + 2) * ((Wi + 2 + 15) / 16);
   /* resident waves only (5 per SIMD with the weights in LDS: 678 us at 4 096 images against 727 with them in registers, 3 per SIMD) */
-  static const int wg_cap = getenv("GENRL_CONVT_WGS") ? atoi(getenv("GENRL_CONVT_WGS")) : (CONVT_FWD_WLDS ? 1280 : 768);
+  const int wg_cap = CONVT_FWD_WLDS ? 1280 : 768;
   const int blocks = (int)(cdiv(nblk, 4) < wg_cap ? cdiv(nblk, 4) : wg_cap);
   hipLaunchKernelGGL((convt_small_co_fwd_kernel<3, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, Wp, bias, out, Nimg, Hi, Wi, Co,
                      out_nchw);
@@ -908,16 +908,15 @@ extern "C" int genrl_convt_small_co_bwd(const float* x, const float* Wp, const f
   hipStream_t s = (hipStream_t)stream;
   if (dx) {
     const long nblk = (long)Nimg * Hi * ((Wi + 15) / 16);
-    static const int dg_cap = getenv("GENRL_CONVT_DGRAD_WGS") ? atoi(getenv("GENRL_CONVT_DGRAD_WGS")) : 768;      // 3 per CU measured best (768: 456 us, 1024: 468, 2048: 457 at 4 096 images)
+    const int dg_cap = 768;      // 3 per CU measured best (768: 456 us, 1024: 468, 2048: 457 at 4 096 images)
     const int blocks = (int)(cdiv(nblk, 4) < dg_cap ? cdiv(nblk, 4) : dg_cap);
     hipLaunchKernelGGL((convt_small_co_dgrad_kernel<3, 14>), dim3(blocks), dim3(256), 0, s, dy, Wp, dx, Nimg, Hi, Wi, Co);
     GENRL_CHECK_LAUNCH();
   }
   if (dWp) {
     const int Wo = 2 * (Wi - 1) + k;
-    static const int wg_lds = getenv("GENRL_CONVT_WGRAD_LDS") ? atoi(getenv("GENRL_CONVT_WGRAD_LDS")) : 1;       // 0: the round-4 kernel everywhere
-    static const int wg_parts = getenv("GENRL_CONVT_WGRAD_WGS") ? std::min(1024, std::max(64, atoi(getenv("GENRL_CONVT_WGRAD_WGS")))) : 512;
-    const bool staged = wg_lds && (Wo & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+    const int wg_parts = 512;
+    const bool staged = (Wo & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
     const int nparts = staged ? wg_parts : 512;
     if (staged) hipLaunchKernelGGL((convt_small_co_wgrad_lds_kernel<3, 7>), dim3(nparts), dim3(256), 0, s, x, dy, ws, Nimg, Hi, Wi, Co);
     else hipLaunchKernelGGL((convt_small_co_wgrad_kernel<3, 7>), dim3(nparts), dim3(256), 0, s, x, dy, ws, Nimg, Hi, Wi, Co);
@@ -1131,7 +1130,7 @@ extern "C" int genrl_conv1_u8_fwd(const uint8_t* in, const float* Wp, const floa
       (long)Nimg * Ho * ((Wo + 15) / 16) > 0x3fffffffL)
     return GENRL_EINVAL;
   const long nblk = (long)Nimg * Ho * ((Wo + 15) / 16);
-  static const int cap = getenv("GENRL_CONV1_WGS") ? atoi(getenv("GENRL_CONV1_WGS")) : 1024;
+  const int cap = 1024;
   const int blocks = (int)(cdiv(nblk, 4) < cap ? cdiv(nblk, 4) : cap);
   hipLaunchKernelGGL((conv1_u8_fwd_kernel<3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, Wp, bias, y, Nimg, Hi, Wi, Ho, Wo);
   GENRL_CHECK_LAUNCH();

@@ -1306,23 +1306,10 @@ struct SplitPlan {
 // remains the fallback for the others.  Measured alone the two are within 2 % on 1024^3 (27.0 vs 26.6 us) and rr
 // wins from 512 tiles up and for K >= 2048 (1024x3072x1024: 70 vs 74 us, 1024x1024x3072: 70 vs 79 us); inside
 // the training step, where kernels of other streams share the CUs, rr everywhere is 0.85 ms / step faster.
-// GENRL_GEMM_RR=0 disables it (calibration).
-inline bool use_rr(int M, int N, int K, int splits) {
-  static const char* f = getenv("GENRL_GEMM_RR");
-  return !(f && f[0] == '0');
-}
-inline bool use_rr_big() {       // 128x128 products through sgemm_rr_kernel<4> (5-8 % faster than sgemm_kernel<128,128,..>);
-  static const char* f = getenv("GENRL_GEMM_RR128");      // GENRL_GEMM_RR128=0 disables (calibration)
-  return !(f && f[0] == '0');
-}
-inline bool use_tall() {          // GENRL_GEMM_TALL=0 disables sgemm_tall_kernel (calibration)
-  static const char* f = getenv("GENRL_GEMM_TALL");
-  return !(f && f[0] == '0');
-}
-inline bool tall_wide() {         // GENRL_GEMM_TALLW=0: no column slabs (calibration)
-  static const char* f = getenv("GENRL_GEMM_TALLW");
-  return !(f && f[0] == '0');
-}
+inline bool use_rr(int M, int N, int K, int splits) { return true; }
+inline bool use_rr_big() { return true; }       // 128x128 products through sgemm_rr_kernel<4> (5-8 % faster than sgemm_kernel<128,128,..>)
+inline bool use_tall() { return true; }          // sgemm_tall_kernel for the tall 3-channel streams
+inline bool tall_wide() { return true; }         // ... per 112-column slab for wider N
 inline bool force_mid() {       // calibration only: GENRL_GEMM_FORCE=m,<splits>
   static const char* f = getenv("GENRL_GEMM_FORCE");
   return f && f[0] == 'm';
@@ -1388,10 +1375,9 @@ inline SplitPlan plan_split(int M, int N, int K) {
 // took 317 us against 261 us for the 1024 tiles of 16384x1024x1024).  The rows of the full rounds go out as one
 // launch and the remaining rows as a second product planned on its own (64x64 tiles fill the chip again).
 // Alone: 352 -> 324 us; inside the step, where other streams' kernels fill the last round, neutral.
-// Returns the rows of the first part, 0 = no split.  GENRL_GEMM_TAIL=0 disables it (calibration).
+// Returns the rows of the first part, 0 = no split.
 inline int tail_split_rows(int M, int N, int K, const SplitPlan& p) {
-  static const char* f = getenv("GENRL_GEMM_TAIL");
-  if ((f && f[0] == '0') || !p.big || p.splits != 1 || K < 512 || !use_rr_big()) return 0;
+  if (!p.big || p.splits != 1 || K < 512 || !use_rr_big()) return 0;
   const long tn = cdiv(N, 128), tm = cdiv(M, 128), tiles = tm * tn, slots = 512;
   const long left = tiles % slots;
   if (tiles < slots || left == 0 || left * 8 > slots * 3) return 0;
@@ -1502,12 +1488,11 @@ int launch_rr(const float* A, long a_rs, long a_ks, const float* B, long b_rs, l
   constexpr int BT = 32 * WB, BKR = WB == 2 ? 64 : 32;
   // 96-wide tiles for the gathered conv products whose channel dimension is 96 / 192 (a quarter of a 128-wide
   // tile would be padding): N side for the patch-matrix-times-weights product (G == 1), M side for the weight
-  // gradient (G == 2).  GENRL_RR_RECT=0 disables (calibration).
-  static const char* rect_env = getenv("GENRL_RR_RECT");
+  // gradient (G == 2).
   // mode 2 ("split on the big tile"): bf16x3 for the 128x128 tile only, fp32 MFMA for the 64x64 tile (where the
   // operand split costs more VALU time than the bf16 cores save)
   const int mode = g_gemm_bf16 == 2 ? (WB == 4 ? 3 : 0) : g_gemm_bf16;
-  const bool rect_ok = WB == 4 && g_gemm_bf16 != 3 && !(rect_env && rect_env[0] == '0');   // (32x32 blocks need even counts; in mode 2 the 96-wide tiles stay fp32 MFMA)
+  const bool rect_ok = WB == 4 && g_gemm_bf16 != 3;   // (32x32 blocks need even counts; in mode 2 the 96-wide tiles stay fp32 MFMA)
   const bool rect_n = rect_ok && G == 1 && cdiv(N, 96) * 96 < cdiv(N, 128) * 128;
   const bool rect_m = rect_ok && G == 2 && cdiv(M, 96) * 96 < cdiv(M, 128) * 128;
   const int BTM = rect_m ? 96 : BT, BTN = rect_n ? 96 : BT;
@@ -1623,8 +1608,7 @@ static int sgemm_impl(const float* A, long a_rs, long a_ks, const float* B, long
                     (!b_kc || (((b_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0)));
     if (!vec) trace_fallback(M, N, K, a_rs, a_ks, b_rs, b_ks, A, B);
     // M > 32: row groups of 32 rows (MB 2) while that is what fills the chip's 256 CUs, of 64 rows (MB 4) beyond
-    static const int skinny_mb = getenv("GENRL_SKINNY_MB") ? atoi(getenv("GENRL_SKINNY_MB")) : 0;
-    const bool g32 = M > 32 && (skinny_mb ? skinny_mb == 2 : (long)cdiv(N, 16) * cdiv(M, 64) < 512);
+    const bool g32 = M > 32 && (long)cdiv(N, 16) * cdiv(M, 64) < 512;
     dim3 grid(cdiv(N, 16), 1, M <= 32 ? 1 : cdiv(M, g32 ? 32 : 64)), block(1024);
     genrl_log_launch("f32/skinny", M, N, K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
 #define GO(MB, BKC) \

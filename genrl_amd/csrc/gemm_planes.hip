@@ -1607,7 +1607,7 @@ static inline double kk_bytes(long M, long N, long K) { return 4.0 * ((double)M 
 // panels in snake order -- 16384 x 1024 x 1024 122.2 -> 116.8 us, 16384 x 1536 x 1024 180.2 -> 164.8, K = 2048 202.3 -> 197.0 against 0 =
 // row-major over the sub-block (rounds of 4 x 8); the L2-miss bytes do NOT change (201.8 MB per launch either way = the compulsory 6 MB per
 // round of 32 resident tiles: no operand survives from one round to the next in a 4 MiB L2), profiles/r05_hl_order.txt
-static int hl_order() { static const int o = getenv("GENRL_HL_ORDER") ? atoi(getenv("GENRL_HL_ORDER")) : 1; return o; }
+static int hl_order() { return 1; }
 // 128 x 192 tiles (gemm_planes_hlw_kernel) where they pad fewer columns than 128-wide ones (N = 192: the sub-pixel products' 4 x 48
 // columns); GENRL_HL_WIDE=0: never, 2: also where both tilings pad the same (N = 384, 768, 1536: fewer, larger tiles -- experiments)
 static bool use_wide(int N) {
@@ -1618,10 +1618,9 @@ static bool use_wide(int N) {
 }
 // 256 x 96 tiles (gemm_planes_hlw_kernel<.., 3, 4>: four waves along m) for the convolution products with N <= 96 output channels instead of
 // 128 x 128 tiles with a quarter of the columns padding: 173056 x 96 x 1728 281 -> 259 us, but 200704 x 96 x 768 189 -> 196 (twelve half
-// stages behind a longer prologue): from K = 1024 up (GENRL_HL_TALL=0: never, 2: always), profiles/r05_wide_ab.txt
+// stages behind a longer prologue): from K = 1024 up, profiles/r05_wide_ab.txt
 static bool use_tall96(int N, int K) {
-  static const int mode = getenv("GENRL_HL_TALL") ? atoi(getenv("GENRL_HL_TALL")) : 1;
-  return mode != 0 && N <= 96 && (mode == 2 || K >= 1024);
+  return N <= 96 && K >= 1024;
 }
 static bool hl_on() { static const bool on = !getenv("GENRL_PLANES_HL") || getenv("GENRL_PLANES_HL")[0] != '0'; return on; }
 int g_planes_nosplit = 0;        // experiments: 1 = no row split against wave quantisation (GENRL_PLANES_NOSPLIT)
@@ -1653,8 +1652,6 @@ int genrl_split_x3(const float* x, long ldx, int R, int Cn, uint16_t* out, long 
 }
 
 static int xcd_split(int tm, int tn) {   // xm XCDs along m (1, 2, 4, 8) such that the grid divides, squarest sub-block
-  static const char* force = getenv("GENRL_XCD_M");          // experiments: force the split (if it divides the grid)
-  if (force) { const int xm = atoi(force); if (xm > 0 && 8 % xm == 0 && tm % xm == 0 && tn % (8 / xm) == 0) return xm; }
   int best = 0; double bs = 1e30;
   for (int xm = 1; xm <= 8; xm *= 2) {
     const int xn = 8 / xm;
@@ -1759,8 +1756,7 @@ static int gemm_h2_impl(const uint16_t* a0, long a0_ld, long a0_plane, const flo
   const long t64 = (long)cdiv(M, 64) * cdiv(N, 64);
   // (128x128 tiles for the 1024x3072 GRU products -- 192 tiles -- measured neutral in the step: 29.65 vs 29.72 ms)
   const bool big = smp.q ? false : (g_planes_force_tile ? g_planes_force_tile == 2 : t64 >= 2048);
-  static const bool nosplit_env = getenv("GENRL_PLANES_NOSPLIT") != nullptr;
-  if (big && !g_planes_force_tile && !g_planes_nosplit && !nosplit_env) {
+  if (big && !g_planes_force_tile && !g_planes_nosplit) {
     // wave quantisation: one 128x128 tile per CU at a time, so 1088 tiles (17 x 1024 rows, N = 1024) take five rounds of
     // the 256 CUs -- 206 us against 146 for the 1024 tiles of 16384 rows.  When the last, partial round is small and made of
     // whole row panels, those rows go to a second launch (64x64 tiles for 1024 rows: ~14 us).
@@ -1779,25 +1775,22 @@ static int gemm_h2_impl(const uint16_t* a0, long a0_ld, long a0_plane, const flo
     // 128x128 tiles, BK 64, two 64 KiB stages (136 us on 16384x1024x1024 against 146 with BK 32 / four stages; the
     // boundary rescale of a second segment does not fit this tile's register budget: two launches, the second accumulating)
     const int tm = cdiv(M, 128), tn = cdiv(N, 128);
-    static const bool bk32 = getenv("GENRL_H2_BK32") != nullptr;
     const PlaneSeg none{nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, nullptr};
     for (int seg = 0; seg < (k1 ? 2 : 1); ++seg) {
       const PlaneSeg& sg = seg ? s1 : s0;
       const float* bs = seg ? nullptr : bias;
       const int acc = seg ? 1 : accumulate;
       log_launch("h2/128", M, N, sg.k, kk_bytes(M, N, sg.k));
-      if (bk32)
-        gemm_planes_kernel<2, 2, 32, 2, 1, 4, false><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
-                                                                                           xcd_split(tm, tn), SampleEpi{}, ConvGather{}, LnEpi{});
 #ifdef PLANES_EXPERIMENTS
-      else if (g_planes_variant == 1 || g_planes_variant == 6)
+      if (g_planes_variant == 1 || g_planes_variant == 6)
         gemm_planes_kernel<2, 2, 64, 2, 1, 2, false, false, 2><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
                                                                                            xcd_split(tm, tn), SampleEpi{}, ConvGather{}, LnEpi{});
       else if (g_planes_variant == 2 || g_planes_variant == 3)
         gemm_planes_kernel<2, 2, 64, 2, 1, 2, false, false, 4><<<tm * tn, 256, 0, (hipStream_t)stream>>>(sg, none, C, ldc, bs, M, N, acc, tm, tn,
                                                                                            xcd_split(tm, tn), SampleEpi{}, ConvGather{}, LnEpi{});
+      else
 #endif
-      else if (hl_on() && use_wide(N)) {
+      if (hl_on() && use_wide(N)) {
         const int tw = cdiv(N, 192);
         gemm_planes_hlw_kernel<false, 3><<<tm * tw, 256, 0, (hipStream_t)stream>>>(sg, C, ldc, bs, M, N, acc, tm, tw, xcd_split(tm, tw), ConvGather{});
       } else if (hl_on())

@@ -462,17 +462,10 @@ int tn_splits(int NI, int NJ, int M) {
   // Rounds 1-4 rounded tiles x splits to the NEAREST multiple -- 6 tiles x 43 = 258, 24 x 11 = 264, 38 x 7 = 266, 72 x 4 = 288 workgroups:
   // a second round for 2 .. 32 stragglers, i.e. twice the time (round 5, scripts/tn_conv_probe.py: the convolution weight gradients with
   // few output tiles ran at 122-145 TF/s where the 252- and 228-workgroup shapes ran at 240-330).  Now: the split count that minimises
-  // rounds x (stages per split + a fixed cost per round) (ties: fewer splits = fewer partial tiles to reduce); GENRL_TN_SPLIT_NEAREST=1
-  // restores the old rule.
+  // rounds x (stages per split + a fixed cost per round) (ties: fewer splits = fewer partial tiles to reduce).
   const int tiles = cdiv(NI, 128) * cdiv(NJ, 128), stages = M / 64;
   int smax = stages / 8 > 0 ? stages / 8 : 1;               // >= 8 stages per workgroup
   if (smax > 64) smax = 64;                                 // (the workspace holds 64 cref slots)
-  static const bool nearest = getenv("GENRL_TN_SPLIT_NEAREST") != nullptr;
-  if (nearest) {
-    int s = tiles >= 192 ? 1 : (256 + tiles / 2) / tiles;
-    if (s > smax) s = smax;
-    return s < 1 ? 1 : s;
-  }
   // cost in stage times: every round pays its stages plus ~8 stage times of prologue / epilogue / partial-tile traffic (without that
   // term 114 tiles x 400 stages went to 50 splits = 23 rounds of 8 stages: 287 -> 373 us)
   int best = 1; long bc = -1;

@@ -8,7 +8,7 @@
 #include <algorithm>
 
 #include <cstdlib>
-static const bool WAVE_LN = !getenv("GENRL_NO_WAVE_LN");   // wave-per-row LayerNorm kernels (A/B switch)
+static const bool WAVE_LN = true;   // wave-per-row LayerNorm kernels for rows of 256 .. 1024 floats
 #ifdef GENRL_NO_NARROW_LN
 #define NARROW_LN false
 #else
@@ -1475,16 +1475,12 @@ int genrl_onehot_gather_ln_fwd(const int* idx, int S, int K, const float* wT, lo
 }
 
 static inline int blk_grid_cap() {
-  static const int cap = [] { const char* e = getenv("GENRL_BLK_GRID"); const int v = e ? atoi(e) : BLK_GRID; return v < 64 ? 64 : (v > REDUCE2M_MAX ? REDUCE2M_MAX : v); }();
-  return cap;
+  return BLK_GRID;        // (768 / 1 024 workgroups measured within +-0.1 ms on every config: profiles/r05_blkgrid_ab.txt)
 }
 static inline int blk_grid_for(int M) { return M < blk_grid_cap() ? M : blk_grid_cap(); }
 // workgroups of the channel-LayerNorm backward (rows of <= 256 floats, one lane group per row; two 16-byte loads in flight per lane and
-// iteration): 1024 = 4 per CU measured 1.5 % of the c4 step faster than 512 and than 2048 (scripts/r05_lngrid_ab.sh; GENRL_LN_NARROW_GRID)
-static inline int narrow_grid_cap() {
-  static const int cap = [] { const char* e = getenv("GENRL_LN_NARROW_GRID"); const int v = e ? atoi(e) : 1024; return v < 64 ? 64 : (v > REDUCE2M_MAX ? REDUCE2M_MAX : v); }();
-  return cap;
-}
+// iteration): 1024 = 4 per CU measured 1.5 % of the c4 step faster than 512 and than 2048 (profiles/r05_lngrid_ab.txt)
+static inline int narrow_grid_cap() { return 1024; }
 static inline int narrow_grid_for(int M, int gl) { return (int)std::min<long>(cdiv(M, 4 * (64 / gl)), narrow_grid_cap()); }
 
 // workspace: >= genrl_ln_ws_floats(M, N) floats

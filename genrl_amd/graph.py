@@ -78,7 +78,6 @@ class GraphedStep:
                 self._begin()
                 self.metrics = step_fn(agent, self.static_batch)
                 self._end()
-                planes.drop_events()
         except BaseException:
             # leave no stream in capture mode and no half-built state behind: the caller may fall back to eager steps
             if self._g is not None:

@@ -264,7 +264,7 @@ def transpose_last2_raw(x, out=None, accumulate=False):
 
 # ------------------------------------------------------------------ Linear
 
-_NO_PAD = os.environ.get('GENRL_NO_PAD_HEADS') == '1'      # calibration only
+_NO_PAD = False      # (calibration only: two-hot head rows left unpadded)
 
 
 def _rows_ld(t2d):
@@ -1270,7 +1270,7 @@ def _ln_bwd_rows(dy2d, pre2d, gamma, beta, mean, rstd, bias=None):
 
 def _implicit_conv(img, C):
     """The GEMM can gather stride-2 patches itself when every patch segment is 16-byte addressable."""
-    return img.dtype == torch.float32 and C % 4 == 0 and img.data_ptr() % 16 == 0 and not os.environ.get('GENRL_EXPLICIT_IM2COL')
+    return img.dtype == torch.float32 and C % 4 == 0 and img.data_ptr() % 16 == 0
 
 
 class _Conv2dS2(Function):
@@ -1721,7 +1721,7 @@ class _GRUSeq(Function):
         BD, B3D = B * D, B * 3 * D
         # few sequences per GPU: the recurrent dgrad d(hm_t) += dpre_t W_h is a weight stream with only D/16
         # column blocks -> K-split into slabs that the next step's gate backward sums (no reduce launch)
-        S = 4 if (B <= 32 and not os.environ.get('GENRL_NO_SCAN_PARTS') and not _p16()) else 0
+        S = 4 if (B <= 32 and not _p16()) else 0
         pa = torch.empty(S, B, D, device=dev) if S else None
         pb = torch.empty(S, B, D, device=dev) if S else None
         cur, nxt, pcur, pnxt = dha, None, pa, None

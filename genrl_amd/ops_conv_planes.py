@@ -68,7 +68,7 @@ def _uniform_split(x2d):
 
 LAZY_FP32 = os.environ.get('GENRL_CONV_LAZY_FP32', '1') != '0'
 CONV1_DIRECT = os.environ.get('GENRL_CONV1_DIRECT', '1') != '0'
-KEEP_COLS = os.environ.get('GENRL_CONV_KEEP_COLS', '1') != '0'      # the u8 first layer's patch matrix is kept for its weight gradient (one im2col launch less)
+KEEP_COLS = True      # (where the first layer still runs im2col + GEMM) the u8 frames' patch matrix is kept for its weight gradient: one im2col launch less
 
 
 def _ln_fwd(pre2d, gamma, beta, eps, want_planes, want_fp32=True):
@@ -233,7 +233,7 @@ def _subpixel(xp, Nimg, Hi, Wi, Cs, Cp, k, Wsrc, s_ci, s_co, s_tap, bias, out, w
     K = T * T * Cs
 
     def build():
-        # (from the parameter alone when the caller names it -- planes.prefetch may run this again at the next iteration's start: Wsrc is
+        # (from the parameter alone when the caller names it: Wsrc is
         # then this iteration's permuted copy, ops.permuted(wkey) the current one, same layout)
         src = ops.permuted(wkey) if isinstance(wkey, torch.nn.Parameter) else Wsrc
         wsub = torch.empty(4 * Cp, K, device=dev)
@@ -241,8 +241,9 @@ def _subpixel(xp, Nimg, Hi, Wi, Cs, Cp, k, Wsrc, s_ci, s_co, s_tap, bias, out, w
         check(lib().genrl_subpixel_weight(_p(src), s_ci, s_co, s_tap, Cs, Cp, k, T, _p(wsub), _p(bias), _p(b4_), _stream()), 'subpixel_weight')
         return planes.split(wsub), b4_
     # (once per optimiser step when the caller names the parameter the weight comes from; weight and bias are stepped together)
-    bkey = (id(bias), bias._version) if bias is not None else None      # (a bias edited or swapped without its weight rebuilds too)
-    wp, b4 = planes.derived(wkey, ('subpixel', bkey), build) if wkey is not None else build()
+    # (a bias edited or swapped without its weight rebuilds too: its identity + version are part of the entry's freshness check, not of its key)
+    bver = (id(bias), bias._version) if bias is not None else None
+    wp, b4 = planes.derived(wkey, 'subpixel', build, extra=bver) if wkey is not None else build()
     _, Ho, Wo, _ = out.shape
     check(lib().genrl_gemm_h2_subpixel(xq.ptr(), xq.ld, xq.plane, xq.inv_ptr(), Nimg, Hp, Wp, Cs, T, wp.ptr(), wp.ld, wp.plane, wp.inv_ptr(),
                                        _p(out), Ho, Wo, Cp, _p(b4), _stream()), 'gemm_h2_subpixel')
@@ -255,7 +256,7 @@ def _wplanes(wsrc, Wp, transpose):
     """planes of the permuted weight matrix Wp (or of its transpose): once per optimiser step when the parameter it comes from is known"""
     if wsrc is None:
         return planes.split(Wp.detach(), transpose=transpose)
-    shape = tuple(Wp.shape)          # (the builder depends on the parameter alone: planes.prefetch may call it again, see _subpixel)
+    shape = tuple(Wp.shape)
     src = (lambda: ops.permuted(wsrc).reshape(shape)) if isinstance(wsrc, torch.nn.Parameter) else (lambda: Wp.detach())
     return planes.derived(wsrc, ('perm_planes', transpose), lambda: planes.split(src(), transpose=transpose))
 

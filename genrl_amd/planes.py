@@ -78,89 +78,31 @@ class _Desc(ctypes.Structure):          # genrl_split_desc (include/genrl_hip.h)
                 ('transpose', ctypes.c_int)]
 
 
-_dcache = {}             # (id(W), tag) -> [epoch, object derived from W, W.data_ptr(), weakref(W), stream that built it, W._version,
-#                          event recorded after a build AHEAD of use on a side stream (prefetch) or None, streams that waited for it]
-_dbuild = {}             # (id(W), tag) -> the latest builder, in first-use order (dicts keep insertion order): what `prefetch` re-runs
-PREFETCH = int(os.environ.get('GENRL_WPREFETCH', '0'))      # 0 off (default: measured slower), 1 weight planes + derived objects, 2 weight planes only
-_wevent = None           # [event after the weight planes' prefetch, streams that have waited for it]
+_dcache = {}             # (id(W), tag) -> [epoch, object derived from W, W.data_ptr(), weakref(W), stream that built it, (W._version, extra)]
 
 
-def _after(slot):
-    """order the current stream after a prefetch (slot = [event, set of stream handles that already waited -- the recording stream among
-    them from the start: a stream that waits for its own event inside a capture takes the process down, scripts/capture_event_probe.py])"""
-    st = _stream()
-    if st not in slot[1]:
-        torch.cuda.current_stream().wait_event(slot[0])
-        slot[1].add(st)
-
-
-def derived(W, tag, build):
+def derived(W, tag, build, extra=None):
     """build() -- something computed from the parameter W alone (a permuted copy, planes of a rearrangement) -- cached until W is
     invalidated (optimiser step, slow-target copy, load_state_dict: `invalidate`), rebuilt at the first use after that on the stream
-    that uses it; a use on another stream than the one that built it rebuilds too (no cross-stream ordering is assumed) -- unless it
-    was built ahead of its use by `prefetch`, which leaves an event: every stream that uses it waits for that event once.
+    that uses it; a use on another stream than the one that built it rebuilds too (no cross-stream ordering is assumed).
     Inside a captured iteration everything is stale at the capture's start, so every replay rebuilds at the same place.
-    build must depend on W (and tensors that change together with it) ONLY: `prefetch` calls the last one given for a key again."""
+    (Round 5's rebuild-ahead-of-use on a side stream, `prefetch`, measured slower -- profiles/r05_prefetch_ab.txt -- and is gone.)"""
     if not isinstance(W, torch.nn.Parameter):
         return build()
     key, st = (id(W), tag), _stream()
     ent = _dcache.get(key)
-    _dbuild[key] = build
-    # (W._version: an in-place edit made through torch -- p.data.copy_, nn.init, a broadcast of weights, an EMA copy -- is seen without an
-    # explicit invalidate; the optimiser's own kernels write through raw pointers and call invalidate)
-    fresh = ent is not None and ent[0] == _epoch and ent[2] == W.data_ptr() and ent[3]() is W and ent[5] == W._version
-    if fresh and ent[6] is not None:
-        _after(ent[6:8])
-        return ent[1]
+    # (W._version catches in-place edits made through torch ON THE PARAMETER ITSELF -- W.copy_ / nn.init under no_grad, load_state_dict.  It
+    # does NOT see edits through `.data` (its own version counter), through views of the optimiser's flat buffers (a broadcast of weights
+    # into g.flat, an EMA copy) or through raw pointers (the optimiser's kernels): those callers invalidate explicitly -- Optimizer.__call__,
+    # the slow-target copy, bench.resync_weights.  `extra`: a version of something else the object is built from -- the bias of a sub-pixel
+    # weight -- checked here so that a stale entry is REPLACED, not kept beside a new one under another key.)
+    ver = (W._version, extra)
+    fresh = ent is not None and ent[0] == _epoch and ent[2] == W.data_ptr() and ent[3]() is W and ent[5] == ver
     if not fresh or ent[4] != st:
         if ent is None:
-            weakref.finalize(W, _forget, key)
-        ent = _dcache[key] = [_epoch, build(), W.data_ptr(), weakref.ref(W), st, W._version, None, None]
+            weakref.finalize(W, _dcache.pop, key, None)
+        ent = _dcache[key] = [_epoch, build(), W.data_ptr(), weakref.ref(W), st, ver]
     return ent[1]
-
-
-def drop_events():
-    """forget the prefetch events (after a capture: an event recorded in a capturing stream means nothing outside it; a later eager use
-    then follows the plain rules -- rebuild on a stream mismatch, refresh where stale)"""
-    global _wevent
-    _wevent = None
-    for ent in _dcache.values():
-        ent[6] = ent[7] = None
-
-
-def _forget(key):
-    _dcache.pop(key, None)
-    _dbuild.pop(key, None)
-
-
-def prefetch(name='wprep'):
-    """at the start of an iteration: re-split the stale cached weight planes and rebuild the stale derived objects that were last used on
-    the CURRENT stream on side stream `name` instead of at their first use -- ~30 small launches (transposes, splits of 10^4..10^6
-    elements) that sat in the main chain in front of the encoder's second layer and the first RSSM product now run beside the first
-    layer's kernels.  Every later use waits for the event of its own build (derived objects, in first-use order) or of the one batched
-    refresh (weight planes).  The side stream is joined with the others at the iteration's end (streams.join)."""
-    global _wevent
-    if not (PREFETCH and ENABLED):
-        return
-    from . import streams
-    main = _stream()
-    wst = [(key, ent) for key, ent in _wcache.items() if ent[0] != _epoch and ent[4] == main and ent[3]() is not None]
-    dst = []
-    for key, build in (_dbuild.items() if PREFETCH == 1 else ()):
-        ent = _dcache.get(key)
-        W = ent[3]() if ent is not None else None
-        if W is not None and ent[4] == main and not (ent[0] == _epoch and ent[2] == W.data_ptr() and ent[5] == W._version):
-            dst.append((key, W, build))
-    if not wst and not dst:
-        return
-    with streams.fork(name) as s:
-        for key, W, build in dst:
-            ent = _dcache[key] = [_epoch, build(), W.data_ptr(), weakref.ref(W), main, W._version, torch.cuda.Event(), {s.cuda_stream}]
-            ent[6].record(s)
-        if wst:
-            _split_entries(wst, s.cuda_stream)
-            _wevent = [torch.cuda.Event(), {s.cuda_stream}]
-            _wevent[0].record(s)
 
 
 def invalidate(params=None):
@@ -226,8 +168,6 @@ def weight(W, transpose=False, c0=0, c1=None):
     ent[4] = st                       # the stream this weight is used on
     if ent[0] != _epoch:
         _refresh_stale(st)
-    if _wevent is not None:           # (a refresh made ahead of use on the prefetch stream: this stream waits for it once)
-        _after(_wevent)
     return ent[1]
 
 

@@ -89,7 +89,7 @@ def test_act_and_report(agent):
     assert rep['video_clip_pred'].shape == (8, 16, 3, 192, 64)
 
 
-@pytest.mark.parametrize('size', ['tiny', 'full_width', 'tiny_overlap', 'full_width_prefetch'])
+@pytest.mark.parametrize('size', ['tiny', 'full_width', 'tiny_overlap'])
 def test_graph_replay_bit_exact(size, monkeypatch):
     """hipGraph replay == eager launches, BIT FOR BIT, over three consecutive optimiser steps (lr > 0, Adam's device step
     counter, the slow-critic copy every 2nd update, fresh replay batches copied into the static inputs): every metric
@@ -103,9 +103,6 @@ def test_graph_replay_bit_exact(size, monkeypatch):
     over = dict(slow_target_update=2, overlap_detached=(size == 'tiny_overlap'))
     if not size.startswith('full_width'):
         over.update(config.tiny_overrides())
-    if size.endswith('prefetch'):        # planes.prefetch (GENRL_WPREFETCH=1, off by default): the weights' planes rebuilt on a side stream,
-        from genrl_amd import planes     # every use ordered after its build by an event -- eagerly and as graph branches
-        monkeypatch.setattr(planes, 'PREFETCH', 1)
     B, T = 4, 16
     batches = [{k: torch.from_numpy(v).cuda() for k, v in synth_batch(B, T, seed=s_).items()} for s_ in range(3)]
     cache = {}
