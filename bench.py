@@ -237,7 +237,7 @@ def _cpu_model():
 def cpu_baseline(threads=None):
     """The CPU oracle (oracle/, a port of the reference's arithmetic validated against golden vectors generated from
     the reference) timed on this box's host cores as BASELINE.md par.4 asks: 1 warm-up + 3 timed iterations, min and
-    median, on all-core (<= 16 threads: more only add OpenMP overhead at these sizes) and 1-thread legs.  The sample
+    median, on all-core (<= 16 threads: measured on the box's 2 x 64-core EPYC 9575F at B8xT32 -- 1.33 s per iteration on 16 threads, 2.56 on 32, 5.60 on 64, 12.0 on 128: profiles/r06_cpu_threads.txt, scripts/cpu_threads.py) and 1-thread legs.  The sample
     is bounded to ~30 s of CPU work: the all-core leg runs the full configs[1] batch (B32xT32) when a B4xT16 probe
     says 4 iterations fit, otherwise B8xT32 scaled linearly in rows; the 1-thread leg runs configs[0]'s size (B4xT16)."""
     from oracle import genrl_oracle as O
