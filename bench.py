@@ -737,8 +737,8 @@ def main():
                     return 'gemm_planes_tn_kernel (weight gradients, 128x128)'
                 if 'conv' in tag or 'subpixel' in tag:
                     return 'gemm_planes_hl(w)_kernel<CONV> (patch-gathering 128-wide tiles)'
-                if 'h2ln' in tag:
-                    return 'gemm_planes_kernel 64x64 tile + LayerNorm epilogue (one launch per Dense -> LayerNorm -> SiLU layer)'
+                if 'h2ln' in tag:      # (the same kernel template with the LayerNorm epilogue: one family, the sub-total listed beside it)
+                    return 'gemm_planes_kernel 64x64 tile'
                 t64 = -(-p_[0] // 64) * -(-p_[1] // 64)
                 return 'gemm_planes_kernel 64x64 tile' if t64 < 2048 else 'gemm_planes_hl_kernel 128x128 tile'
             return {'bf16_split': 'sgemm_rr_kernel<BF=3>', 'bf16': 'sgemm_rr_kernel<BF=1>'}.get(pipe_of(tag), 'fp32-MFMA kernels (sgemm_rr / tall / direct 3-channel)')
@@ -746,6 +746,7 @@ def main():
         for p_ in prof:
             d = fams.setdefault(family_of(p_), dict(launches=0, ms=0.0, flop=0.0, pipe=pipe_of(p_[5])))
             d['launches'] += 1; d['ms'] += p_[3].elapsed_time(p_[4]); d['flop'] += 2.0 * p_[0] * p_[1] * p_[2]
+        ln_sub = [p_ for p_ in prof if 'h2ln' in p_[5]]
         dk = max(fams, key=lambda k_: fams[k_]['ms'])
         mult = {'fp16_split': 3.0, 'bf16_split': 6.0}.get(fams[dk]['pipe'], 1.0)
         pk = PEAK_F32_MFMA_TFLOPS if fams[dk]['pipe'] == 'fp32_mfma' else PEAK_BF16_MFMA_TFLOPS
@@ -757,6 +758,10 @@ def main():
                                              'frac': ({'fp16_split': 3.0, 'bf16_split': 6.0}.get(v['pipe'], 1.0) * v['flop'] / (v['ms'] * 1e-3) / 1e12
                                                       / (PEAK_F32_MFMA_TFLOPS if v['pipe'] == 'fp32_mfma' else PEAK_BF16_MFMA_TFLOPS))}
                                         for k_, v in fams.items()},
+                           'of_which_64x64_launches_with_the_LayerNorm_epilogue': {
+                               'launches': len(ln_sub), 'ms_per_step': sum(p_[3].elapsed_time(p_[4]) for p_ in ln_sub),
+                               'what': 'Dense -> LayerNorm -> SiLU in ONE launch (genrl_gemm_h2_ln): their time includes the normalisation, the exchange of row '
+                                       'statistics inside an XCD and the y / plane stores that used to be a separate LayerNorm launch'},
                            'note': 'HIP-event time of one single-stream eager step (includes launch gaps; NOT under rocprofv3, whose per-kernel '
                                    'durations in profiles/*kernel_table* run ~15 % higher than untraced)'}
         tot_ms = sum(d['ms_per_step'] for d in pipes.values())

@@ -602,7 +602,11 @@ __global__ __launch_bounds__(256, (TM * TN == 1 && NS == 2 && FMT == 1) ? 2 : 1)
         if (__all(all)) { ok = true; break; }
         __builtin_amdgcn_s_sleep(2);
       }
-      if (!ok && lane == 0) __hip_atomic_store((gu32_*)ln.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!ok) {          // never silently wrong: the failure word for the host, NaN rows for whoever reads the results first
+        if (lane == 0) __hip_atomic_store((gu32_*)ln.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int jt = 0; jt < 16; ++jt) rec[jt][0] = __builtin_nanf("");
+      }
     }
     float mu = 0.f;
 #pragma unroll

@@ -79,11 +79,20 @@ static inline int gemm2_ln(const genrl_rollout* r, const genrl_planes_ref& a, lo
                            const genrl_planes_ref* b1, float* C, const float* bias, int M, int N, const float* g, const float* be, float eps,
                            float* y, float* mean, float* rstd, const genrl_planes_ref& P, long row0, void* st) {
   const bool two = a1 && a1->p;
-  return genrl_gemm_h2_ln(a.p + ar * a.ld, a.ld, a.plane, a.inv + ar, b.p, b.ld, b.plane, b.inv, (int)a.ld,
-                          two ? a1->p + a1r * a1->ld : nullptr, two ? a1->ld : 0, two ? a1->plane : 0, two ? a1->inv + a1r : nullptr,
-                          two ? b1->p : nullptr, two ? b1->ld : 0, two ? b1->plane : 0, two ? b1->inv : nullptr, two ? (int)a1->ld : 0,
-                          C, N, bias, M, N, g, be, eps, 1, y, N, mean, rstd, const_cast<uint16_t*>(P.p) + row0 * P.ld, P.ld, P.plane,
-                          const_cast<float*>(P.inv) + row0, r->ln_part, r->ln_sync, st);
+  const int rc = genrl_gemm_h2_ln(a.p + ar * a.ld, a.ld, a.plane, a.inv + ar, b.p, b.ld, b.plane, b.inv, (int)a.ld,
+                                  two ? a1->p + a1r * a1->ld : nullptr, two ? a1->ld : 0, two ? a1->plane : 0, two ? a1->inv + a1r : nullptr,
+                                  two ? b1->p : nullptr, two ? b1->ld : 0, two ? b1->plane : 0, two ? b1->inv : nullptr, two ? (int)a1->ld : 0,
+                                  C, N, bias, M, N, g, be, eps, 1, y, N, mean, rstd, const_cast<uint16_t*>(P.p) + row0 * P.ld, P.ld, P.plane,
+                                  const_cast<float*>(P.inv) + row0, r->ln_part, r->ln_sync, st);
+  if (rc != GENRL_EINVAL) return rc;
+  // (an operand the fused form does not take -- a pointer off its 16-byte alignment: the two launches it replaces take anything)
+  const int rc2 = genrl_gemm_h2(a.p + ar * a.ld, a.ld, a.plane, a.inv + ar, b.p, b.ld, b.plane, b.inv, (int)a.ld,
+                                two ? a1->p + a1r * a1->ld : nullptr, two ? a1->ld : 0, two ? a1->plane : 0, two ? a1->inv + a1r : nullptr,
+                                two ? b1->p : nullptr, two ? b1->ld : 0, two ? b1->plane : 0, two ? b1->inv : nullptr, two ? (int)a1->ld : 0,
+                                C, N, bias, M, N, 0, st);
+  if (rc2) return rc2;
+  return genrl_ln_act_fwd_h2(C, N, g, be, y, N, mean, rstd, M, N, eps, 1, const_cast<uint16_t*>(P.p) + row0 * P.ld, P.ld, P.plane,
+                             const_cast<float*>(P.inv) + row0, st);
 }
 static inline int ln_h2(const float* pre, const float* g, const float* be, float* y, float* mean, float* rstd, int M, int N, float eps,
                         const genrl_planes_ref& P, long row0, void* st) {

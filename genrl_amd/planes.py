@@ -238,6 +238,19 @@ def gemm_ln(A, B, C, bias, M, N, gamma, beta, eps, out_p, out_row0, y=None, mean
         assert A1.ld == B1.ld and a1_row0 + M <= A1.rows and N <= B1.rows
         k1 = A1.ld
         a1, b1 = (A1.ptr(a1_row0), A1.ld, A1.plane, A1.inv_ptr(a1_row0)), (B1.ptr(0), B1.ld, B1.plane, B1.inv_ptr(0))
+    cptr = C.data_ptr() + 4 * c_off
+    yptr = (y.data_ptr() + 4 * y_off) if y is not None else 0
+    if (cptr | yptr | gamma.data_ptr() | beta.data_ptr() | (bias.data_ptr() if bias is not None else 0)) & 15:
+        # (a parameter or an output row that is not 16-byte aligned -- not the case for the optimiser's flat buffers and torch's own
+        # allocations: the two launches take any alignment)
+        gemm(A, B, C, N, bias, M, N, a_row0=a_row0, A1=A1, B1=B1, a1_row0=a1_row0, c_off=c_off)
+        mean_ = mean if mean is not None else torch.empty(M, device=C.device)
+        rstd_ = rstd if rstd is not None else torch.empty(M, device=C.device)
+        mo = m_off if mean is not None else 0
+        check(lib().genrl_ln_act_fwd_h2(cptr, N, gamma.data_ptr(), beta.data_ptr(), yptr or None, N, mean_.data_ptr() + 4 * mo,
+                                        rstd_.data_ptr() + 4 * (m_off if rstd is not None else 0), M, N, float(eps), int(act),
+                                        out_p.ptr(out_row0), out_p.ld, out_p.plane, out_p.inv_ptr(out_row0), _stream()), 'ln_act_fwd_h2')
+        return
     sync, part = _ln_workspace(C.device)
     check(lib().genrl_gemm_h2_ln(A.ptr(a_row0), A.ld, A.plane, A.inv_ptr(a_row0), B.ptr(0), B.ld, B.plane, B.inv_ptr(0), A.ld, *a1, *b1, k1,
                                  C.data_ptr() + 4 * c_off, N, bias.data_ptr() if bias is not None else None, M, N,

@@ -117,3 +117,63 @@ def test_fused_form_is_refused_where_it_cannot_run():
     with streams.fork('detached'):
         assert not planes.gemm_ln_ok(1024, 1024)        # never on a side stream: two such launches must not run concurrently
     streams.join()
+
+
+@pytest.mark.parametrize('BS,BL', [(32, 32), (8, 32), (16, 16)])
+def test_imagination_update_with_fused_layers_equals_the_two_launch_form(BS, BL, monkeypatch):
+    """update_imag_behavior at full width on 1024 / 256 rollout rows (c2 and its DP-4 per-rank size, c5's 256 rows): Dense -> LayerNorm -> SiLU as
+    ONE launch (10 launches per rollout step) against product + LayerNorm launch (16): sampled latents identical up to near-ties (< 1e-4 of them), every metric within 2e-5,
+    actor / critic gradients within 1e-4 of their norms (the fused form scales its operand planes by a bound instead of the row maximum:
+    same 22 bits per element, other rounding)"""
+    import detgen
+    from param_shapes import agent_param_shapes
+    from oracle import genrl_oracle as O
+    from genrl_amd import config, noise as gnoise, planes
+    from genrl_amd.agent import dreamer_utils as common
+    from test_gpu_iteration import FakeClip
+    monkeypatch.delenv('GENRL_PLANES_MIN_ROWS', raising=False)
+    A, S, K, H, seed = 10, 32, 32, 15, 8
+    ocfg = O.make_cfg(stoch=S, discrete=K, act_dim=A, horizon=H)
+    p = detgen.det_state_dict(agent_param_shapes(ocfg), seed)
+    gen = torch.Generator().manual_seed(seed)
+    idx = torch.randint(0, K, (BS, BL, S), generator=gen)
+    post = dict(stoch=F.one_hot(idx, K).float(), deter=torch.tanh(torch.randn(BS, BL, 1024, generator=gen)), logit=torch.randn(BS, BL, S, K, generator=gen))
+    nz = detgen.iteration_noise(BS, BL, S, K, A, H, seed=seed)['imag']
+
+    def run(fused):
+        monkeypatch.setattr(planes, 'LN_FUSED', fused)
+        calls = []
+        orig = planes.gemm_ln
+        monkeypatch.setattr(planes, 'gemm_ln', lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+        from genrl_amd import ops
+        monkeypatch.setattr(ops, 'SEQ_C', False)           # (the Python twin of the C launch loop: its launches are countable here)
+        zero = dict(lr=0.0, wd=0.0)
+        cfg = config.default_cfg(BS, BL, device='cuda', imag_horizon=H, model_opt=zero, actor_opt=zero, critic_opt=zero)
+        ag = config.make_agent(cfg, act_dim=A)
+        ag.load_state_dict({k: v.cuda() for k, v in p.items()})
+        ag.wm.viclip_model = FakeClip()
+        grads = {}
+        names = {id(q): n for n, q in ag.named_parameters()}
+        common.Optimizer.grad_hook = lambda opt, params: grads.__setitem__(opt, {names[id(q)]: q.grad.detach().clone().cpu() for q in params})
+        try:
+            with gnoise.inject({'imag.act_eps': nz['act_eps'], 'imag.step_q': nz['step_q'], 'imag.target_init_q': nz['target_init_q']}):
+                outputs = dict(post={k: v.cuda() for k, v in post.items()}, is_terminal=torch.zeros(BS, BL, device='cuda'))
+                seq, mets = ag.update_imag_behavior(state=None, outputs=outputs, metrics={}, seq_data=None)
+        finally:
+            common.Optimizer.grad_hook = None
+        torch.cuda.synchronize()
+        planes.check_ln_failure()
+        st = seq['stoch'].detach().argmax(-1).cpu() if isinstance(seq, dict) and 'stoch' in seq else None
+        return {k: float(v) for k, v in mets.items()}, grads, len(calls), st
+    m1, g1, n1, t1 = run(True)
+    m0, g0, n0, t0 = run(False)
+    assert n0 == 0 and n1 >= H * 6, (n1, n0)            # 4 policy layers + img_in + img_out per rollout step (+ the heads' layers)
+    if t1 is not None:                                   # imagined latents: identical up to near-ties (another rounding of the same 22-bit operands)
+        assert (t1 != t0).float().mean().item() < 1e-4
+    for k, v in m0.items():
+        if np.isfinite(v):
+            np.testing.assert_allclose(m1[k], v, rtol=2e-5, atol=1e-6, err_msg=k)
+    for ph in ('actor', 'critic'):
+        num = np.sqrt(sum(float(((g1[ph][n].double() - g0[ph][n].double()) ** 2).sum()) for n in g0[ph]))
+        den = np.sqrt(sum(float((g0[ph][n].double() ** 2).sum()) for n in g0[ph]))
+        assert num <= 1e-4 * den, (ph, num, den)
