@@ -114,6 +114,9 @@ __device__ __forceinline__ float pow2_ratio(float a, float b) {
   return __builtin_bit_cast(float, (unsigned)e << 23);
 }
 
+#ifndef LNE_ABL
+#define LNE_ABL 0      /* ablations of the LayerNorm epilogue (scripts/gemm_ln_abl.sh): 1 no y / plane stores, 2 no wait for the peers' records, 3 no SiLU, 4 no pre-activation store */
+#endif
 #ifndef PLANES_DMA_AUX
 #define PLANES_DMA_AUX 0      /* cache policy bits of the operand DMAs (experiments: 2 = nt) */
 #endif
@@ -557,7 +560,7 @@ __global__ __launch_bounds__(256, (TM * TN == 1 && NS == 2 && FMT == 1) ? 2 : 1)
       *reinterpret_cast<f32x4*>(part_rb + (tile_n * 64 + rl) * 4) = f32x4{mean_t, tagf, m2, tagf};
     }
     // (while the peers arrive) the pre-activation for the backward, and the scale bound from gamma / beta of all N columns
-    if (row < M) {
+    if (row < M && LNE_ABL != 4) {
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int col = n0 + wn * 32 + 8 * gq + 4 * h32;
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(256, (TM * TN == 1 && NS == 2 && FMT == 1) ? 2 : 1)
           const float t1 = rec[jt][1], t3 = rec[jt][3];
           all = all && (__builtin_bit_cast(unsigned, t1) == tag) && (__builtin_bit_cast(unsigned, t3) == tag);
         }
-        if (__all(all)) { ok = true; break; }
+        if (__all(all) || LNE_ABL == 2) { ok = true; break; }
         __builtin_amdgcn_s_sleep(2);
       }
       if (!ok) {          // never silently wrong: the failure word for the host, NaN rows for whoever reads the results first
@@ -638,10 +641,15 @@ __global__ __launch_bounds__(256, (TM * TN == 1 && NS == 2 && FMT == 1) ? 2 : 1)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const float z = (o[4 * gq + v] - mu) * rs * g[v] + b[v];
-          y[v] = ln.act ? siluf_(z) : z;
+          y[v] = (ln.act && LNE_ABL != 3) ? siluf_(z) : z;
         }
+#if LNE_ABL == 1
+        asm volatile("" ::"v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]));
+        if (ln.yp && u_sc == 123.f) {
+#else
         if (ln.y) *reinterpret_cast<float4*>(ln.y + (long)row * ln.ldy + col) = make_float4(y[0], y[1], y[2], y[3]);
         if (ln.yp) {
+#endif
           h2_u32x2 hh, ll;
           unsigned a, bq;
           h2_split2(y[0] * u_sc, y[1] * u_sc, a, bq); hh[0] = a; ll[0] = bq;
