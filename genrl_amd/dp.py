@@ -190,9 +190,25 @@ def install(optimizer_cls, reward_ema_cls, force=False):
         # RCCL orders every collective of the process group on its own stream: the connector's side stream
         # (cfg.overlap_detached) may issue its reductions beside the main stream's (gloo's worker threads give no such order)
         optimizer_cls.overlap_under_dp = dist.get_backend() == 'nccl' and os.environ.get('GENRL_DP_OVERLAP', '1') != '0'
+        # The fused Dense -> LayerNorm launches (planes.gemm_ln) wait for their peer workgroups to be RESIDENT.  Beside RCCL's persistent
+        # kernels (reductions run beside the next phase) -- or beside a second rank sharing the GPU, as in the gloo rehearsals -- that
+        # residency has never been exercised on hardware here: with more than one rank the layers keep their two launches (-0.1 ms of
+        # a 10-15 ms per-rank step given up; GENRL_GEMM_LN=2 keeps the fused form).
+        if dist.get_world_size() > 1 and os.environ.get('GENRL_GEMM_LN') != '2':
+            from . import planes
+            global _ln_fused_before
+            _ln_fused_before = planes.LN_FUSED if _ln_fused_before is None else _ln_fused_before
+            planes.LN_FUSED = False
+
+
+_ln_fused_before = None
 
 
 def uninstall(optimizer_cls, reward_ema_cls):
+    global _ln_fused_before
+    if _ln_fused_before is not None:
+        from . import planes
+        planes.LN_FUSED, _ln_fused_before = _ln_fused_before, None
     optimizer_cls.grad_reduce = None
     optimizer_cls.grad_reduce_async = None
     optimizer_cls.overlap_under_dp = False
