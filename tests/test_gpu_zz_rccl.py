@@ -34,6 +34,8 @@ def _rccl_worker(port, q):
     from genrl_amd.agent import dreamer_utils as common
     from genrl_amd.graph import GraphedStep
     from bench import synth_batch, one_step
+    import faulthandler
+    faulthandler.dump_traceback_later(200, exit=False)       # (a stalled worker says where, on stderr, before the parent gives up on it)
     try:
         torch.cuda.set_device(0)
         over = dict(config.tiny_overrides(), overlap_detached=True)
@@ -77,17 +79,30 @@ def _rccl_worker(port, q):
 
 
 def test_rccl_one_rank_eager_ingraph_and_cut():
+    import queue
     ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    p_ = ctx.Process(target=_rccl_worker, args=(29650 + os.getpid() % 100, q))
-    p_.start()
-    try:
-        item = q.get(timeout=150)
-        assert item[0] == 'ok', item[1]
-        p_.join(timeout=60)
-    finally:
-        if p_.is_alive():
-            p_.terminate()
+    item = None
+    # (a second try on a fresh process and port if the worker does not answer: RCCL's bootstrap on a loaded fresh box has been seen to stall
+    # once in ~10 runs of this file with the product untouched; a worker that ANSWERS with an error fails the test at once)
+    for attempt in range(2):
+        q = ctx.Queue()
+        p_ = ctx.Process(target=_rccl_worker, args=(29650 + (os.getpid() + 37 * attempt) % 100, q))
+        p_.start()
+        try:
+            item = q.get(timeout=240)
+        except queue.Empty:
+            item = None
+        finally:
+            if item is None or item[0] != 'ok':
+                if p_.is_alive():
+                    p_.terminate()
+            p_.join(timeout=60)
+            if p_.is_alive():
+                p_.kill()
+        if item is not None:
+            break
+    assert item is not None, 'the RCCL worker did not answer within 240 s, twice'
+    assert item[0] == 'ok', item[1]
     _, ref, eager, ingraph, cut, n_in, n_cut, drained = item
     assert all(drained), drained           # the deterministic drain (flight recorder) saw the watchdog's list empty every time
     assert n_in == 1, n_in                 # every collective inside the one captured graph
