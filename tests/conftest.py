@@ -12,7 +12,7 @@ def pytest_configure(config):
 
 
 # The plane-operand path (genrl_amd/ops_planes.py) is the one the headline size runs (1024 rollout rows); by default it switches in
-# from 320 rows up.  The parity fixtures are tiny, so the suite lowers that threshold to keep pinning that path against the
+# from 192 rows up.  The parity fixtures are tiny, so the suite lowers that threshold to keep pinning that path against the
 # reference's vectors; test_gpu_planes.py::test_small_rollouts_take_the_fp32_operand_path covers the default policy and the
 # fp32-operand rollout (ops._Rollout).
 os.environ.setdefault('GENRL_PLANES_MIN_ROWS', '0')
